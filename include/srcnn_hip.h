@@ -1,0 +1,173 @@
+/*
+ * srcnn_hip.h -- flat C ABI of libsrcnn_hip.so, the MI355X (gfx950) native
+ * replacement for the Stereo R-CNN inference hot path.
+ *
+ * This is the drop-in boundary.  The reference crosses it with cffi
+ * (torch.utils.ffi) into two CUDA extensions; every entry point below names the
+ * reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless
+ *     the name ends in _host; no torch types;
+ *   - the caller allocates every output and every workspace (query the size
+ *     with the matching *_workspace_bytes); the library never allocates memory
+ *     the caller can see and never frees/syncs behind the caller's back;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the null stream) and is hipGraph-capturable;
+ *   - return value: 0 = SRCNN_OK, negative = error (srcnn_last_error() gives
+ *     text).  The two legacy-named wrappers keep the reference's "1 = ok,
+ *     0 = bad roi shape" convention (roi_align_cuda.c:19-22,39; nms_cuda.c:18).
+ *   - activations are NHWC float32 inside the library; NCHW only at the edge.
+ */
+#ifndef SRCNN_HIP_H
+#define SRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRCNN_OK 0
+#define SRCNN_ERR_ARG (-1)
+#define SRCNN_ERR_HIP (-2)
+#define SRCNN_ERR_WORKSPACE (-3)
+
+typedef void *srcnn_stream_t; /* hipStream_t */
+
+#define SRCNN_API __attribute__((visibility("default")))
+
+SRCNN_API int srcnn_version(void);
+SRCNN_API const char *srcnn_last_error(void);
+
+/* ------------------------------------------------------------------ NMS (A6)
+ * Replaces  int nms_cuda(THCudaIntTensor *keep_out, THCudaTensor *boxes_host,
+ *                        THCudaIntTensor *num_out, float nms_overlap_thresh)
+ *           lib/model/nms/src/nms_cuda.h:4-5, nms_cuda.c:8-19, and the kernel +
+ *           host greedy loop nms_cuda_kernel.cu:31-161.
+ * dets (n, dim>=4) float32 [x1,y1,x2,y2,(score)], ALREADY score-sorted.
+ * keep_out (n) int32, num_out (1) int32 -- both on the device, as in the
+ * reference (nms_gpu.py:8-9).  The greedy reduction also runs on the device:
+ * nothing is copied to the host.
+ */
+SRCNN_API size_t srcnn_nms_workspace_bytes(int n);
+SRCNN_API int srcnn_nms(int *keep_out, const float *dets, int *num_out, int n, int dim, float thresh,
+              void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
+/* nb independent problems of n boxes each (RPN: {left,right} x batch). n_valid (nb) may be NULL. */
+SRCNN_API size_t srcnn_nms_batched_workspace_bytes(int nb, int n);
+SRCNN_API int srcnn_nms_batched(int *keep_out, const float *dets, int *num_out, const int *n_valid,
+                      int nb, int n, int dim, float thresh,
+                      void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
+/* legacy name/return convention: 1 = ok. Scratch comes from a library-owned pool sized at first use. */
+SRCNN_API int nms_cuda(int *keep_out, const float *boxes, int *num_out, int boxes_num, int boxes_dim,
+             float nms_overlap_thresh, srcnn_stream_t stream);
+
+/* ------------------------------------------------------------- ROIAlign (A8)
+ * Replaces  int roi_align_forward_cuda(int aligned_height, int aligned_width,
+ *                 float spatial_scale, THCudaTensor *features,
+ *                 THCudaTensor *rois, THCudaTensor *output)
+ *           lib/model/roi_align/src/roi_align_cuda.h:1-2, roi_align_cuda.c:7-40,
+ *           kernel roi_align_kernel.cu:15-91.
+ * features (B,C,H,W) NCHW, rois (n, roi_cols) [batch,x1,y1,x2,y2], output (n,C,ah,aw).
+ * Returns 1 on success, 0 when roi_cols != 5 (output untouched) -- reference convention.
+ */
+SRCNN_API int roi_align_forward_cuda(int aligned_height, int aligned_width, float spatial_scale,
+                           const float *features, int batch, int channels, int height, int width,
+                           const float *rois, int num_rois, int roi_cols, float *output,
+                           srcnn_stream_t stream);
+/* Fused PyramidRoI_Feat (stereo_rcnn.py:110-139) = level routing (natural log, round half away)
+ * + RoIAlignAvg (modules/roi_align.py:26-29: (A+1)^2 lattice, then 2x2/s1 avg-pool), NHWC maps.
+ * maps[l] is the level-(l+2) map (B, mh[l], mw[l], C) NHWC.  out is (n, A, A, out_cstride) NHWC and
+ * channels [out_coffset, out_coffset+C) are written (lets left|right be concatenated in place). */
+SRCNN_API int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, const int *mw_host,
+                            int channels, float im_height, const float *rois, int num_rois, int A,
+                            float *out, int out_cstride, int out_coffset, srcnn_stream_t stream);
+
+/* ------------------------------------------------- convolution engine (A1-A3, A9, A10)
+ * Replaces the cuDNN calls behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear in
+ * stereo_rcnn/resnet.py:66-146,243-286, rpn/stereo_rpn.py:32-40.  Implicit GEMM on the
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32): y = act(conv(x, w) + bias + residual).
+ * x: (B,H,W,*) NHWC with pixel stride x_cstride floats, Cin must be a multiple of 32.
+ * w: (Cout, KH, KW, Cin) float32 (K-contiguous rows).  Frozen BN is folded by the caller.
+ */
+typedef struct srcnn_conv_desc {
+    const float *x;
+    const float *w;
+    const float *bias;     /* (Cout) or NULL */
+    const float *residual; /* NHWC with pixel stride res_cstride, or NULL */
+    float *y;              /* NHWC, pixel stride y_cstride, channels [y_coffset, y_coffset+Cout) */
+    int B, H, W, Cin, x_cstride;
+    int OH, OW, Cout;
+    int KH, KW, stride, pad;
+    int y_cstride, y_coffset, res_cstride;
+    int relu;
+    int mode;              /* 0 = conv; 1 = ConvTranspose2d(k=2,s=2): Cout = 4*Cq ordered (i,j,co) */
+} srcnn_conv_desc;
+SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
+SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
+
+/* stem input repack: NCHW (B,3,H,W) -> zero-bordered NHWC4 (B, H+6, W+8, 4) so that the 7x7/2
+ * stem (resnet.py:109) becomes 7 taps of 32 contiguous floats for the conv engine. */
+SRCNN_API int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, srcnn_stream_t stream);
+/* MaxPool2d(3, stride 2, pad 0, ceil_mode) NHWC (resnet.py:113). */
+SRCNN_API int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y, int OH, int OW,
+                            srcnn_stream_t stream);
+/* _upsample_add (stereo_rcnn.py:91-108): y = bilinear_align_corners(top -> (H,W)) + lateral, NHWC. */
+SRCNN_API int srcnn_upsample_add(const float *top, int TH, int TW, const float *lateral, int B, int H, int W, int C,
+                       float *y, srcnn_stream_t stream);
+/* MaxPool2d(1, stride 2) (stereo_rcnn.py:39,168): y[b,i,j,:] = x[b,2i,2j,:]. */
+SRCNN_API int srcnn_subsample2(const float *x, int B, int H, int W, int C, float *y, int OH, int OW, srcnn_stream_t stream);
+/* layout edge helpers */
+SRCNN_API int srcnn_nhwc_to_nchw(const float *x, int B, int H, int W, int C, float *y, srcnn_stream_t stream);
+SRCNN_API int srcnn_nchw_to_nhwc(const float *x, int B, int C, int H, int W, float *y, srcnn_stream_t stream);
+
+/* ---------------------------------------------------- stereo RPN scoring + proposals (A3-A5)
+ * head: (B, hw, head_cstride>=24) NHWC rows of one level's fused 1x1 heads, channels [0,6) =
+ * RPN_cls_score logits, [6,24) = RPN_bbox_pred_left_right.  Writes that level's slice of probs
+ * (B, A, 2) and deltas (B, A, 6) (anchor index = level_offset + loc*3 + a) in the reference's
+ * flattened order, reproducing the (c, c+3) softmax pairing quirk (stereo_rpn.py:81-83,89-91). */
+SRCNN_API int srcnn_rpn_score(const float *head, int B, int hw, int head_cstride, float *probs, float *deltas,
+                    int level_offset, int num_anchors_total, srcnn_stream_t stream);
+/* Whole _ProposalLayer.forward (proposal_layer.py:42-145): anchors (generate_anchors.py:112-173),
+ * decode+clip (bbox_transform.py:79-104,177-185), stable descending sort / top pre_nms,
+ * NMS(left) & NMS(right), sorted intersection, first post_nms, zero pad, batch index in col 0.
+ * probs (B, A, 2), deltas (B, A, 6); level_hw_host: nlevels x {H, W}; rois_* (B, post_nms, 5). */
+SRCNN_API size_t srcnn_proposal_workspace_bytes(int B, int num_anchors, int pre_nms, int post_nms);
+SRCNN_API int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num_anchors,
+                         const int *level_hw_host, int nlevels, const float *im_info /* (B,3) device */,
+                         int pre_nms, int post_nms, float nms_thresh,
+                         float *rois_left, float *rois_right, int *num_valid /* (B) device, may be NULL */,
+                         void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
+
+/* ------------------------------------------------------------------ heads (A9-A12)
+ * cls softmax over n_cls logits (stereo_rcnn.py:257). */
+SRCNN_API int srcnn_softmax_rows(const float *x, int rows, int cols, int x_stride, float *y, srcnn_stream_t stream);
+/* keypoint tail (stereo_rcnn.py:262-271): logits (n, G, G, 6) NHWC from kpts_class ->
+ * sum over H, softmax over 4*G (kpts) and G (left/right borders). */
+SRCNN_API int srcnn_kpts_tail(const float *logits, int n, int G, float *kpts_prob, float *left_prob, float *right_prob,
+                    srcnn_stream_t stream);
+/* detection decode (demo.py:144-218, bbox_transform.py:133-155) for B == 1 blocks of n rois. */
+SRCNN_API int srcnn_decode_detections(const float *rois_left, const float *rois_right, const float *bbox_pred,
+                            const float *dim_orien_pred, const float *kpts_prob, const float *left_prob,
+                            const float *right_prob, const float *im_info, int n, int n_cls, int G,
+                            float *boxes_left, float *boxes_right, float *dim_orien, float *kpts,
+                            srcnn_stream_t stream);
+/* per-class filter + sort + NMS (demo.py:231-257): scores (n, n_cls) column j; outputs the kept
+ * ORIGINAL roi indices in descending score order and their count, all on the device. */
+SRCNN_API size_t srcnn_class_nms_workspace_bytes(int n);
+SRCNN_API int srcnn_class_nms(const float *scores, int n, int n_cls, int j, const float *boxes_left /* (n,4*n_cls) */,
+                    float score_thresh, float nms_thresh, int *keep_idx, int *num_keep,
+                    void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
+
+/* ------------------------------------------------------------------ profiling hooks
+ * When enabled, every conv-engine launch is bracketed by hipEvents on its stream; the
+ * accumulated kernel time / algorithmic flops / launch count are read back with
+ * srcnn_prof_read (which synchronises those events). Used by bench.py for `roofline`. */
+SRCNN_API int srcnn_prof_enable(int on);
+SRCNN_API int srcnn_prof_read(double *conv_ms, double *conv_flops, long long *conv_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRCNN_HIP_H */

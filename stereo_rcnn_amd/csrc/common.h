@@ -1,0 +1,63 @@
+// Shared helpers for libsrcnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/srcnn_hip.h"
+
+namespace srcnn {
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(srcnn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return SRCNN_ERR_HIP;
+    }
+    return SRCNN_OK;
+}
+
+#define SRCNN_HIP_TRY(expr)                                                     \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) {                                                 \
+            ::srcnn::set_error("%s failed: %s", #expr, hipGetErrorString(_e));  \
+            return SRCNN_ERR_HIP;                                               \
+        }                                                                       \
+    } while (0)
+
+#define SRCNN_REQUIRE(cond, msg)                         \
+    do {                                                 \
+        if (!(cond)) {                                   \
+            ::srcnn::set_error("%s: %s", __func__, msg); \
+            return SRCNN_ERR_ARG;                        \
+        }                                                \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// carve 256-byte aligned chunks out of a caller-provided workspace
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *p) : base(static_cast<char *>(p)), off(0) {}
+    template <typename T>
+    T *take(size_t count)
+    {
+        T *r = reinterpret_cast<T *>(base + off);
+        off += align_up(count * sizeof(T), 256);
+        return r;
+    }
+};
+
+// profiling hooks (conv engine)
+bool prof_enabled();
+void prof_begin(hipStream_t s);
+void prof_end(hipStream_t s, double flops);
+
+}  // namespace srcnn

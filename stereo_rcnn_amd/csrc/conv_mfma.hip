@@ -1,0 +1,343 @@
+// Convolution engine: implicit GEMM on the gfx950 fp32 matrix core.
+//
+// Replaces the cuDNN convolutions behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear on the
+// reference's hot path (stereo_rcnn/resnet.py:66-146,243-286; rpn/stereo_rpn.py:32-40).
+//
+//   y[m, n] = act( sum_k A[m, k] * W[n, k] + bias[n] + residual[m, n] )
+//   m = (b, oh, ow)   k = (kh, kw, c)   n = cout          NHWC activations, W = [Cout][KH][KW][Cin]
+//
+// Design (MI355X-first, not a cuDNN/CUTLASS shape):
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 157 TF peak.  It is paced at
+//     64 cycles/instruction, so LDS/HBM pressure per flop is 16x lower than a bf16 GEMM: a 2x2
+//     wave grid with (32*MR)x(32*NR) wave tiles saturates the pipe without deep pipelining.
+//   * K order inside a 32-wide K tile is permuted so that ONE ds_read_b128 feeds FOUR MFMAs:
+//     lane (i, g) reads k = kk*8 + g*4 .. +3 of row i; MFMA s pairs k=kk*8+s (g=0) with
+//     k=kk*8+4+s (g=1) on both operands.  The sum over k is order-independent in exact
+//     arithmetic; in fp32 it is one fixed, deterministic order.
+//   * LDS rows are 32 floats + 4 pad (144 B): the 16-lane groups of ds_read_b128 then touch 16
+//     distinct 4-bank slots -> conflict-free; ds_write_b128 writes one row per 8 lanes.
+//   * im2col is never materialised: a K tile is 32 contiguous channels of one (kh, kw) tap,
+//     i.e. one 128-B run per output pixel, fetched as 8 lanes x 16 B (coalesced), zero-filled
+//     outside the image.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t;
+//     LDS is double-buffered -> one barrier per K tile.
+//   * 256 CUs / 8 XCDs: tile ids are remapped so that consecutive logical tiles (which share the
+//     activation rows) run on the same XCD and hit its L2; small-M layers use split-K so that
+//     the grid still covers the chip (partials in the caller's workspace, deterministic reduce).
+//   * epilogue fuses folded-BN bias, residual add, ReLU, channel-offset writes (concat in place)
+//     and the ConvTranspose2d(2,2) pixel scatter.
+#include "common.h"
+
+namespace srcnn {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;          // floats per K tile (128 B)
+constexpr int LDS_ROW = BK + 4; // padded row (floats)
+
+struct ConvArgs {
+    const float *x, *w, *bias, *res;
+    float *y, *partial;
+    int H, W, Cin, xcs;
+    int OH, OW, Cout;
+    int KH, KW, stride, pad;
+    int ycs, yco, rcs, relu, mode;
+    int M, K;
+    int ctiles;       // Cin / 32
+    int nkt;          // K tiles in total
+    int kt_per_split; // K tiles per grid.y slice
+    int mtiles, ntiles;
+};
+
+template <int MR, int NR>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p)
+{
+    constexpr int BM = 64 * MR, BN = 64 * NR;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32;   // float4 loads per thread per tile
+    __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * LDS_ROW];
+
+    const int t = threadIdx.x;
+    // ---- XCD-aware tile mapping (bijective; blocks b -> XCD b%8)
+    const int nblk = p.mtiles * p.ntiles;
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int mt = logical / p.ntiles, nt = logical - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_end = min(p.nkt, kt_begin + p.kt_per_split);
+
+    // ---- per-thread staging geometry
+    const int lrow = t >> 3;          // 0..31
+    const int lcol = (t & 7) * 4;     // float offset inside the 32-float run
+    int a_ih0[A_LD], a_iw0[A_LD], a_pix[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int ohw = p.OH * p.OW;
+            const int b = m / ohw;
+            const int rem = m - b * ohw;
+            const int oh = rem / p.OW;
+            const int ow = rem - oh * p.OW;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
+            a_pix[i] = (b * p.H + a_ih0[i]) * p.W + a_iw0[i];
+        } else {
+            a_ih0[i] = -(1 << 28);
+            a_iw0[i] = 0;
+            a_pix[i] = 0;
+        }
+    }
+    const float *b_ptr[B_LD];
+    bool b_ok[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        b_ok[i] = n < p.Cout;
+        b_ptr[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + lcol;
+    }
+
+    float4 ra[A_LD], rb[B_LD];
+    auto load_tile = [&](int kt) {
+        const int tap = kt / p.ctiles;
+        const int c0 = (kt - tap * p.ctiles) * BK;
+        const int kh = tap / p.KW;
+        const int kw = tap - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const int pix = ok ? a_pix[i] + kh * p.W + kw : 0;
+            const float4 v = *reinterpret_cast<const float4 *>(p.x + (size_t)pix * p.xcs + c0 + lcol);
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(b_ptr[i] + (size_t)kt * BK);
+            rb[i] = b_ok[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float *sa = smem[buf];
+        float *sb = smem[buf] + BM * LDS_ROW;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            *reinterpret_cast<float4 *>(sa + (lrow + 32 * i) * LDS_ROW + lcol) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            *reinterpret_cast<float4 *>(sb + (lrow + 32 * i) * LDS_ROW + lcol) = rb[i];
+    };
+
+    // ---- wave geometry
+    const int wave = t >> 6, lane = t & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lg = lane >> 5;
+    floatx16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1);
+        const float *sa = smem[buf] + (wm * 32 * MR + li) * LDS_ROW + lg * 4;
+        const float *sb = smem[buf] + BM * LDS_ROW + (wn * 32 * NR + li) * LDS_ROW + lg * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 fa[MR], fb[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) fa[i] = *reinterpret_cast<const float4 *>(sa + i * 32 * LDS_ROW + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) fb[j] = *reinterpret_cast<const float4 *>(sb + j * 32 * LDS_ROW + kk * 8);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const bool split = gridDim.y > 1;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + li;
+            if (col >= p.Cout) continue;
+            const float bv = (!split && p.bias) ? p.bias[p.mode == 1 ? col % (p.Cout >> 2) : col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wm * MR + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (split) {
+                    p.partial[((size_t)blockIdx.y * p.M + row) * p.Cout + col] = v;
+                    continue;
+                }
+                v += bv;
+                if (p.mode == 0) {
+                    if (p.res) v += p.res[(size_t)row * p.rcs + col];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[(size_t)row * p.ycs + p.yco + col] = v;
+                } else {   // ConvTranspose2d(k=2, s=2): col = (i2*2 + j2)*Cq + co
+                    const int cq = p.Cout >> 2;
+                    const int ij = col / cq, co = col - ij * cq;
+                    const int ohw = p.OH * p.OW;
+                    const int b = row / ohw, rem = row - b * ohw;
+                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    const size_t opix = ((size_t)b * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[opix * p.ycs + p.yco + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// deterministic split-K reduction + epilogue (mode 0 only)
+__global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
+{
+    const size_t total = (size_t)p.M * p.Cout;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / p.Cout), col = (int)(idx - (size_t)row * p.Cout);
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += p.partial[(size_t)s * total + idx];
+        if (p.bias) v += p.bias[col];
+        if (p.res) v += p.res[(size_t)row * p.rcs + col];
+        if (p.relu) v = fmaxf(v, 0.f);
+        p.y[(size_t)row * p.ycs + p.yco + col] = v;
+    }
+}
+
+struct Plan {
+    int mr, nr, splits, kt_per_split;
+};
+
+static Plan make_plan(int M, int N, int nkt, int mode)
+{
+    static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+    Plan pl{1, 1, 1, nkt};
+    const long target = 512;   // >= 2 workgroups per CU
+    bool found = false;
+    for (auto &c : cand) {
+        if (c[1] == 2 && N <= 64) continue;
+        long blocks = (long)cdiv(M, 64 * c[0]) * cdiv(N, 64 * c[1]);
+        if (blocks >= target) {
+            pl.mr = c[0];
+            pl.nr = c[1];
+            found = true;
+            break;
+        }
+    }
+    if (!found) {
+        pl.mr = 1;
+        pl.nr = 1;
+        long blocks = (long)cdiv(M, 64) * cdiv(N, 64);
+        if (mode == 0 && blocks < 256 && nkt >= 16) {
+            int s = (int)((target + blocks - 1) / blocks);
+            s = min(s, nkt / 8);   // keep >= 8 K tiles per slice
+            s = min(s, 32);
+            if (s > 1) {
+                pl.kt_per_split = cdiv(nkt, s);
+                pl.splits = cdiv(nkt, pl.kt_per_split);
+            }
+        }
+    }
+    return pl;
+}
+
+static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
+{
+    SRCNN_REQUIRE(d && d->x && d->w && d->y, "null pointer");
+    SRCNN_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, "Cin must be a positive multiple of 32");
+    SRCNN_REQUIRE(d->x_cstride % 4 == 0, "x_cstride must be a multiple of 4 floats (16-B loads)");
+    SRCNN_REQUIRE(d->B > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "bad output shape");
+    SRCNN_REQUIRE(d->mode == 0 || (d->mode == 1 && d->Cout % 4 == 0 && d->KH == 1 && d->KW == 1 && !d->residual),
+                  "bad mode");
+    a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->residual; a.y = d->y; a.partial = nullptr;
+    a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.xcs = d->x_cstride;
+    a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.ycs = d->y_cstride; a.yco = d->y_coffset; a.rcs = d->res_cstride; a.relu = d->relu; a.mode = d->mode;
+    const long long M = (long long)d->B * d->OH * d->OW;
+    SRCNN_REQUIRE(M < (1LL << 31) && (long long)d->B * d->H * d->W < (1LL << 31), "tensor too large");
+    a.M = (int)M;
+    a.K = d->KH * d->KW * d->Cin;
+    a.ctiles = d->Cin / BK;
+    a.nkt = a.K / BK;
+    return SRCNN_OK;
+}
+
+template <int MR, int NR>
+static void launch(const ConvArgs &a, int splits, hipStream_t st)
+{
+    hipLaunchKernelGGL((conv_mfma_kernel<MR, NR>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
+}
+
+}  // namespace srcnn
+
+extern "C" {
+
+size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d)
+{
+    using namespace srcnn;
+    ConvArgs a;
+    if (fill_args(d, a) != SRCNN_OK) return 0;
+    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode);
+    if (pl.splits <= 1) return 256;
+    return align_up((size_t)pl.splits * a.M * a.Cout * sizeof(float), 256);
+}
+
+int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    ConvArgs a;
+    int rc = fill_args(d, a);
+    if (rc != SRCNN_OK) return rc;
+    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode);
+    a.kt_per_split = pl.kt_per_split;
+    a.mtiles = cdiv(a.M, 64 * pl.mr);
+    a.ntiles = cdiv(a.Cout, 64 * pl.nr);
+    if (pl.splits > 1) {
+        const size_t need = (size_t)pl.splits * a.M * a.Cout * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+            set_error("srcnn_conv2d: workspace too small (%zu < %zu)", workspace_bytes, need);
+            return SRCNN_ERR_WORKSPACE;
+        }
+        a.partial = static_cast<float *>(workspace);
+    }
+    hipStream_t st = as_stream(stream);
+    const bool prof = prof_enabled();
+    if (prof) prof_begin(st);
+    if (pl.mr == 2 && pl.nr == 2) launch<2, 2>(a, pl.splits, st);
+    else if (pl.mr == 2 && pl.nr == 1) launch<2, 1>(a, pl.splits, st);
+    else if (pl.mr == 1 && pl.nr == 2) launch<1, 2>(a, pl.splits, st);
+    else launch<1, 1>(a, pl.splits, st);
+    if (pl.splits > 1) {
+        const size_t total = (size_t)a.M * a.Cout;
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a, pl.splits);
+    }
+    if (prof) prof_end(st, 2.0 * (double)a.M * (double)a.Cout * (double)a.K);
+    return check_launch("srcnn_conv2d");
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+// HBM-bound NHWC helpers of the trunk/FPN: stem repack, ceil-mode max-pool,
+// align_corners bilinear upsample + add, stride-2 subsample, layout edge transposes.
+// All are one-pass, channel-vectorised (float4 = 16 B/lane, coalesced over C).
+//
+// Reference semantics: resnet.py:113 (MaxPool2d(3,2,0,ceil_mode=True)),
+// stereo_rcnn.py:91-108 (_upsample_add; torch-0.3 bilinear == align_corners=True),
+// stereo_rcnn.py:39,168 (MaxPool2d(1, stride=2)).
+#include "common.h"
+
+namespace srcnn {
+
+// NCHW (B,3,H,W) -> NHWC4 with a zero border: out (B, H+6, W+8, 4); pixel (y,x) -> (y+3, x+3).
+__global__ void stem_pack_kernel(const float *__restrict__ im, int B, int H, int W, float4 *__restrict__ out)
+{
+    const int HP = H + 6, WP = W + 8;
+    const size_t total = (size_t)B * HP * WP;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int xp = (int)(idx % WP);
+        const int yp = (int)((idx / WP) % HP);
+        const int b = (int)(idx / ((size_t)WP * HP));
+        const int y = yp - 3, x = xp - 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const float *p = im + (size_t)b * 3 * H * W + (size_t)y * W + x;
+            v.x = p[0];
+            v.y = p[(size_t)H * W];
+            v.z = p[(size_t)2 * H * W];
+        }
+        out[idx] = v;
+    }
+}
+
+__global__ void maxpool3x3s2_kernel(const float4 *__restrict__ x, int B, int H, int W, int C4, float4 *__restrict__ y,
+                                    int OH, int OW)
+{
+    const size_t total = (size_t)B * OH * OW * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        size_t r = idx / C4;
+        const int ow = (int)(r % OW);
+        r /= OW;
+        const int oh = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const int h0 = oh * 2, w0 = ow * 2;
+        const int h1 = min(h0 + 3, H), w1 = min(w0 + 3, W);   // ceil_mode windows are clipped at the edge
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                const float4 v = x[(((size_t)b * H + h) * W + w) * C4 + c];
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+            }
+        y[idx] = m;
+    }
+}
+
+// y = bilinear(top, align_corners=True -> (H,W)) + lateral.  Index/weight arithmetic follows
+// ATen's upsample_bilinear2d (area_pixel_compute_scale: (in-1)/(out-1); h1 = (int)h1r;
+// lambda = h1r - h1), accumulation order w0*(... ) as written there.
+__global__ void upsample_add_kernel(const float4 *__restrict__ top, int TH, int TW, const float4 *__restrict__ lat,
+                                    int B, int H, int W, int C4, float4 *__restrict__ y)
+{
+    const float rh = H > 1 ? (float)(TH - 1) / (float)(H - 1) : 0.f;
+    const float rw = W > 1 ? (float)(TW - 1) / (float)(W - 1) : 0.f;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        size_t r = idx / C4;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        const float h1r = rh * (float)h;
+        const int h1 = (int)h1r;
+        const int h1p = (h1 < TH - 1) ? 1 : 0;
+        const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+        const float w1r = rw * (float)w;
+        const int w1 = (int)w1r;
+        const int w1p = (w1 < TW - 1) ? 1 : 0;
+        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        const float4 *t0 = top + (((size_t)b * TH + h1) * TW + w1) * C4 + c;
+        const float4 a = t0[0], bb = t0[(size_t)w1p * C4];
+        const float4 cc = t0[(size_t)h1p * TW * C4], d = t0[((size_t)h1p * TW + w1p) * C4];
+        const float4 l = lat[idx];
+        float4 o;
+        o.x = (h0l * (w0l * a.x + w1l * bb.x) + h1l * (w0l * cc.x + w1l * d.x)) + l.x;
+        o.y = (h0l * (w0l * a.y + w1l * bb.y) + h1l * (w0l * cc.y + w1l * d.y)) + l.y;
+        o.z = (h0l * (w0l * a.z + w1l * bb.z) + h1l * (w0l * cc.z + w1l * d.z)) + l.z;
+        o.w = (h0l * (w0l * a.w + w1l * bb.w) + h1l * (w0l * cc.w + w1l * d.w)) + l.w;
+        y[idx] = o;
+    }
+}
+
+__global__ void subsample2_kernel(const float4 *__restrict__ x, int B, int H, int W, int C4, float4 *__restrict__ y,
+                                  int OH, int OW)
+{
+    const size_t total = (size_t)B * OH * OW * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        size_t r = idx / C4;
+        const int ow = (int)(r % OW);
+        r /= OW;
+        const int oh = (int)(r % OH);
+        const int b = (int)(r / OH);
+        y[idx] = x[(((size_t)b * H + 2 * oh) * W + 2 * ow) * C4 + c];
+    }
+}
+
+// tiled transpose of the innermost two "axes": in (B, R, S) -> out (B, S, R)
+__global__ void transpose_kernel(const float *__restrict__ in, int R, int S, float *__restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const float *src = in + (size_t)b * R * S;
+    float *dst = out + (size_t)b * R * S;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = r0 + i, s = s0 + threadIdx.x;
+        if (r < R && s < S) tile[i][threadIdx.x] = src[(size_t)r * S + s];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int s = s0 + i, r = r0 + threadIdx.x;
+        if (r < R && s < S) dst[(size_t)s * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+static inline int grid_for(size_t total, int threads) { return (int)std::min<size_t>((total + threads - 1) / threads, 16384); }
+
+}  // namespace srcnn
+
+extern "C" {
+
+int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(im_nchw && out && B > 0 && H > 0 && W > 0, "bad args");
+    const size_t total = (size_t)B * (H + 6) * (W + 8);
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), im_nchw, B, H, W,
+                       reinterpret_cast<float4 *>(out));
+    return check_launch("srcnn_stem_pack");
+}
+
+int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y, int OH, int OW,
+                            srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
+    SRCNN_REQUIRE((OH - 1) * 2 < H && (OW - 1) * 2 < W, "output too large for input");
+    const size_t total = (size_t)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(x), B, H, W, C / 4, reinterpret_cast<float4 *>(y), OH, OW);
+    return check_launch("srcnn_maxpool3x3s2_ceil");
+}
+
+int srcnn_upsample_add(const float *top, int TH, int TW, const float *lateral, int B, int H, int W, int C, float *y,
+                       srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(top), TH, TW, reinterpret_cast<const float4 *>(lateral), B, H,
+                       W, C / 4, reinterpret_cast<float4 *>(y));
+    return check_launch("srcnn_upsample_add");
+}
+
+int srcnn_subsample2(const float *x, int B, int H, int W, int C, float *y, int OH, int OW, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
+    SRCNN_REQUIRE((OH - 1) * 2 < H && (OW - 1) * 2 < W, "output too large for input");
+    const size_t total = (size_t)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(x), B, H, W, C / 4, reinterpret_cast<float4 *>(y), OH, OW);
+    return check_launch("srcnn_subsample2");
+}
+
+int srcnn_nhwc_to_nchw(const float *x, int B, int H, int W, int C, float *y, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    const int R = H * W, S = C;   // (B, HW, C) -> (B, C, HW)
+    SRCNN_REQUIRE(B <= 65535, "batch too large");
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(S, 32), cdiv(R, 32), B), dim3(32, 8), 0, as_stream(stream), x, R, S, y);
+    return check_launch("srcnn_nhwc_to_nchw");
+}
+
+int srcnn_nchw_to_nhwc(const float *x, int B, int C, int H, int W, float *y, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    const int R = C, S = H * W;   // (B, C, HW) -> (B, HW, C)
+    SRCNN_REQUIRE(B <= 65535, "batch too large");
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(S, 32), cdiv(R, 32), B), dim3(32, 8), 0, as_stream(stream), x, R, S, y);
+    return check_launch("srcnn_nchw_to_nhwc");
+}
+
+}  // extern "C"

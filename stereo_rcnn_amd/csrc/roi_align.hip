@@ -1,0 +1,174 @@
+// Legacy point-lattice ROIAlign (gfx950).
+//
+// Reference: lib/model/roi_align/src/roi_align_kernel.cu:15-91 (one thread per output
+// element, NCHW) + modules/roi_align.py:26-29 (RoIAlignAvg = (A+1)^2 lattice, then
+// avg_pool2d(2, stride 1)) + stereo_rcnn/stereo_rcnn.py:110-139 (pyramid level routing).
+//
+// Two entry points:
+//   * roi_align_forward_cuda : the reference's operator, same layout/semantics (NCHW in,
+//     (n,C,ah,aw) out), kept as the drop-in symbol and as the op-level parity target.
+//   * srcnn_pyramid_roi_align: the MI355X-native fused form used by the forward pass:
+//     NHWC maps (the 4 bilinear taps of a lattice point are 4 coalesced channel runs),
+//     level routing on the device (no nonzero()/host sync), both lattice rows of an output
+//     row in registers, 2x2 average fused, result written straight into the (left|right)
+//     channel slice of the head's GEMM operand.
+// The float/double promotion pattern of the reference kernel (its `1.` literals) is
+// reproduced operation by operation; the library is built with -ffp-contract=off.
+#include "common.h"
+
+namespace srcnn {
+
+struct RoiGeom {
+    float start_w, start_h, bin_w, bin_h;
+    int batch;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float *r, float scale, int ah, int aw)
+{
+    RoiGeom g;
+    g.batch = (int)r[0];
+    g.start_w = r[1] * scale;
+    g.start_h = r[2] * scale;
+    float end_w = r[3] * scale;
+    float end_h = r[4] * scale;
+    float roi_w = fmaxf((float)((double)(end_w - g.start_w) + 1.), 0.0f);   // roi_align_kernel.cu:40
+    float roi_h = fmaxf((float)((double)(end_h - g.start_h) + 1.), 0.0f);   // :41
+    g.bin_h = (float)((double)roi_h / ((double)ah - 1.));                   // :42
+    g.bin_w = (float)((double)roi_w / ((double)aw - 1.));                   // :43
+    return g;
+}
+
+// value of one lattice point; `at(y, x)` fetches the feature value
+template <typename Fetch>
+__device__ __forceinline__ float lattice_point(float h, float w, int height, int width, Fetch at)
+{
+    if (h < 0 || h >= height || w < 0 || w >= width) return 0.0f;           // :54-55
+    int hstart = (int)fminf(floorf(h), (float)(height - 2));                 // :48
+    int wstart = (int)fminf(floorf(w), (float)(width - 2));                  // :49
+    float h_ratio = h - (float)hstart;
+    float w_ratio = w - (float)wstart;
+    double hr = (double)h_ratio, wr = (double)w_ratio;
+    double v = (double)at(hstart, wstart) * (1. - hr) * (1. - wr)            // :64-67
+             + (double)at(hstart, wstart + 1) * (1. - hr) * wr
+             + (double)at(hstart + 1, wstart) * hr * (1. - wr)
+             + (double)at(hstart + 1, wstart + 1) * hr * wr;
+    return (float)v;
+}
+
+__global__ void roi_align_nchw_kernel(int total, const float *__restrict__ feat, float scale, int height,
+                                      int width, int channels, int ah, int aw, const float *__restrict__ rois,
+                                      float *__restrict__ out)
+{
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += blockDim.x * gridDim.x) {
+        int pw = idx % aw;
+        int ph = (idx / aw) % ah;
+        int c = (idx / aw / ah) % channels;
+        int n = idx / aw / ah / channels;
+        const float *r = rois + (size_t)n * 5;
+        RoiGeom g = roi_geom(r, scale, ah, aw);
+        // reference: int img_start = roi_batch_ind * channels * height * width (float product, :51)
+        int img_start = (int)(r[0] * (float)channels * (float)height * (float)width);
+        float h = (float)ph * g.bin_h + g.start_h;
+        float w = (float)pw * g.bin_w + g.start_w;
+        const float *plane = feat + img_start + (size_t)c * height * width;
+        out[idx] = lattice_point(h, w, height, width,
+                                 [&](int y, int x) { return plane[y * width + x]; });
+    }
+}
+
+struct PyramidArgs {
+    const float *maps[4];
+    int mh[4], mw[4];
+    float scale[4];
+};
+
+// grid (A, n); block = C threads (C multiple of 64, <= 1024). One output row per block.
+template <int A>
+__global__ void pyramid_roi_align_kernel(PyramidArgs pa, int channels, const float *__restrict__ rois,
+                                         float *__restrict__ out, int out_cstride, int out_coffset)
+{
+    const int n = blockIdx.y, py = blockIdx.x, c = threadIdx.x;
+    const float *r = rois + (size_t)n * 5;
+    // level routing, stereo_rcnn.py:113-119 (natural log; round half away from zero; clamp 2..5)
+    float bh = r[4] - r[2] + 1.0f;
+    float bw = r[3] - r[1] + 1.0f;
+    float lv = logf(sqrtf(bh * bw) / 224.0f) + 4.0f;
+    lv = copysignf(floorf(fabsf(lv) + 0.5f), lv);
+    lv = fminf(fmaxf(lv, 2.0f), 5.0f);
+    const int l = __builtin_amdgcn_readfirstlane((int)lv - 2);   // same roi for the whole block
+    const int height = pa.mh[l], width = pa.mw[l];
+    RoiGeom g = roi_geom(r, pa.scale[l], A + 1, A + 1);
+    const float *base = pa.maps[l] + (size_t)g.batch * height * width * channels + c;
+    auto at = [&](int y, int x) { return base[((size_t)y * width + x) * channels]; };
+    float top[A + 1], bot[A + 1];
+    const float h0 = (float)py * g.bin_h + g.start_h;
+    const float h1 = (float)(py + 1) * g.bin_h + g.start_h;
+#pragma unroll
+    for (int px = 0; px <= A; ++px) {
+        float w = (float)px * g.bin_w + g.start_w;
+        top[px] = lattice_point(h0, w, height, width, at);
+        bot[px] = lattice_point(h1, w, height, width, at);
+    }
+    float *o = out + ((size_t)(n * A + py) * A) * out_cstride + out_coffset + c;
+#pragma unroll
+    for (int px = 0; px < A; ++px) {
+        float s = top[px];
+        s = s + top[px + 1];
+        s = s + bot[px];
+        s = s + bot[px + 1];
+        o[(size_t)px * out_cstride] = s * 0.25f;
+    }
+}
+
+}  // namespace srcnn
+
+extern "C" {
+
+int roi_align_forward_cuda(int aligned_height, int aligned_width, float spatial_scale, const float *features,
+                           int batch, int channels, int height, int width, const float *rois, int num_rois,
+                           int roi_cols, float *output, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    (void)batch;
+    if (roi_cols != 5) return 0;   // roi_align_cuda.c:19-22
+    const long long total = (long long)num_rois * aligned_height * aligned_width * channels;
+    if (total == 0) return 1;
+    if (total > 0x7fffffffLL) {
+        set_error("roi_align_forward_cuda: output too large");
+        return 0;
+    }
+    const int threads = 256;
+    const int blocks = (int)((total + threads - 1) / threads);
+    hipLaunchKernelGGL(roi_align_nchw_kernel, dim3(blocks), dim3(threads), 0, as_stream(stream), (int)total,
+                       features, spatial_scale, height, width, channels, aligned_height, aligned_width, rois,
+                       output);
+    return check_launch("roi_align_forward_cuda") == SRCNN_OK ? 1 : 0;
+}
+
+int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, const int *mw_host, int channels,
+                            float im_height, const float *rois, int num_rois, int A, float *out, int out_cstride,
+                            int out_coffset, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(channels % 64 == 0 && channels <= 1024, "channels must be a multiple of 64, <= 1024");
+    SRCNN_REQUIRE(A == 7 || A == 14, "A must be 7 or 14");
+    if (num_rois == 0) return SRCNN_OK;
+    PyramidArgs pa;
+    for (int l = 0; l < 4; ++l) {
+        pa.maps[l] = maps_host[l];
+        pa.mh[l] = mh_host[l];
+        pa.mw[l] = mw_host[l];
+        // python: feat_maps[i].size(2) / im_info[0][0] -> double, narrowed to float at the C boundary
+        pa.scale[l] = (float)((double)mh_host[l] / (double)im_height);
+    }
+    dim3 grid(A, num_rois), block(channels);
+    if (A == 7)
+        hipLaunchKernelGGL(pyramid_roi_align_kernel<7>, grid, block, 0, as_stream(stream), pa, channels, rois, out,
+                           out_cstride, out_coffset);
+    else
+        hipLaunchKernelGGL(pyramid_roi_align_kernel<14>, grid, block, 0, as_stream(stream), pa, channels, rois,
+                           out, out_cstride, out_coffset);
+    return check_launch("srcnn_pyramid_roi_align");
+}
+
+}  // extern "C"

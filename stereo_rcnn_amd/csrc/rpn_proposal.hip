@@ -1,0 +1,392 @@
+// Stereo RPN scoring and the proposal layer, fully on the device (gfx950).
+//
+// Reference: rpn/stereo_rpn.py:81-91 (pair softmax quirk + NHWC flatten),
+// rpn/proposal_layer.py:42-145, rpn/generate_anchors.py:112-173,
+// rpn/bbox_transform.py:79-104,177-185.
+//
+// What the reference does on the host (anchors in numpy every call + H2D, two NMS
+// round-trips with a 4.5 MB mask D2H each, np.intersect1d on the CPU) is here five
+// device launches with no host synchronisation:
+//   1. topk_sort_kernel     exact top-K by (score desc, index asc): radix select on the
+//                           order-preserving score key, tie-break select on the index,
+//                           compaction into LDS and an in-LDS bitonic sort (one CU / image).
+//                           == torch.sort(descending, stable)[:K]  (proposal_layer.py:96,111-115)
+//   2. gather_decode_kernel anchors recomputed analytically in float64 (bit-equal to the
+//                           numpy anchors cast to float32), left/right decode + clip.
+//   3-4. batched NMS        (nms.hip) over 2*B problems.
+//   5. intersect_pad_kernel sorted-set intersection, first `post` rows, zero padding.
+#include "common.h"
+
+namespace srcnn {
+
+// ------------------------------------------------------------------ RPN scoring
+// head rows: [0,6) cls logits, [6,24) deltas.  probs index (b, off + loc*3 + a, {0,1}).
+__global__ void rpn_score_kernel(const float *__restrict__ head, int B, int hw, int hcs, float *__restrict__ probs,
+                                 float *__restrict__ deltas, int level_off, int a_total)
+{
+    const int total = B * hw;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += blockDim.x * gridDim.x) {
+        const int b = idx / hw, loc = idx - b * hw;
+        const float *h = head + (size_t)idx * hcs;
+        float pr[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {   // softmax over the channel pair (c, c+3)  (stereo_rpn.py:81-83)
+            const float s0 = h[c], s1 = h[c + 3];
+            const float m = fmaxf(s0, s1);
+            const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+            const float sum = e0 + e1;
+            pr[c] = e0 / sum;
+            pr[c + 3] = e1 / sum;
+        }
+        const size_t base = (size_t)b * a_total + level_off + (size_t)loc * 3;
+        float *po = probs + base * 2;      // NHWC flatten pairs CONSECUTIVE channels (:89-90)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) po[c] = pr[c];
+        float *dl = deltas + base * 6;
+#pragma unroll
+        for (int c = 0; c < 18; ++c) dl[c] = h[6 + c];
+    }
+}
+
+// ------------------------------------------------------------------ top-K + sort
+__device__ __forceinline__ unsigned score_key(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // larger float -> larger key
+}
+
+constexpr int TK_THREADS = 1024;
+constexpr int TK_MAXK = 8192;
+
+// scores: probs[(b*A + i)*2 + 1].  order_out[b*K + r] = index of the r-th best anchor.
+__global__ __launch_bounds__(TK_THREADS) void topk_sort_kernel(const float *__restrict__ probs, int A, int K,
+                                                              int *__restrict__ order_out)
+{
+    __shared__ unsigned long long cand[TK_MAXK];
+    __shared__ unsigned hist[16][256];
+    __shared__ unsigned s_prefix, s_remaining, s_ties, s_count;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float *sc = probs + (size_t)b * A * 2 + 1;
+    const int ksel = min(K, A);
+
+    auto clear_hist = [&]() {
+        for (int i = tid; i < 16 * 256; i += TK_THREADS) (&hist[0][0])[i] = 0;
+    };
+    // picks the digit holding the `remaining`-th element counted from the top (desc) or bottom (asc)
+    auto pick_digit = [&](bool from_top, int shift) {
+        if (tid < 256) {   // fold the 16 sub-histograms
+            unsigned s = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += hist[r][tid];
+            hist[0][tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned rem = s_remaining, cum = 0;
+            int d = from_top ? 255 : 0;
+            for (int step = 0; step < 256; ++step, d += from_top ? -1 : 1) {
+                const unsigned h = hist[0][d];
+                if (cum + h >= rem) break;
+                cum += h;
+            }
+            s_remaining = rem - cum;
+            s_prefix |= (unsigned)d << shift;
+            s_ties = hist[0][d];
+        }
+        __syncthreads();
+    };
+
+    if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)ksel; s_ties = 0; s_count = 0; }
+    __syncthreads();
+    // ---- phase 1: key of the ksel-th largest score
+    unsigned mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        clear_hist();
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (int i = tid; i < A; i += TK_THREADS) {
+            const unsigned k = score_key(sc[(size_t)i * 2]);
+            if ((k & mask) == prefix) atomicAdd(&hist[tid & 15][(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        pick_digit(true, shift);
+        mask |= 0xFFu << shift;
+    }
+    const unsigned T = s_prefix;
+    const unsigned need_ties = s_remaining;   // how many elements with key == T are taken
+    const unsigned have_ties = s_ties;
+    __syncthreads();
+    // ---- phase 2: among key == T take the `need_ties` smallest indices
+    unsigned idx_limit = 0xFFFFFFFFu;
+    if (need_ties < have_ties) {
+        if (tid == 0) { s_prefix = 0; s_remaining = need_ties; }
+        __syncthreads();
+        unsigned imask = 0;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            clear_hist();
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            for (int i = tid; i < A; i += TK_THREADS) {
+                if (score_key(sc[(size_t)i * 2]) == T && (((unsigned)i) & imask) == prefix)
+                    atomicAdd(&hist[tid & 15][((unsigned)i >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            pick_digit(false, shift);
+            imask |= 0xFFu << shift;
+        }
+        idx_limit = s_prefix;
+        __syncthreads();
+    }
+    // ---- compaction into LDS (arbitrary order; unique 64-bit keys make the sort total)
+    int np = 1;
+    while (np < ksel) np <<= 1;
+    for (int i = tid; i < np; i += TK_THREADS) cand[i] = 0ULL;
+    __syncthreads();
+    for (int i0 = 0; i0 < A; i0 += TK_THREADS) {
+        const int i = i0 + tid;
+        bool take = false;
+        unsigned k = 0;
+        if (i < A) {
+            k = score_key(sc[(size_t)i * 2]);
+            take = (k > T) || (k == T && (unsigned)i <= idx_limit);
+        }
+        const unsigned long long bal = __ballot(take);
+        unsigned base = 0;
+        const int lane = tid & 63;
+        if (lane == 0 && bal) base = atomicAdd(&s_count, (unsigned)__popcll(bal));
+        base = __shfl(base, 0);
+        if (take) {
+            const unsigned pos = base + __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (pos < (unsigned)np) cand[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    // ---- bitonic sort, descending
+    for (int k = 2; k <= np; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np; i += TK_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = cand[i], c = cand[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < c) : (a > c)) { cand[i] = c; cand[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < ksel; i += TK_THREADS)
+        order_out[(size_t)b * K + i] = (int)(0xFFFFFFFFu - (unsigned)(cand[i] & 0xFFFFFFFFULL));
+}
+
+// ------------------------------------------------------------------ anchors + decode + clip
+struct LevelTable {
+    int off[6];        // anchor offset of each level (off[nl] = A)
+    int w[5];          // feature width per level
+    double stride[5];
+    double aw[5][3], ah[5][3];   // anchor widths/heights per (level, ratio) in float64
+    int nl;
+};
+
+__device__ __forceinline__ void decode_one(const float ax1, const float ay1, const float ax2, const float ay2,
+                                           float dx, float dy, float dw, float dh, float wmax, float hmax, float *o)
+{
+    // bbox_transform.py:81-104, float32, one rounding per operation (no contraction)
+    const float widths = ax2 - ax1 + 1.0f;
+    const float heights = ay2 - ay1 + 1.0f;
+    const float ctr_x = ax1 + 0.5f * widths;
+    const float ctr_y = ay1 + 0.5f * heights;
+    const float pcx = dx * widths + ctr_x;
+    const float pcy = dy * heights + ctr_y;
+    const float pw = expf(dw) * widths;
+    const float ph = expf(dh) * heights;
+    o[0] = fminf(fmaxf(pcx - 0.5f * pw, 0.f), wmax);   // clip_boxes :177-185
+    o[1] = fminf(fmaxf(pcy - 0.5f * ph, 0.f), hmax);
+    o[2] = fminf(fmaxf(pcx + 0.5f * pw, 0.f), wmax);
+    o[3] = fminf(fmaxf(pcy + 0.5f * ph, 0.f), hmax);
+}
+
+// dets: (B, 2, n, 5): [b][0] = left, [b][1] = right
+__global__ void gather_decode_kernel(const float *__restrict__ probs, const float *__restrict__ deltas, int A, int B,
+                                     int n, int K, const int *__restrict__ order, LevelTable lt,
+                                     const float *__restrict__ im_info, float *__restrict__ dets)
+{
+    const int total = B * n;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += blockDim.x * gridDim.x) {
+        const int b = idx / n, r = idx - b * n;
+        const int ai = order[(size_t)b * K + r];
+        int l = 0;
+        while (l + 1 < lt.nl && ai >= lt.off[l + 1]) ++l;
+        const int local = ai - lt.off[l];
+        const int a = local % 3, loc = local / 3;
+        const int x = loc % lt.w[l], y = loc / lt.w[l];
+        const double cx = (double)x * lt.stride[l], cy = (double)y * lt.stride[l];
+        const float ax1 = (float)(cx - 0.5 * lt.aw[l][a]), ay1 = (float)(cy - 0.5 * lt.ah[l][a]);
+        const float ax2 = (float)(cx + 0.5 * lt.aw[l][a]), ay2 = (float)(cy + 0.5 * lt.ah[l][a]);
+        const float *d = deltas + ((size_t)b * A + ai) * 6;
+        const float wmax = im_info[b * 3 + 1] - 1.0f, hmax = im_info[b * 3 + 0] - 1.0f;
+        const float score = probs[((size_t)b * A + ai) * 2 + 1];
+        float *ol = dets + (((size_t)b * 2 + 0) * n + r) * 5;
+        float *orr = dets + (((size_t)b * 2 + 1) * n + r) * 5;
+        decode_one(ax1, ay1, ax2, ay2, d[0], d[1], d[2], d[3], wmax, hmax, ol);     // left : (dx, dy, dw, dh)
+        decode_one(ax1, ay1, ax2, ay2, d[4], d[1], d[5], d[3], wmax, hmax, orr);    // right: (dx_r, dy, dw_r, dh)
+        ol[4] = score;
+        orr[4] = score;
+    }
+}
+
+// ------------------------------------------------------------------ intersect + top `post` + pad
+__global__ __launch_bounds__(1024) void intersect_pad_kernel(const int *__restrict__ keep, const int *__restrict__ num,
+                                                             const float *__restrict__ dets, int n, int post,
+                                                             float *__restrict__ rois_l, float *__restrict__ rois_r,
+                                                             int *__restrict__ num_valid)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int s_base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int *kl = keep + (size_t)(2 * b) * n, *kr = keep + (size_t)(2 * b + 1) * n;
+    const int nl = num[2 * b], nr = num[2 * b + 1];
+    const float *dl = dets + (size_t)(2 * b) * n * 5, *dr = dets + (size_t)(2 * b + 1) * n * 5;
+    float *ol = rois_l + (size_t)b * post * 5, *orr = rois_r + (size_t)b * post * 5;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nl; i0 += 1024) {
+        const int base = s_base;
+        if (base >= post) break;
+        const int i = i0 + tid;
+        bool hit = false;
+        int v = -1;
+        if (i < nl) {
+            v = kl[i];
+            int lo = 0, hi = nr;   // lower_bound in the ascending right keep list
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (kr[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            hit = lo < nr && kr[lo] == v;
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wave_sum[wv] = __popcll(bal);
+        __syncthreads();
+        int pre = 0;
+        for (int w = 0; w < wv; ++w) pre += wave_sum[w];
+        const int pos = base + pre + __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (hit && pos < post) {
+            const float *sl = dl + (size_t)v * 5, *sr = dr + (size_t)v * 5;
+            ol[pos * 5 + 0] = (float)b; orr[pos * 5 + 0] = (float)b;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ol[pos * 5 + 1 + c] = sl[c]; orr[pos * 5 + 1 + c] = sr[c]; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_sum[w];
+            s_base = base + tot;
+        }
+        __syncthreads();
+    }
+    const int count = min(s_base, post);
+    for (int p = count + tid; p < post; p += 1024) {   // proposal_layer.py:98-99,139-143
+        ol[p * 5 + 0] = (float)b; orr[p * 5 + 0] = (float)b;
+#pragma unroll
+        for (int c = 1; c < 5; ++c) { ol[p * 5 + c] = 0.f; orr[p * 5 + c] = 0.f; }
+    }
+    if (tid == 0 && num_valid) num_valid[b] = count;
+}
+
+struct ProposalLayout {
+    size_t order, dets, keep, num, nms, total;
+};
+
+static ProposalLayout proposal_layout(int B, int n, int K)
+{
+    ProposalLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    L.order = take((size_t)B * K * sizeof(int));
+    L.dets = take((size_t)B * 2 * n * 5 * sizeof(float));
+    L.keep = take((size_t)B * 2 * n * sizeof(int));
+    L.num = take((size_t)B * 2 * sizeof(int));
+    L.nms = take(srcnn_nms_batched_workspace_bytes(2 * B, n));
+    L.total = off;
+    return L;
+}
+
+}  // namespace srcnn
+
+extern "C" {
+
+int srcnn_rpn_score(const float *head, int B, int hw, int head_cstride, float *probs, float *deltas,
+                    int level_offset, int num_anchors_total, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(head && probs && deltas && B > 0 && hw > 0 && head_cstride >= 24, "bad args");
+    const int total = B * hw;
+    hipLaunchKernelGGL(rpn_score_kernel, dim3(std::min(cdiv(total, 256), 4096)), dim3(256), 0, as_stream(stream), head,
+                       B, hw, head_cstride, probs, deltas, level_offset, num_anchors_total);
+    return check_launch("srcnn_rpn_score");
+}
+
+size_t srcnn_proposal_workspace_bytes(int B, int num_anchors, int pre_nms, int post_nms)
+{
+    (void)post_nms;
+    const int n = pre_nms > 0 && pre_nms < num_anchors ? pre_nms : num_anchors;
+    return srcnn::proposal_layout(B, n, n).total;
+}
+
+int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num_anchors, const int *level_hw_host,
+                         int nlevels, const float *im_info, int pre_nms, int post_nms, float nms_thresh,
+                         float *rois_left, float *rois_right, int *num_valid, void *workspace,
+                         size_t workspace_bytes, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(probs && deltas && im_info && rois_left && rois_right, "null pointer");
+    SRCNN_REQUIRE(nlevels >= 1 && nlevels <= 5 && B > 0 && post_nms > 0, "bad sizes");
+    static const double scales[5] = {32, 64, 128, 256, 512};      // cfg.FPN_ANCHOR_SCALES (config.py:216)
+    static const double strides[5] = {4, 8, 16, 32, 64};          // cfg.FPN_FEAT_STRIDES  (config.py:219)
+    static const double ratios[3] = {0.5, 1, 2};                  // cfg.ANCHOR_RATIOS     (config.py:210)
+    LevelTable lt;
+    lt.nl = nlevels;
+    int off = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        lt.off[l] = off;
+        lt.w[l] = level_hw_host[2 * l + 1];
+        lt.stride[l] = strides[l];
+        for (int r = 0; r < 3; ++r) {   // generate_anchors.py:128-129
+            lt.ah[l][r] = scales[l] / std::sqrt(ratios[r]);
+            lt.aw[l][r] = scales[l] * std::sqrt(ratios[r]);
+        }
+        off += level_hw_host[2 * l] * level_hw_host[2 * l + 1] * 3;
+    }
+    for (int l = nlevels; l <= 5; ++l) lt.off[l] = off;
+    SRCNN_REQUIRE(off == num_anchors, "num_anchors does not match the level shapes");
+    // proposal_layer.py:111: keep everything when pre_nms >= numel
+    const int n = pre_nms > 0 && pre_nms < num_anchors ? pre_nms : num_anchors;
+    SRCNN_REQUIRE(n <= TK_MAXK, "pre_nms_topN > 8192 not supported");
+    ProposalLayout L = proposal_layout(B, n, n);
+    if (!workspace || workspace_bytes < L.total) {
+        set_error("srcnn_proposal_layer: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+        return SRCNN_ERR_WORKSPACE;
+    }
+    char *ws = static_cast<char *>(workspace);
+    int *order = reinterpret_cast<int *>(ws + L.order);
+    float *dets = reinterpret_cast<float *>(ws + L.dets);
+    int *keep = reinterpret_cast<int *>(ws + L.keep);
+    int *num = reinterpret_cast<int *>(ws + L.num);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(topk_sort_kernel, dim3(B), dim3(TK_THREADS), 0, st, probs, num_anchors, n, order);
+    hipLaunchKernelGGL(gather_decode_kernel, dim3(cdiv(B * n, 256)), dim3(256), 0, st, probs, deltas, num_anchors, B,
+                       n, n, order, lt, im_info, dets);
+    int rc = check_launch("proposal: select/decode");
+    if (rc != SRCNN_OK) return rc;
+    rc = srcnn_nms_batched(keep, dets, num, nullptr, 2 * B, n, 5, nms_thresh, ws + L.nms,
+                           workspace_bytes - L.nms, stream);
+    if (rc != SRCNN_OK) return rc;
+    hipLaunchKernelGGL(intersect_pad_kernel, dim3(B), dim3(1024), 0, st, keep, num, dets, n, post_nms, rois_left,
+                       rois_right, num_valid);
+    return check_launch("proposal: intersect");
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Host-side driver of the HIP convolution engine and NHWC helpers.
+
+Thin Python over the C ABI (include/srcnn_hip.h): weight re-layout / frozen-BN folding
+at load time, and one function per native op that fills the C descriptor and launches on
+torch's current stream.  No arithmetic happens here.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class ConvW(object):
+    """A convolution prepared for the engine: weight (Cout, KH, KW, Cin) K-contiguous, bias."""
+
+    def __init__(self, weight, bias, kh, kw, stride, pad, relu, mode=0):
+        self.weight = weight.contiguous()
+        self.bias = None if bias is None else bias.contiguous()
+        self.cout = int(weight.shape[0])
+        self.cin = int(weight.numel() // (weight.shape[0] * kh * kw))
+        self.kh, self.kw, self.stride, self.pad, self.relu, self.mode = kh, kw, stride, pad, int(relu), mode
+
+
+def fold_bn(w, bn, eps=1e-5):
+    """Frozen BN (resnet.py:300-309: always eval) folded into the preceding bias-free conv.
+    Done in float64, stored float32:  w' = w * g/sqrt(v+eps),  b' = beta - mean * g/sqrt(v+eps)."""
+    s = bn['weight'].double() / torch.sqrt(bn['running_var'].double() + eps)
+    wf = (w.double() * s.view(-1, 1, 1, 1)).float()
+    bf = (bn['bias'].double() - bn['running_mean'].double() * s).float()
+    return wf, bf
+
+
+def prep_conv(w, b, stride=1, pad=0, relu=False, bn=None, device='cuda'):
+    """nn.Conv2d weight (Cout, Cin, KH, KW) -> engine layout (Cout, KH, KW, Cin)."""
+    if bn is not None:
+        w, b = fold_bn(w, bn)
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    wt = w.permute(0, 2, 3, 1).contiguous().to(device)
+    return ConvW(wt, None if b is None else b.to(device), kh, kw, stride, pad, relu)
+
+
+def prep_stem(w, bn, device='cuda'):
+    """7x7/2 stem (resnet.py:109) as 7 row-taps of 32 floats = 8 pixels x NHWC4 (see srcnn_stem_pack)."""
+    wf, bf = fold_bn(w, bn)
+    cout = wf.shape[0]
+    wt = torch.zeros(cout, 7, 8, 4)
+    wt[:, :, :7, :3] = wf.permute(0, 2, 3, 1)          # (co, kh, kw, c)
+    cw = ConvW(wt.view(cout, 7, 1, 32).to(device), bf.to(device), 7, 1, 2, 0, True)
+    return cw
+
+
+def prep_deconv2x2(w, b, relu=True, device='cuda'):
+    """nn.ConvTranspose2d(k=2, s=2) weight (Cin, Cout, 2, 2) -> GEMM rows ordered (i, j, co)."""
+    cin, cout = int(w.shape[0]), int(w.shape[1])
+    wt = w.permute(2, 3, 1, 0).contiguous().view(4 * cout, 1, 1, cin)
+    return ConvW(wt.to(device), b.to(device), 1, 1, 1, 0, relu, mode=1)
+
+
+def prep_linear_stack(ws, bs, device='cuda'):
+    """Several nn.Linear(in, out_i) sharing the input -> one (sum out_i, 1, 1, in) conv."""
+    w = torch.cat([x for x in ws], 0)
+    b = torch.cat([x for x in bs], 0)
+    return ConvW(w.view(w.shape[0], 1, 1, w.shape[1]).to(device), b.to(device), 1, 1, 1, 0, False)
+
+
+def conv_out_hw(h, w, k_h, k_w, stride, pad):
+    return (h + 2 * pad - k_h) // stride + 1, (w + 2 * pad - k_w) // stride + 1
+
+
+def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
+           res_cstride=None, x_offset_elems=0, relu=None):
+    """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory)."""
+    L = _lib.lib()
+    d = _lib.ConvDesc()
+    d.x = x.data_ptr() + 4 * x_offset_elems
+    d.w = cw.weight.data_ptr()
+    d.bias = cw.bias.data_ptr() if cw.bias is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.y = y.data_ptr()
+    d.B, d.H, d.W, d.Cin = B, H, W, cw.cin
+    d.x_cstride = cw.cin if x_cstride is None else x_cstride
+    d.OH, d.OW, d.Cout = OH, OW, cw.cout
+    d.KH, d.KW, d.stride, d.pad = cw.kh, cw.kw, cw.stride, cw.pad
+    cq = cw.cout // 4 if cw.mode == 1 else cw.cout
+    d.y_cstride = cq if y_cstride is None else y_cstride
+    d.y_coffset = y_coffset
+    d.res_cstride = cw.cout if res_cstride is None else res_cstride
+    d.relu = cw.relu if relu is None else int(relu)
+    d.mode = cw.mode
+    need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
+    ws = _lib.workspace(need, x.device, "conv")
+    _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")
+
+
+def stem_pack(im_nchw, out, batch_offset=0):
+    B, C, H, W = im_nchw.shape
+    assert C == 3
+    L = _lib.lib()
+    off = batch_offset * (H + 6) * (W + 8) * 4 * 4
+    _lib.check(L.srcnn_stem_pack(_lib.ptr(im_nchw), B, H, W, out.data_ptr() + off, _lib.stream()), "srcnn_stem_pack")
+
+
+def maxpool3x3s2_ceil(x, B, H, W, C, y, OH, OW):
+    _lib.check(_lib.lib().srcnn_maxpool3x3s2_ceil(x.data_ptr(), B, H, W, C, y.data_ptr(), OH, OW, _lib.stream()),
+               "srcnn_maxpool3x3s2_ceil")
+
+
+def upsample_add(top, TH, TW, lateral, B, H, W, C, y):
+    _lib.check(_lib.lib().srcnn_upsample_add(top.data_ptr(), TH, TW, lateral.data_ptr(), B, H, W, C, y.data_ptr(),
+                                             _lib.stream()), "srcnn_upsample_add")
+
+
+def subsample2(x, B, H, W, C, y, OH, OW):
+    _lib.check(_lib.lib().srcnn_subsample2(x.data_ptr(), B, H, W, C, y.data_ptr(), OH, OW, _lib.stream()),
+               "srcnn_subsample2")
+
+
+def nhwc_to_nchw(x_nhwc):
+    """(B,H,W,C) contiguous -> new (B,C,H,W) contiguous tensor (API-edge helper)."""
+    B, H, W, C = x_nhwc.shape
+    y = torch.empty((B, C, H, W), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    _lib.check(_lib.lib().srcnn_nhwc_to_nchw(_lib.ptr(x_nhwc), B, H, W, C, y.data_ptr(), _lib.stream()),
+               "srcnn_nhwc_to_nchw")
+    return y
+
+
+def nchw_to_nhwc(x_nchw):
+    B, C, H, W = x_nchw.shape
+    y = torch.empty((B, H, W, C), dtype=x_nchw.dtype, device=x_nchw.device)
+    _lib.check(_lib.lib().srcnn_nchw_to_nhwc(_lib.ptr(x_nchw), B, C, H, W, y.data_ptr(), _lib.stream()),
+               "srcnn_nchw_to_nhwc")
+    return y
