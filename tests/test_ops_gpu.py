@@ -1,0 +1,230 @@
+"""Op-level parity: HIP kernels (through the C ABI) vs the CPU oracle on identical inputs.
+Bit-exact for index outputs (NMS keep lists) and for ROIAlign (same float/double op order);
+conv within a float32 accumulation-order tolerance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as oops
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_dets(rng, n, w=1987.0, h=600.0, cluster=True):
+    if cluster:   # clusters of overlapping boxes so that suppression actually happens
+        nc = max(1, n // 12)
+        cx = rng.uniform(0, w, nc); cy = rng.uniform(0, h, nc); s = rng.uniform(16, 300, nc)
+        idx = rng.integers(0, nc, n)
+        x = cx[idx] + rng.normal(0, 0.15, n) * s[idx]; y = cy[idx] + rng.normal(0, 0.15, n) * s[idx]
+        bw = s[idx] * rng.uniform(0.7, 1.4, n); bh = s[idx] * rng.uniform(0.5, 1.2, n)
+    else:
+        x = rng.uniform(0, w, n); y = rng.uniform(0, h, n); bw = rng.uniform(1, 400, n); bh = rng.uniform(1, 300, n)
+    b = np.stack([x - bw / 2, y - bh / 2, x + bw / 2, y + bh / 2], 1)
+    b[:, 0::2] = np.clip(b[:, 0::2], 0, w - 1); b[:, 1::2] = np.clip(b[:, 1::2], 0, h - 1)
+    sc = np.sort(rng.uniform(0, 1, n))[::-1]
+    return np.concatenate([b, sc[:, None]], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 4097, 6000])
+@pytest.mark.parametrize("thresh", [0.7, 0.3])
+def test_nms_bit_exact(dev, n, thresh):
+    from stereo_rcnn_amd.model.nms.nms_wrapper import nms
+    rng = np.random.default_rng(n * 7 + int(thresh * 10))
+    dets = _rand_dets(rng, n)
+    ref = oops.nms(dets, thresh)
+    got = nms(torch.from_numpy(dets).to(dev), thresh)
+    assert got.dtype == torch.int32 and got.dim() == 2 and got.shape[1] == 1
+    assert np.array_equal(got.view(-1).cpu().numpy(), ref)
+
+
+def test_nms_edge_cases(dev):
+    from stereo_rcnn_amd.model.nms.nms_wrapper import nms
+    assert nms(torch.zeros((0, 5), device=dev), 0.7) == []
+    # degenerate / identical / zero-area boxes
+    d = np.array([[10, 10, 10, 10, .9], [10, 10, 10, 10, .8], [0, 0, 0, 0, .7], [5, 5, 4, 4, .6],
+                  [0, 0, 1986, 599, .5], [0, 0, 1986, 599, .4]], np.float32)
+    for th in (0.0, 0.3, 0.7, 1.0):
+        assert np.array_equal(nms(torch.from_numpy(d).to(dev), th).view(-1).cpu().numpy(), oops.nms(d, th))
+    # all identical boxes: only the first survives
+    d = np.tile(np.array([[3, 4, 50, 60, 0.5]], np.float32), (200, 1))
+    assert nms(torch.from_numpy(d).to(dev), 0.7).view(-1).tolist() == [0]
+
+
+def test_nms_legacy_symbol(dev):
+    from stereo_rcnn_amd import _lib
+    rng = np.random.default_rng(5)
+    dets = _rand_dets(rng, 777)
+    t = torch.from_numpy(dets).to(dev)
+    keep = torch.zeros(777, dtype=torch.int32, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().nms_cuda(keep.data_ptr(), t.data_ptr(), num.data_ptr(), 777, 5, 0.7, _lib.stream())
+    assert rc == 1
+    ref = oops.nms(dets, 0.7)
+    assert int(num[0]) == len(ref) and np.array_equal(keep[:len(ref)].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("a", [8, 15])
+@pytest.mark.parametrize("shape", [(1, 8, 38, 125), (2, 16, 19, 63)])
+def test_roi_align_legacy_bit_exact(dev, a, shape):
+    from stereo_rcnn_amd.model.roi_align.functions.roi_align import RoIAlignFunction
+    rng = np.random.default_rng(a * 100 + shape[2])
+    feat = rng.normal(0, 1, shape).astype(np.float32)
+    n = 40
+    x1 = rng.uniform(-20, 1900, n); y1 = rng.uniform(-20, 560, n)
+    rois = np.stack([rng.integers(0, shape[0], n).astype(np.float64), x1, y1, x1 + rng.uniform(0, 500, n),
+                     y1 + rng.uniform(0, 300, n)], 1).astype(np.float32)
+    rois[0, 1:] = 0                      # the zero-padded proposal
+    rois[1, 1:] = [1900, 500, 2100, 700]  # sticks out of the image
+    scale = shape[2] / 600.0
+    ref = oops.roi_align_forward(feat, rois, a, a, scale)
+    got = RoIAlignFunction(a, a, scale)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev))
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_roi_align_bad_roi_shape_is_noop(dev):
+    from stereo_rcnn_amd.model.roi_align.functions.roi_align import RoIAlignFunction
+    feat = torch.ones((1, 4, 8, 8), device=dev)
+    out = RoIAlignFunction(3, 3, 1.0)(feat, torch.zeros((5, 4), device=dev))   # roi_align_cuda.c:19-22
+    assert float(out.abs().sum()) == 0.0
+
+
+def test_roi_align_avg_module(dev):
+    from stereo_rcnn_amd.model.roi_align.modules.roi_align import RoIAlignAvg
+    rng = np.random.default_rng(11)
+    feat = rng.normal(0, 1, (1, 32, 38, 125)).astype(np.float32)
+    rois = np.array([[0, 100, 50, 400, 300], [0, 0, 0, 0, 0], [0, 1500, 10, 1986, 599]], np.float32)
+    ref = oops.roi_align_avg(feat, rois, 7, 7, 38 / 600.0)
+    got = RoIAlignAvg(7, 7, 1 / 16.0)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev), 38 / 600.0)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("A", [7, 14])
+def test_pyramid_roi_align_fused(dev, A):
+    """Fused NHWC kernel == per-level legacy op + avg-pool + level routing of the oracle."""
+    import ctypes
+    from stereo_rcnn_amd import _lib
+    from oracle import net as onet
+    rng = np.random.default_rng(A)
+    C, B = 64, 2
+    hw = [(150, 497), (75, 249), (38, 125), (19, 63)]
+    maps = [rng.normal(0, 1, (B, C, h, w)).astype(np.float32) for h, w in hw]
+    n = 120
+    cx = rng.uniform(0, 1987, n); cy = rng.uniform(0, 600, n)
+    sz = np.exp(rng.uniform(np.log(8), np.log(900), n)); ar = rng.uniform(0.5, 2.0, n)
+    bw, bh = sz * np.sqrt(ar), sz / np.sqrt(ar)
+    rois = np.stack([rng.integers(0, B, n).astype(np.float64), np.clip(cx - bw / 2, 0, 1986), np.clip(cy - bh / 2, 0, 599),
+                     np.clip(cx + bw / 2, 0, 1986), np.clip(cy + bh / 2, 0, 599)], 1).astype(np.float32)
+    rois[:5, 1:] = 0
+    im_info = torch.tensor([[600.0, 1987.0, 1.6]])
+    # oracle: pyramid_roi_feat handles only one batch index per call through rois[:,0]; it passes rois through
+    ref = onet.pyramid_roi_feat([torch.from_numpy(m) for m in maps], torch.from_numpy(rois), im_info, kpts=(A == 14))
+    tm = [torch.from_numpy(m).to(dev).permute(0, 2, 3, 1).contiguous() for m in maps]
+    out = torch.zeros((n, A, A, 2 * C), device=dev)
+    ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in tm])
+    mh = (ctypes.c_int * 4)(*[h for h, _ in hw]); mw = (ctypes.c_int * 4)(*[w for _, w in hw])
+    tr = torch.from_numpy(rois).to(dev)
+    _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, C, 600.0, tr.data_ptr(), n, A, out.data_ptr(), 2 * C, C,
+                                                  _lib.stream()))
+    got = out[:, :, :, C:].permute(0, 3, 1, 2).cpu().numpy()
+    lv_dev = onet.roi_levels(torch.from_numpy(rois))
+    assert float(out[:, :, :, :C].abs().sum()) == 0.0          # other channel slice untouched
+    assert np.array_equal(got, ref.numpy()), float(np.abs(got - ref.numpy()).max())
+
+
+def _conv_case(dev, B, H, W, cin, cout, k, stride, pad, relu, res, bn, seed):
+    from stereo_rcnn_amd import engine
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = None if bn else torch.randn(cout, generator=g)
+    bnp = None
+    if bn:
+        bnp = {'weight': torch.rand(cout, generator=g) + 0.5, 'bias': torch.randn(cout, generator=g),
+               'running_mean': torch.randn(cout, generator=g) * 0.1, 'running_var': torch.rand(cout, generator=g) + 0.5}
+    ref = F.conv2d(x, w, b, stride, pad)
+    if bn:
+        ref = F.batch_norm(ref, bnp['running_mean'], bnp['running_var'], bnp['weight'], bnp['bias'], False, 0.0, 1e-5)
+    OH, OW = ref.shape[2:]
+    r = torch.randn(B, cout, OH, OW, generator=g) if res else None
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    cw = engine.prep_conv(w, b, stride, pad, relu, bn=bnp, device=dev)
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    rd = r.to(dev).permute(0, 2, 3, 1).contiguous() if res else None
+    y = torch.empty((B, OH, OW, cout), device=dev)
+    engine.conv2d(cw, xd, B, H, W, y, OH, OW, residual=rd)
+    got = y.permute(0, 3, 1, 2).cpu()
+    err = float((got - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, cin, cout, k, stride, pad, relu, res, bn
+    (1, 19, 63, 64, 64, 1, 1, 0, True, False, True),
+    (2, 38, 125, 256, 256, 3, 1, 1, True, False, True),      # layer3 conv2 shape
+    (2, 38, 125, 256, 1024, 1, 1, 0, True, True, True),      # layer3 conv3 + residual
+    (2, 75, 249, 512, 256, 1, 2, 0, True, False, True),      # stride-2 1x1 (layer3.0.conv1)
+    (1, 150, 497, 64, 64, 3, 1, 1, True, False, True),       # layer1 conv2, big M
+    (1, 10, 32, 256, 512, 3, 1, 1, True, False, False),      # RPN conv on P6 (bias, no bn)
+    (1, 19, 63, 1024, 24, 1, 1, 0, False, False, False),     # fused RPN heads, Cout=24 (N guard)
+    (1, 7, 9, 2048, 512, 1, 1, 0, False, False, False),      # small M, long K -> split-K
+    (3, 14, 14, 256, 256, 3, 1, 1, True, False, False),      # kpts tower
+])
+def test_conv_engine_vs_torch_cpu(dev, case):
+    _conv_case(dev, *case, seed=hash(case) % 1000)
+
+
+def test_conv_stem_vs_torch_cpu(dev):
+    from stereo_rcnn_amd import engine
+    g = torch.Generator().manual_seed(1)
+    B, H, W = 2, 75, 131
+    x = torch.randn(B, 3, H, W, generator=g) * 50
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.01
+    bnp = {'weight': torch.rand(64, generator=g) + 0.5, 'bias': torch.randn(64, generator=g),
+           'running_mean': torch.randn(64, generator=g) * 0.1, 'running_var': torch.rand(64, generator=g) + 0.5}
+    ref = F.relu(F.batch_norm(F.conv2d(x, w, None, 2, 3), bnp['running_mean'], bnp['running_var'], bnp['weight'],
+                              bnp['bias'], False, 0.0, 1e-5))
+    refp = F.max_pool2d(ref, 3, 2, 0, ceil_mode=True)
+    cw = engine.prep_stem(w, bnp, device=dev)
+    packed = torch.empty((B, H + 6, W + 8, 4), device=dev)
+    engine.stem_pack(x.to(dev), packed)
+    OH, OW = ref.shape[2:]
+    y = torch.empty((B, OH, OW, 64), device=dev)
+    engine.conv2d(cw, packed, B, H + 6, W + 8, y, OH, OW, x_cstride=4)
+    assert float((y.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 1e-4
+    PH, PW = refp.shape[2:]
+    p = torch.empty((B, PH, PW, 64), device=dev)
+    engine.maxpool3x3s2_ceil(y, B, OH, OW, 64, p, PH, PW)
+    assert float((p.permute(0, 3, 1, 2).cpu() - refp).abs().max()) < 1e-4
+
+
+def test_deconv2x2_vs_torch_cpu(dev):
+    from stereo_rcnn_amd import engine
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 256, 14, 14, generator=g)
+    w = torch.randn(256, 256, 2, 2, generator=g) / 16
+    b = torch.randn(256, generator=g)
+    ref = F.relu(F.conv_transpose2d(x, w, b, 2))
+    cw = engine.prep_deconv2x2(w, b, device=dev)
+    y = torch.empty((5, 28, 28, 256), device=dev)
+    engine.conv2d(cw, x.to(dev).permute(0, 2, 3, 1).contiguous(), 5, 14, 14, y, 14, 14)
+    assert float((y.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 2e-5
+
+
+def test_upsample_add_subsample_layout(dev):
+    from stereo_rcnn_amd import engine
+    g = torch.Generator().manual_seed(3)
+    top = torch.randn(2, 256, 19, 63, generator=g); lat = torch.randn(2, 256, 38, 125, generator=g)
+    ref = F.interpolate(top, size=(38, 125), mode='bilinear', align_corners=True) + lat
+    td = engine.nchw_to_nhwc(top.to(dev)); ld = engine.nchw_to_nhwc(lat.to(dev))
+    assert torch.equal(td.cpu(), top.permute(0, 2, 3, 1).contiguous())
+    y = torch.empty_like(ld)
+    engine.upsample_add(td, 19, 63, ld, 2, 38, 125, 256, y)
+    got = engine.nhwc_to_nchw(y).cpu()
+    assert float((got - ref).abs().max()) < 5e-6
+    s = torch.empty((2, 10, 32, 256), device=dev)
+    engine.subsample2(td, 2, 19, 63, 256, s, 10, 32)
+    assert torch.equal(engine.nhwc_to_nchw(s).cpu(), top[:, :, ::2, ::2])
