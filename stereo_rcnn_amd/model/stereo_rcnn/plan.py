@@ -1,0 +1,297 @@
+"""Static execution plan of the Stereo R-CNN inference forward on one MI355X.
+
+MI355X-first structure (not the reference's eager module tree):
+  * weights are re-laid-out once (frozen BN folded, K-contiguous GEMM rows) and stay resident;
+  * left and right images run through the shared trunk/FPN as ONE batch of 2B images
+    (the reference runs the Siamese halves sequentially, stereo_rcnn.py:155-185);
+  * every activation lives in a pre-allocated NHWC buffer (288 GB of HBM: nothing is
+    re-allocated per call), so the whole forward is a fixed list of asynchronous launches with
+    no host synchronisation and can be captured in a hipGraph and replayed;
+  * concatenations (RPN left|right, ROI left|right) are channel-offset writes, never copies.
+Every arithmetic step is a call into libsrcnn_hip.so (see include/srcnn_hip.h).
+"""
+import ctypes
+
+import torch
+
+from ... import _lib, engine
+from ..utils.config import cfg
+
+
+def _bn_dict(sd, prefix):
+    return {k: sd[prefix + '.' + k] for k in ('weight', 'bias', 'running_mean', 'running_var')}
+
+
+class Weights(object):
+    """Engine-ready weights built from a reference-schema state_dict (CPU tensors)."""
+
+    def __init__(self, sd, device):
+        sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self.device = device
+        self.stem = engine.prep_stem(sd['RCNN_layer0.0.weight'], _bn_dict(sd, 'RCNN_layer0.1'), device)
+        self.layers = []
+        for li in (1, 2, 3, 4):
+            blocks = []
+            b = 0
+            while 'RCNN_layer%d.0.%d.conv1.weight' % (li, b) in sd:
+                p = 'RCNN_layer%d.0.%d' % (li, b)
+                stride = 2 if (b == 0 and li > 1) else 1          # stride on the first 1x1 (resnet.py:71)
+                blk = {
+                    'conv1': engine.prep_conv(sd[p + '.conv1.weight'], None, stride, 0, True, _bn_dict(sd, p + '.bn1'), device),
+                    'conv2': engine.prep_conv(sd[p + '.conv2.weight'], None, 1, 1, True, _bn_dict(sd, p + '.bn2'), device),
+                    'conv3': engine.prep_conv(sd[p + '.conv3.weight'], None, 1, 0, True, _bn_dict(sd, p + '.bn3'), device),
+                    'down': None,
+                }
+                if p + '.downsample.0.weight' in sd:
+                    blk['down'] = engine.prep_conv(sd[p + '.downsample.0.weight'], None, stride, 0, False,
+                                                   _bn_dict(sd, p + '.downsample.1'), device)
+                blocks.append(blk)
+                b += 1
+            self.layers.append(blocks)
+
+        def cb(name, stride=1, pad=0, relu=False):
+            return engine.prep_conv(sd[name + '.weight'], sd[name + '.bias'], stride, pad, relu, None, device)
+
+        self.toplayer = cb('RCNN_toplayer')
+        self.smooth = [cb('RCNN_smooth%d' % i, 1, 1) for i in (1, 2, 3)]
+        self.lateral = [cb('RCNN_latlayer%d' % i) for i in (1, 2, 3)]
+        self.rpn_conv = cb('RCNN_rpn.RPN_Conv', 1, 1, True)
+        hw = torch.cat((sd['RCNN_rpn.RPN_cls_score.weight'], sd['RCNN_rpn.RPN_bbox_pred_left_right.weight']), 0)
+        hb = torch.cat((sd['RCNN_rpn.RPN_cls_score.bias'], sd['RCNN_rpn.RPN_bbox_pred_left_right.bias']), 0)
+        self.rpn_head = engine.prep_conv(hw, hb, 1, 0, False, None, device)
+        # box head: 7x7/7 conv over the (7,7,512) NHWC roi tile == one GEMM row of 25088 (resnet.py:256-263)
+        w0 = sd['RCNN_top.0.weight']                                  # (2048, 512, 7, 7)
+        self.top0 = engine.ConvW(w0.permute(0, 2, 3, 1).contiguous().view(w0.shape[0], 1, 1, -1).to(device),
+                                 sd['RCNN_top.0.bias'].to(device), 1, 1, 1, 0, True)
+        self.top3 = cb('RCNN_top.3', 1, 0, True)
+        self.fc = engine.prep_linear_stack(
+            [sd['RCNN_bbox_pred.weight'], sd['RCNN_dim_orien_pred.weight'], sd['RCNN_cls_score.weight']],
+            [sd['RCNN_bbox_pred.bias'], sd['RCNN_dim_orien_pred.bias'], sd['RCNN_cls_score.bias']], device)
+        self.n_bbox = int(sd['RCNN_bbox_pred.weight'].shape[0])
+        self.n_dim = int(sd['RCNN_dim_orien_pred.weight'].shape[0])
+        self.n_cls = int(sd['RCNN_cls_score.weight'].shape[0])
+        self.kpts = [cb('RCNN_kpts.%d' % i, 1, 1, True) for i in (0, 2, 4, 6, 8, 10)]
+        self.kpts_up = engine.prep_deconv2x2(sd['RCNN_kpts.12.weight'], sd['RCNN_kpts.12.bias'], True, device)
+        self.kpts_class = cb('kpts_class')
+
+
+class Plan(object):
+    """Buffers + launch list for a fixed (B, H, W) network input."""
+
+    def __init__(self, weights, B, H, W):
+        self.w = weights
+        self.B, self.H, self.W = B, H, W
+        dev = weights.device
+        self.dev = dev
+        N = 2 * B
+        self.N = N
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self.im_left = e(B, 3, H, W)
+        self.im_right = e(B, 3, H, W)
+        self.im_info = e(B, 3)
+        self.packed = e(N, H + 6, W + 8, 4)
+        sh, sw = engine.conv_out_hw(H, W, 7, 7, 2, 3)
+        self.stem_hw = (sh, sw)
+        self.stem_out = e(N, sh, sw, 64)
+        ph, pw = -(-(sh - 3) // 2) + 1, -(-(sw - 3) // 2) + 1           # ceil_mode (resnet.py:113)
+        if (ph - 1) * 2 >= sh:
+            ph -= 1
+        if (pw - 1) * 2 >= sw:
+            pw -= 1
+        self.c1_hw = (ph, pw)
+        self.c1 = e(N, ph, pw, 64)
+        self.layer_hw, self.layer_bufs = [], []
+        h, w_ = ph, pw
+        for li, planes in enumerate((64, 128, 256, 512)):
+            if li > 0:
+                h, w_ = engine.conv_out_hw(h, w_, 1, 1, 2, 0)
+            self.layer_hw.append((h, w_))
+            self.layer_bufs.append({'m1': e(N, h, w_, planes), 'm2': e(N, h, w_, planes),
+                                    'a': e(N, h, w_, 4 * planes), 'b': e(N, h, w_, 4 * planes)})
+        self.c = [None] * 4
+        # FPN
+        (h2, w2), (h3, w3), (h4, w4), (h5, w5) = self.layer_hw
+        self.p5 = e(N, h5, w5, 256)
+        self.lat = [e(N, h4, w4, 256), e(N, h3, w3, 256), e(N, h2, w2, 256)]
+        self.summed = [e(N, h4, w4, 256), e(N, h3, w3, 256), e(N, h2, w2, 256)]
+        self.p4, self.p3, self.p2 = e(N, h4, w4, 256), e(N, h3, w3, 256), e(N, h2, w2, 256)
+        h6, w6 = (h5 + 1) // 2, (w5 + 1) // 2
+        self.p6 = e(N, h6, w6, 256)
+        self.rpn_shapes = [(h2, w2), (h3, w3), (h4, w4), (h5, w5), (h6, w6)]
+        self.A = sum(3 * a * b for a, b in self.rpn_shapes)
+        self.rpn_cat = [e(B, a, b, 1024) for a, b in self.rpn_shapes]
+        self.rpn_hd = [e(B, a, b, 24) for a, b in self.rpn_shapes]
+        self.probs = e(B, self.A, 2)
+        self.deltas = e(B, self.A, 6)
+        self.post = cfg.TEST.RPN_POST_NMS_TOP_N
+        R = B * self.post
+        self.R = R
+        self.rois_left = e(B, self.post, 5)
+        self.rois_right = e(B, self.post, 5)
+        self.num_valid = torch.empty((B,), dtype=torch.int32, device=dev)
+        P = cfg.POOLING_SIZE
+        self.sem = e(R, P, P, 512)
+        self.h1 = e(R, 2048)
+        self.h2 = e(R, 2048)
+        self.fc = e(R, weights.fc.cout)
+        self.cls_prob = e(R, weights.n_cls)
+        self.kp_in = e(R, 2 * P, 2 * P, 256)
+        self.kp_a = e(R, 2 * P, 2 * P, 256)
+        self.kp_b = e(R, 2 * P, 2 * P, 256)
+        G = cfg.KPTS_GRID
+        self.kp_up = e(R, G, G, 256)
+        self.kp_logits = e(R, G, G, 6)
+        self.kpts_prob = e(R, 4 * G)
+        self.left_prob = e(R, G)
+        self.right_prob = e(R, G)
+        self.graph = None
+
+    # ------------------------------------------------------------------ stages
+    def trunk(self):
+        w, N = self.w, self.N
+        H, W = self.H, self.W
+        engine.stem_pack(self.im_left, self.packed, 0)
+        engine.stem_pack(self.im_right, self.packed, self.B)
+        sh, sw = self.stem_hw
+        engine.conv2d(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, x_cstride=4)
+        ph, pw = self.c1_hw
+        engine.maxpool3x3s2_ceil(self.stem_out, N, sh, sw, 64, self.c1, ph, pw)
+        x, xh, xw = self.c1, ph, pw
+        for li, blocks in enumerate(w.layers):
+            h, w_ = self.layer_hw[li]
+            bufs = self.layer_bufs[li]
+            cur, nxt = bufs['a'], bufs['b']
+            for bi, blk in enumerate(blocks):
+                engine.conv2d(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_)
+                engine.conv2d(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_)
+                if blk['down'] is not None:
+                    engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_)
+                    res = nxt
+                else:
+                    res = x
+                engine.conv2d(blk['conv3'], bufs['m2'], N, h, w_, cur, h, w_, residual=res)
+                x, xh, xw = cur, h, w_
+                cur, nxt = nxt, cur
+            self.c[li] = x
+
+    def fpn(self):
+        w, N = self.w, self.N
+        (h2, w2), (h3, w3), (h4, w4), (h5, w5) = self.layer_hw
+        c2, c3, c4, c5 = self.c
+        engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5)
+        tops = [(self.p5, h5, w5), None, None]
+        for i, (cin, (h, w_), out) in enumerate(((c4, (h4, w4), self.p4), (c3, (h3, w3), self.p3),
+                                                 (c2, (h2, w2), self.p2))):
+            top, th, tw = tops[i]
+            engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_)
+            engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i])     # stereo_rcnn.py:91-108
+            engine.conv2d(w.smooth[i], self.summed[i], N, h, w_, out, h, w_)
+            if i + 1 < 3:
+                tops[i + 1] = (out, h, w_)
+        h6, w6 = self.rpn_shapes[4]
+        engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                              # stereo_rcnn.py:168
+
+    def rpn(self):
+        w, B = self.w, self.B
+        L = _lib.lib()
+        feats = [self.p2, self.p3, self.p4, self.p5, self.p6]
+        off = 0
+        st = _lib.stream()
+        for l, (h, w_) in enumerate(self.rpn_shapes):
+            cat, hd = self.rpn_cat[l], self.rpn_hd[l]
+            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0)
+            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
+                          x_offset_elems=B * h * w_ * 256)
+            engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_)
+            _lib.check(L.srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(), self.deltas.data_ptr(),
+                                         off, self.A, st), "srcnn_rpn_score")
+            off += 3 * h * w_
+
+    def proposals(self):
+        L = _lib.lib()
+        nl = len(self.rpn_shapes)
+        hw = (ctypes.c_int * (2 * nl))(*[int(v) for s in self.rpn_shapes for v in s])
+        pre = cfg.TEST.RPN_PRE_NMS_TOP_N
+        ws = _lib.workspace(L.srcnn_proposal_workspace_bytes(self.B, self.A, pre, self.post), self.dev, "proposal")
+        _lib.check(L.srcnn_proposal_layer(self.probs.data_ptr(), self.deltas.data_ptr(), self.B, self.A, hw, nl,
+                                          self.im_info.data_ptr(), pre, self.post, float(cfg.TEST.RPN_NMS_THRESH),
+                                          self.rois_left.data_ptr(), self.rois_right.data_ptr(),
+                                          self.num_valid.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+                   "srcnn_proposal_layer")
+
+    def _pyramid(self, right, rois, A, out, cstride, coffset):
+        maps = [self.p2, self.p3, self.p4, self.p5]
+        hw = self.rpn_shapes[:4]
+        ptrs = (ctypes.c_void_p * 4)()
+        for l in range(4):
+            h, w_ = hw[l]
+            ptrs[l] = maps[l].data_ptr() + (4 * self.B * h * w_ * 256 if right else 0)
+        mh = (ctypes.c_int * 4)(*[h for h, _ in hw])
+        mw = (ctypes.c_int * 4)(*[w_ for _, w_ in hw])
+        _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, 256, float(self.H), rois.data_ptr(), self.R, A,
+                                                      out.data_ptr(), cstride, coffset, _lib.stream()),
+                   "srcnn_pyramid_roi_align")
+
+    def heads(self):
+        w, R = self.w, self.R
+        P = cfg.POOLING_SIZE
+        L = _lib.lib()
+        st = _lib.stream()
+        self._pyramid(False, self.rois_left, P, self.sem, 512, 0)        # stereo_rcnn.py:248-249
+        self._pyramid(True, self.rois_right, P, self.sem, 512, 256)
+        engine.conv2d(w.top0, self.sem, R, 1, 1, self.h1, 1, 1)           # 7x7/7 conv == GEMM (resnet.py:257)
+        engine.conv2d(w.top3, self.h1, R, 1, 1, self.h2, 1, 1)
+        engine.conv2d(w.fc, self.h2, R, 1, 1, self.fc, 1, 1)
+        ncol = w.fc.cout
+        _lib.check(L.srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, ncol,
+                                        self.cls_prob.data_ptr(), st), "srcnn_softmax_rows")
+        self._pyramid(False, self.rois_left, 2 * P, self.kp_in, 256, 0)   # stereo_rcnn.py:260
+        x = self.kp_in
+        s = 2 * P
+        for i, cw in enumerate(w.kpts):
+            y = self.kp_a if i % 2 == 0 else self.kp_b
+            engine.conv2d(cw, x, R, s, s, y, s, s)
+            x = y
+        engine.conv2d(w.kpts_up, x, R, s, s, self.kp_up, s, s)
+        G = cfg.KPTS_GRID
+        engine.conv2d(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G)
+        _lib.check(L.srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, self.kpts_prob.data_ptr(),
+                                     self.left_prob.data_ptr(), self.right_prob.data_ptr(), st), "srcnn_kpts_tail")
+
+    def launch_all(self):
+        self.trunk()
+        self.fpn()
+        self.rpn()
+        self.proposals()
+        self.heads()
+
+    # ------------------------------------------------------------------ driver
+    def set_inputs(self, im_left, im_right, im_info):
+        self.im_left.copy_(im_left, non_blocking=True)
+        self.im_right.copy_(im_right, non_blocking=True)
+        self.im_info.copy_(im_info.view(self.B, 3), non_blocking=True)
+
+    def run(self, use_graph=False):
+        if not use_graph:
+            self.launch_all()
+            return
+        if self.graph is None:
+            self.launch_all()                 # warm-up: sizes every workspace before capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.launch_all()
+            self.graph = g
+        self.graph.replay()
+
+    def outputs(self):
+        w, B = self.w, self.B
+        fc = self.fc.view(B, self.post, -1)
+        return {
+            'rois_left': self.rois_left.clone(), 'rois_right': self.rois_right.clone(),
+            'cls_prob': self.cls_prob.view(B, self.post, -1).clone(),
+            'bbox_pred': fc[:, :, :w.n_bbox].contiguous(),
+            'dim_orien_pred': fc[:, :, w.n_bbox:w.n_bbox + w.n_dim].contiguous(),
+            'kpts_prob': self.kpts_prob.clone(), 'left_border_prob': self.left_prob.clone(),
+            'right_border_prob': self.right_prob.clone(),
+        }

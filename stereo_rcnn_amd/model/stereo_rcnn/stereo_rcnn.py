@@ -1,0 +1,139 @@
+"""`_StereoRCNN` - reference lib/model/stereo_rcnn/stereo_rcnn.py:24-324 (inference branch).
+
+The class keeps the reference's surface: construction through a subclass that defines
+`_init_modules`, `create_architecture()`, `load_state_dict()` with the reference's key
+schema, `PyramidRoI_Feat`, and `forward(9 args) -> 15-tuple`.  The nn.Module parameters are
+containers only; `forward` executes a static launch plan (plan.py) in the HIP library.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from ... import _lib, engine
+from ..roi_align.modules.roi_align import RoIAlignAvg
+from ..rpn.stereo_rpn import _Stereo_RPN
+from ..utils.config import cfg
+from .plan import Plan, Weights
+
+
+class _StereoRCNN(nn.Module):
+    """ FPN-based Stereo R-CNN, eval mode only (the training branch of the reference,
+    stereo_rcnn.py:198-230,273-311, is out of scope). """
+
+    def __init__(self, classes):
+        super(_StereoRCNN, self).__init__()
+        self.classes = classes
+        self.n_classes = len(classes)
+        self.RCNN_loss_cls = 0
+        self.RCNN_loss_bbox_left_right = 0
+        self.RCNN_loss_bbox = 0
+        self.RCNN_loss_dis = 0
+        self.RCNN_loss_dim = 0
+        self.RCNN_loss_dim_orien = 0
+        self.RCNN_loss_kpts = 0
+        self.RCNN_rpn = _Stereo_RPN(self.dout_base_model)
+        self.RCNN_roi_align = RoIAlignAvg(cfg.POOLING_SIZE, cfg.POOLING_SIZE, 1.0 / 16.0)
+        self.RCNN_roi_kpts_align = RoIAlignAvg(cfg.POOLING_SIZE * 2, cfg.POOLING_SIZE * 2, 1.0 / 16.0)
+        self.use_graph = False            # replay the forward as one hipGraph (see plan.py)
+        self._weights = None
+        self._plans = {}
+
+    # ------------------------------------------------------------------ construction
+    def _init_weights(self):
+        """stereo_rcnn.py:47-85: N(0, std) weights / zero bias for the new layers."""
+        def normal_(m, std):
+            m.weight.data.normal_(0.0, std)
+            m.bias.data.zero_()
+        for m in (self.RCNN_toplayer, self.RCNN_smooth1, self.RCNN_smooth2, self.RCNN_smooth3,
+                  self.RCNN_latlayer1, self.RCNN_latlayer2, self.RCNN_latlayer3,
+                  self.RCNN_rpn.RPN_Conv, self.RCNN_rpn.RPN_cls_score, self.RCNN_rpn.RPN_bbox_pred_left_right,
+                  self.RCNN_cls_score):
+            normal_(m, 0.01)
+        normal_(self.RCNN_bbox_pred, 0.001)
+        normal_(self.RCNN_dim_orien_pred, 0.001)
+        normal_(self.kpts_class, 0.1)
+        for seq in (self.RCNN_top, self.RCNN_kpts):
+            for m in seq.modules():
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                    normal_(m, 0.02)
+
+    def create_architecture(self):
+        self._init_modules()
+        self._init_weights()
+        self.invalidate()
+
+    def invalidate(self):
+        """Drop the engine-side copies of the weights (call after editing parameters in place)."""
+        self._weights = None
+        self._plans = {}
+
+    def load_state_dict(self, state_dict, strict=True):
+        state_dict = {k: v for k, v in state_dict.items() if not k.endswith('num_batches_tracked')}
+        own = self.state_dict()
+        missing = [k for k in own if k not in state_dict and not k.endswith('num_batches_tracked')]
+        extra = [k for k in state_dict if k not in own]
+        if strict and (missing or extra):
+            raise RuntimeError("load_state_dict: missing %s unexpected %s" % (missing[:5], extra[:5]))
+        with torch.no_grad():
+            for k, v in state_dict.items():
+                if k in own:
+                    own[k].copy_(v)
+        self.invalidate()
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("this build is the inference path; training is out of scope")
+        return nn.Module.train(self, False)
+
+    # ------------------------------------------------------------------ execution
+    def _device(self):
+        return self.RCNN_toplayer.weight.device
+
+    def _get_plan(self, B, H, W):
+        dev = self._device()
+        if dev.type != 'cuda':
+            raise RuntimeError("_StereoRCNN.forward needs the model on a GPU (call .cuda()); there is no CPU path")
+        if self._weights is None or self._weights.device != dev:
+            self._weights = Weights(self.state_dict(), dev)
+            self._plans = {}
+        key = (B, H, W)
+        if key not in self._plans:
+            self._plans[key] = Plan(self._weights, B, H, W)
+        return self._plans[key]
+
+    def PyramidRoI_Feat(self, feat_maps, rois, im_info, kpts=False, single_level=None):
+        """stereo_rcnn.py:110-139 with the reference's NCHW in / NCHW out contract.
+        feat_maps: 4 NCHW maps (P2..P5); rois (n,5).  One fused native call (level routing,
+        lattice sampling, 2x2 average) instead of the per-level Python loop."""
+        maps = [engine.nchw_to_nhwc(m.contiguous().float()) for m in feat_maps]
+        C = int(feat_maps[0].shape[1])
+        A = cfg.POOLING_SIZE * 2 if kpts else cfg.POOLING_SIZE
+        n = int(rois.shape[0])
+        rois = rois.contiguous().float()
+        out = torch.empty((n, A, A, C), device=rois.device)
+        ptrs = (ctypes.c_void_p * 4)(*[m.data_ptr() for m in maps])
+        mh = (ctypes.c_int * 4)(*[int(m.shape[1]) for m in maps])
+        mw = (ctypes.c_int * 4)(*[int(m.shape[2]) for m in maps])
+        _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, C, float(im_info[0][0]), rois.data_ptr(), n, A,
+                                                      out.data_ptr(), C, 0, _lib.stream()), "srcnn_pyramid_roi_align")
+        return engine.nhwc_to_nchw(out)
+
+    def forward(self, im_left_data, im_right_data, im_info, gt_boxes_left=None, gt_boxes_right=None,
+                gt_boxes_merge=None, gt_dim_orien=None, gt_kpts=None, num_boxes=None):
+        """Reference signature and 15-tuple return (stereo_rcnn.py:141-142,322-324).
+        The gt_* / num_boxes arguments are accepted and ignored exactly as in eval mode."""
+        if self.training:
+            raise NotImplementedError("training forward is out of scope; call .eval()")
+        B, _, H, W = im_left_data.shape
+        plan = self._get_plan(int(B), int(H), int(W))
+        plan.set_inputs(im_left_data, im_right_data, im_info)
+        plan.run(self.use_graph)
+        o = plan.outputs()
+        self.RCNN_loss_cls = 0
+        self.RCNN_loss_bbox = 0
+        rpn_loss_cls, rpn_loss_bbox_left_right = 0, 0
+        rois_label = None
+        return o['rois_left'], o['rois_right'], o['cls_prob'], o['bbox_pred'], o['dim_orien_pred'], \
+            o['kpts_prob'], o['left_border_prob'], o['right_border_prob'], rpn_loss_cls, rpn_loss_bbox_left_right, \
+            self.RCNN_loss_cls, self.RCNN_loss_bbox, self.RCNN_loss_dim_orien, self.RCNN_loss_kpts, rois_label

@@ -1,0 +1,227 @@
+"""Stage-level and end-to-end parity of the HIP forward against the CPU oracle.
+
+Small case (192x640 network input): the oracle runs live on the host and every stage is
+checked on full tensors, each stage fed with the ORACLE's inputs so errors cannot cascade.
+Full case (375x1242 -> 600x1987, BASELINE configs[1]): checked against the committed golden
+file tests/golden/full_r101_seed3.npz (the oracle needs minutes per pair at that size).
+
+Tolerances (float32 network, ~104 conv layers, different accumulation order):
+  feature maps / logits: 2e-4 * max(1, |ref|max);  regressions (bbox_pred, dim_orien_pred):
+  1e-4 absolute (north_star);  proposals: 2e-3 px;  index outputs: exact where inputs are identical.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _nchw(buf, b):
+    return buf[b].permute(2, 0, 1).contiguous().cpu()
+
+
+def _relerr(got, ref):
+    return float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+
+
+def _build_model(dev, seed=3):
+    from stereo_rcnn_amd import fixture
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    m = resnet(('__background__', 'Car'), 101, pretrained=False)
+    m.create_architecture()
+    sd = fixture.make_state_dict(seed)
+    m.load_state_dict(sd)
+    m.cuda()
+    m.eval()
+    return m, sd
+
+
+@pytest.fixture(scope='module')
+def small(dev):
+    from oracle import net as onet
+    from stereo_rcnn_amd import fixture
+    torch.set_num_threads(os.cpu_count())
+    m, sd = _build_model(dev)
+    l, r, info = fixture.make_inputs(3, 120, 400, target_short=192)
+    ref = onet.forward(sd, l, r, info, keep=True)
+    with torch.no_grad():
+        out = m(l.to(dev), r.to(dev), info.to(dev), None, None, None, None, None, None)
+    torch.cuda.synchronize()
+    plan = m._get_plan(1, l.shape[2], l.shape[3])
+    return {'m': m, 'sd': sd, 'ref': ref, 'out': out, 'plan': plan, 'inputs': (l, r, info)}
+
+
+def test_forward_returns_reference_tuple(small):
+    out = small['out']
+    assert len(out) == 15
+    assert out[0].shape == (1, 300, 5) and out[1].shape == (1, 300, 5)
+    assert out[2].shape == (1, 300, 2) and out[3].shape == (1, 300, 12) and out[4].shape == (1, 300, 10)
+    assert out[5].shape == (300, 112) and out[6].shape == (300, 28) and out[7].shape == (300, 28)
+    assert out[8] == 0 and out[9] == 0 and out[10] == 0 and out[11] == 0 and out[14] is None
+
+
+def test_trunk_and_fpn_maps(small):
+    plan, ref = small['plan'], small['ref']
+    for i in range(4):
+        for side, key in ((0, 'c_left'), (1, 'c_right')):
+            e = _relerr(_nchw(plan.c[i], side), ref[key][i][0])
+            assert e < 2e-4, ('c', i + 2, side, e)
+    for i, buf in enumerate((plan.p2, plan.p3, plan.p4, plan.p5, plan.p6)):
+        for side, key in ((0, 'p_left'), (1, 'p_right')):
+            e = _relerr(_nchw(buf, side), ref[key][i][0])
+            assert e < 2e-4, ('p', i + 2, side, e)
+
+
+def test_rpn_probs_and_deltas(small):
+    plan, ref = small['plan'], small['ref']
+    assert [list(s) for s in plan.rpn_shapes] == ref['rpn_shapes']
+    assert float((plan.probs.cpu() - ref['rpn_probs']).abs().max()) < 1e-4
+    assert _relerr(plan.deltas.cpu(), ref['rpn_deltas']) < 2e-4
+
+
+def test_proposal_layer_isolated(small, dev):
+    """Same probs/deltas in -> same proposals out (sort is stable in both; exp() may differ by an ulp)."""
+    from stereo_rcnn_amd.model.rpn.proposal_layer import _ProposalLayer
+    ref = small['ref']
+    layer = _ProposalLayer(16, [0.5, 1, 2])
+    info = small['inputs'][2]
+    rl, rr = layer((ref['rpn_probs'].to(dev), ref['rpn_deltas'].to(dev), info.to(dev), 'TEST', ref['rpn_shapes']))
+    n_ref = len(ref['proposal_extra']['keep'][0])
+    assert int(layer.last_num_valid[0]) == n_ref
+    assert float((rl.cpu() - ref['rois_left']).abs().max()) < 2e-3
+    assert float((rr.cpu() - ref['rois_right']).abs().max()) < 2e-3
+
+
+def test_heads_isolated(small, dev):
+    """Heads fed with the oracle's FPN maps and proposals."""
+    from stereo_rcnn_amd import engine
+    plan, ref = small['plan'], small['ref']
+    for i, buf in enumerate((plan.p2, plan.p3, plan.p4, plan.p5)):
+        both = torch.cat((ref['p_left'][i], ref['p_right'][i]), 0).to(dev)
+        buf.copy_(engine.nchw_to_nhwc(both))
+    plan.rois_left.copy_(ref['rois_left'].to(dev))
+    plan.rois_right.copy_(ref['rois_right'].to(dev))
+    plan.heads()
+    torch.cuda.synchronize()
+    o = plan.outputs()
+    sem = plan.sem.permute(0, 3, 1, 2).cpu()
+    assert torch.equal(sem, ref['sem_feat'])                    # fused pyramid ROIAlign is bit-exact
+    assert torch.equal(plan.kp_in.permute(0, 3, 1, 2).cpu(), ref['kpts_feat'])
+    assert float((o['bbox_pred'].cpu() - ref['bbox_pred']).abs().max()) < 1e-4
+    assert float((o['dim_orien_pred'].cpu() - ref['dim_orien_pred']).abs().max()) < 1e-4
+    assert float((o['cls_prob'].cpu() - ref['cls_prob']).abs().max()) < 1e-4
+    assert float((o['kpts_prob'].cpu() - ref['kpts_prob']).abs().max()) < 1e-4
+    assert float((o['left_border_prob'].cpu() - ref['left_border_prob']).abs().max()) < 1e-4
+    assert float((o['right_border_prob'].cpu() - ref['right_border_prob']).abs().max()) < 1e-4
+
+
+def _match_rois(got, ref, tol):
+    """For each reference roi the index of the closest HIP roi (L-inf over the 4 coords), or -1."""
+    d = (ref[:, None, 1:] - got[None, :, 1:]).abs().amax(2)
+    best, idx = d.min(1)
+    idx[best > tol] = -1
+    return idx
+
+
+def _check_end_to_end(out, ref_rois_l, ref_rois_r, ref_out, min_frac):
+    rl, rr = out[0][0].cpu(), out[1][0].cpu()
+    idx = _match_rois(rl, ref_rois_l, 5e-2)
+    ok = idx >= 0
+    frac = float(ok.float().mean())
+    assert frac >= min_frac, frac            # discrete sort/NMS decisions on near-tied scores may differ
+    j = idx[ok]
+    assert float((rr[j] - ref_rois_r[ok]).abs().max()) < 5e-2
+    errs = {}
+    for k, t in (('cls_prob', out[2][0]), ('bbox_pred', out[3][0]), ('dim_orien_pred', out[4][0]),
+                 ('kpts_prob', out[5]), ('left_border_prob', out[6]), ('right_border_prob', out[7])):
+        r = ref_out[k]
+        r = r[0] if r.dim() == 3 else r
+        errs[k] = float((t.cpu()[j] - r[ok]).abs().max())
+    return frac, errs
+
+
+def test_end_to_end_small(small):
+    ref = small['ref']
+    frac, errs = _check_end_to_end(small['out'], ref['rois_left'][0], ref['rois_right'][0], ref, 0.95)
+    print('matched fraction', frac, errs)
+    for k, v in errs.items():
+        assert v < 2e-3, (k, v)     # proposals differ by <=5e-2 px here, so outputs move a little
+
+
+def test_graph_replay_matches_eager(small, dev):
+    m = small['m']
+    l, r, info = [t.to(dev) for t in small['inputs']]
+    eager = small['out']
+    m.use_graph = True
+    try:
+        with torch.no_grad():
+            g1 = m(l, r, info)
+            g2 = m(l, r, info)
+        torch.cuda.synchronize()
+    finally:
+        m.use_graph = False
+    for a, b, c in zip(eager[:8], g1[:8], g2[:8]):
+        assert torch.equal(a, b) and torch.equal(a, c)      # deterministic kernels: bitwise repeatable
+
+
+def test_full_size_vs_golden(dev):
+    """BASELINE configs[1]: 375x1242 pair -> 600x1987, ResNet-101 FPN, 300 proposals."""
+    from stereo_rcnn_amd import fixture
+    path = os.path.join(GOLD, 'full_r101_seed3.npz')
+    if not os.path.exists(path):
+        pytest.skip('full-size golden not generated')
+    g = np.load(path)
+    m, _ = _build_model(dev)
+    l, r, info = fixture.make_inputs(3, 375, 1242)
+    assert list(l.shape) == list(g['input_shape'])
+    with torch.no_grad():
+        out = m(l.to(dev), r.to(dev), info.to(dev))
+    torch.cuda.synchronize()
+    plan = m._get_plan(1, l.shape[2], l.shape[3])
+    worst = 0.0
+    for key, bufs, side in (('c_left', plan.c, 0), ('c_right', plan.c, 1),
+                            ('p_left', (plan.p2, plan.p3, plan.p4, plan.p5, plan.p6), 0),
+                            ('p_right', (plan.p2, plan.p3, plan.p4, plan.p5, plan.p6), 1)):
+        for i, buf in enumerate(bufs):
+            got = _nchw(buf, side).reshape(-1)[torch.from_numpy(g['%s%d_pos' % (key, i)])]
+            refv = torch.from_numpy(g['%s%d_val' % (key, i)])
+            e = _relerr(got, refv)
+            worst = max(worst, e)
+            assert e < 2e-4, (key, i, e)
+    pos = torch.from_numpy(g['rpn_pos'])
+    assert float((plan.probs[0].cpu()[pos] - torch.from_numpy(g['rpn_probs_val'])).abs().max()) < 1e-4
+    assert _relerr(plan.deltas[0].cpu()[pos], torch.from_numpy(g['rpn_deltas_val'])) < 2e-4
+    ref_out = {k: torch.from_numpy(g[k]) for k in ('cls_prob', 'bbox_pred', 'dim_orien_pred', 'kpts_prob',
+                                                   'left_border_prob', 'right_border_prob')}
+    frac, errs = _check_end_to_end(out, torch.from_numpy(g['rois_left'])[0], torch.from_numpy(g['rois_right'])[0],
+                                   ref_out, 0.90)
+    print('full-size: worst feature rel err %.2e, matched proposals %.3f, head errs %s' % (worst, frac, errs))
+    for k, v in errs.items():
+        assert v < 2e-3, (k, v)
+
+
+def test_decode_and_class_nms_isolated(small, dev):
+    """Decode + per-class NMS fed with the ORACLE's network outputs: boxes within float rounding
+    (expf may differ by an ulp), kept indices bit-exact."""
+    from oracle import postprocess as opost
+    from stereo_rcnn_amd import postprocess as hpost
+    ref = small['ref']
+    info = small['inputs'][2]
+    rdet = opost.decode_detections(ref, info)
+    rcls = opost.class_detections(rdet)
+    args = [ref[k].to(dev) for k in ('rois_left', 'rois_right', 'cls_prob', 'bbox_pred', 'dim_orien_pred',
+                                     'kpts_prob', 'left_border_prob', 'right_border_prob')]
+    det = hpost.decode_detections(*args, info.to(dev))
+    for k in ('boxes_left', 'boxes_right', 'dim_orien', 'kpts'):
+        assert float((det[k].cpu() - rdet[k]).abs().max()) < 1e-3, k
+    assert torch.equal(det['kpts'][:, 1].cpu(), rdet['kpts'][:, 1])          # keypoint type: exact
+    # NMS on identical boxes: feed the oracle's decoded boxes so the index chain must be bit-exact
+    det_same = {k: (v.to(dev).contiguous() if torch.is_tensor(v) else v) for k, v in rdet.items()}
+    cls = hpost.class_detections(det_same)
+    ref_idx = rcls['inds'][rcls['order']][torch.from_numpy(rcls['keep'].astype(np.int64))]
+    assert torch.equal(cls['keep_idx'].cpu().long(), ref_idx)
+    assert torch.equal(cls['dets_left'].cpu(), rcls['dets_left'])
+    assert torch.equal(cls['kpts'].cpu(), rcls['kpts'])
