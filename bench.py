@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Headline benchmark: stereo pairs/sec @1242x375 (600x1987 network input), ResNet-101 FPN,
+batch=1, 300 proposals, no dense-align  (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one synthetic stereo pair per GPU:
+  _StereoRCNN.forward (trunk+FPN on both eyes, stereo RPN, proposals, ROIAlign, heads)
+  + detection decode + per-class NMS  (the reference's det_time region, demo.py:137-220, plus :231-257)
+  + (N > 1) an RCCL all_gather of the fixed-size detection record.
+Inputs are preprocessed and resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--height', type=int, default=375)
+    ap.add_argument('--width', type=int, default=1242)
+    return ap.parse_args()
+
+
+def cpu_baseline(seed, height, width):
+    """The CPU oracle (a port of the reference path; the reference itself cannot be imported or
+    built here) timed on the host cores: one full stereo pair, forward + decode (det_time)."""
+    from oracle import net as onet
+    from oracle import postprocess as opost
+    from stereo_rcnn_amd import fixture
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = fixture.make_state_dict(seed)
+    l, r, info = fixture.make_inputs(seed, height, width)
+    t0 = time.time()
+    out = onet.forward(sd, l, r, info)
+    det = opost.decode_detections(out, info)
+    opost.class_detections(det)
+    dt = time.time() - t0
+    return {'value': 1.0 / dt, 'unit': 'stereo pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 stereo pair %dx%d (network input %dx%d): full forward + decode + class NMS, %.1f s'
+                      % (width, height, l.shape[3], l.shape[2], dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from stereo_rcnn_amd import _lib, engine, fixture
+    from stereo_rcnn_amd import distributed as sdist
+    from stereo_rcnn_amd import postprocess as hpost
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+
+    _lib.lib()    # fail loudly right here if the HIP library is missing
+    model = resnet(('__background__', 'Car'), 101, pretrained=False)
+    model.create_architecture()
+    model.load_state_dict(fixture.make_state_dict(3))
+    model.cuda()
+    model.eval()
+    model.use_graph = not args.no_graph
+    # every rank works on its own synthetic pair (weak scaling: per-GPU work is fixed)
+    im_l, im_r, im_info = [t.to(dev) for t in fixture.make_inputs(3 + rank, args.height, args.width)]
+    gather_stream = torch.cuda.Stream() if world > 1 else None
+
+    def step():
+        out = model(im_l, im_r, im_info)
+        det = hpost.decode_detections(out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], im_info)
+        keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
+        if world > 1:
+            rec = sdist.pack_records_device(det, keep_idx, num, 1)
+            gather_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(gather_stream):      # xGMI gather overlaps the next pair's trunk
+                rec.record_stream(gather_stream)
+                sdist.gather_detections(rec)
+        return keep_idx, num
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el[0])
+
+        # ---- roofline of the dominant kernel (conv engine, fp32 MFMA): HIP events recorded by the
+        # library on the launch stream around every conv launch, over the same K steps (eager
+        # launches: events cannot be read back from inside a replayed graph).
+        roofline = None
+        if rank == 0:
+            L = _lib.lib()
+            model.use_graph = False
+            step()
+            torch.cuda.synchronize()
+            engine.FlopCounter.enabled, engine.FlopCounter.flops, engine.FlopCounter.launches = True, 0.0, 0
+            L.srcnn_prof_enable(1)
+            nprof = min(args.steps, 5)
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
+            ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+            L.srcnn_prof_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
+            L.srcnn_prof_enable(0)
+            engine.FlopCounter.enabled = False
+            alg = engine.FlopCounter.flops
+            achieved = alg / (ms.value * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (fp32 implicit-GEMM conv engine)',
+                        'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                        'launches_per_step': int(cnt.value // nprof),
+                        'avg_launch_ms': round(ms.value / max(cnt.value, 1), 5),
+                        'algorithmic_gflop_per_step': round(alg / nprof / 1e9, 1),
+                        'conv_ms_per_step': round(ms.value / nprof, 3)}
+            model.use_graph = not args.no_graph
+
+    if rank == 0:
+        pairs = args.steps * world
+        res = {
+            'metric': 'stereo pairs/sec @1242x375 ResNet-101', 'value': round(pairs / elapsed, 3),
+            'unit': 'stereo pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: ResNet-101 FPN, batch=1 stereo pair per GPU, %dx%d synthetic '
+                                   '(network input %dx%d), 300 proposals, forward + decode + class NMS, no dense-align'
+                                   % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
+                       'weights': 'seeded random init, reference state_dict schema', 'hipgraph': not args.no_graph,
+                       'parallelism': 'pairs sharded 1/GPU, RCCL all_gather of detections' if world > 1 else 'single GPU'},
+            'roofline': roofline,
+        }
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(3, args.height, args.width)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,73 @@
+"""Multi-GPU driver pieces: stereo pairs shard embarrassingly, detections are gathered.
+
+The reference has no parallelism at all (test.sh pins one GPU and
+test_net.py loops over images with batch_size=1).  MI355X design: one process per GPU
+(torch.distributed, backend "nccl" == RCCL over xGMI), pair i -> rank i mod world, weights
+replicated, NO collective on the data path; one all_gather of fixed-size padded detection
+records per step (~29 KB/image: latency-bound on xGMI, issued asynchronously).
+"""
+import torch
+import torch.distributed as dist
+
+REC_COLS = 24    # [score, left box 4, right box 4, dim_orien 5, kpts 5, roi index, pad...]
+
+
+def shard_indices(num_items, rank, world_size):
+    """Pair indices owned by `rank`: i with i % world_size == rank (order preserved)."""
+    return list(range(rank, num_items, world_size))
+
+
+def pack_records(cls_det, max_det=300):
+    """Per-class detection dict (postprocess.class_detections) -> fixed (max_det + 1, REC_COLS)
+    float32 record; row 0 holds the valid count."""
+    dl = cls_det['dets_left']
+    dev = dl.device
+    k = min(int(dl.shape[0]), max_det)
+    rec = torch.zeros((max_det + 1, REC_COLS), dtype=torch.float32, device=dev)
+    rec[0, 0] = k
+    if k:
+        rec[1:k + 1, 0] = dl[:k, 4]
+        rec[1:k + 1, 1:5] = dl[:k, :4]
+        rec[1:k + 1, 5:9] = cls_det['dets_right'][:k, :4]
+        rec[1:k + 1, 9:14] = cls_det['dim_orien'][:k]
+        rec[1:k + 1, 14:19] = cls_det['kpts'][:k]
+        rec[1:k + 1, 19] = cls_det['keep_idx'][:k].float()
+    return rec
+
+
+def pack_records_device(det, keep_idx, num, j=1):
+    """Same record, built on the device from the -1 padded keep list with no host sync
+    (det: postprocess.decode_detections; keep_idx/num: postprocess.class_nms_device)."""
+    n = int(keep_idx.shape[0])
+    dev = keep_idx.device
+    idx = keep_idx.clamp(min=0).long()
+    valid = (torch.arange(n, device=dev) < num.to(torch.int64)).float().unsqueeze(1)
+    body = torch.zeros((n, REC_COLS), dtype=torch.float32, device=dev)
+    body[:, 0] = det['scores'][idx, j]
+    body[:, 1:5] = det['boxes_left'][idx, 4 * j:4 * j + 4]
+    body[:, 5:9] = det['boxes_right'][idx, 4 * j:4 * j + 4]
+    body[:, 9:14] = det['dim_orien'][idx, 5 * j:5 * j + 5]
+    body[:, 14:19] = det['kpts'][idx]
+    body[:, 19] = idx.float()
+    head = torch.zeros((1, REC_COLS), dtype=torch.float32, device=dev)
+    head[0, 0] = num[0].float()
+    return torch.cat((head, body * valid), 0)
+
+
+def unpack_records(rec):
+    k = int(rec[0, 0])
+    body = rec[1:k + 1]
+    return {'scores': body[:, 0], 'boxes_left': body[:, 1:5], 'boxes_right': body[:, 5:9],
+            'dim_orien': body[:, 9:14], 'kpts': body[:, 14:19], 'roi_index': body[:, 19].long()}
+
+
+def gather_detections(rec, async_op=False):
+    """all_gather of one fixed-size record per rank -> (world, max_det + 1, REC_COLS) on every rank.
+    Works with the gloo backend on CPU tensors (tests) and nccl/RCCL on device tensors."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return rec.unsqueeze(0), None
+    out = torch.empty((world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
+    work = dist.all_gather_into_tensor(out.view(-1), rec.contiguous().view(-1), async_op=async_op) \
+        if rec.is_cuda else dist.all_gather(list(out.unbind(0)), rec.contiguous(), async_op=async_op)
+    return out, work

@@ -20,6 +20,7 @@ class ConvW(object):
         self.cout = int(weight.shape[0])
         self.cin = int(weight.numel() // (weight.shape[0] * kh * kw))
         self.kh, self.kw, self.stride, self.pad, self.relu, self.mode = kh, kw, stride, pad, int(relu), mode
+        self.alg_k = self.cin * kh * kw      # algorithmic K (the stem pads 147 -> 224; see prep_stem)
 
 
 def fold_bn(w, bn, eps=1e-5):
@@ -47,6 +48,7 @@ def prep_stem(w, bn, device='cuda'):
     wt = torch.zeros(cout, 7, 8, 4)
     wt[:, :, :7, :3] = wf.permute(0, 2, 3, 1)          # (co, kh, kw, c)
     cw = ConvW(wt.view(cout, 7, 1, 32).to(device), bf.to(device), 7, 1, 2, 0, True)
+    cw.alg_k = 3 * 7 * 7
     return cw
 
 
@@ -66,6 +68,13 @@ def prep_linear_stack(ws, bs, device='cuda'):
 
 def conv_out_hw(h, w, k_h, k_w, stride, pad):
     return (h + 2 * pad - k_h) // stride + 1, (w + 2 * pad - k_w) // stride + 1
+
+
+class FlopCounter(object):
+    """Algorithmic conv FLOPs (2*M*N*K with the true K) of the launches issued while enabled."""
+    enabled = False
+    flops = 0.0
+    launches = 0
 
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
@@ -88,6 +97,9 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     d.res_cstride = cw.cout if res_cstride is None else res_cstride
     d.relu = cw.relu if relu is None else int(relu)
     d.mode = cw.mode
+    if FlopCounter.enabled:
+        FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
+        FlopCounter.launches += 1
     need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _lib.workspace(need, x.device, "conv")
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")

@@ -36,22 +36,30 @@ def decode_detections(rois_left, rois_right, cls_prob, bbox_pred, dim_orien_pred
     return {'scores': f(cls_prob[0]), 'boxes_left': boxes_l, 'boxes_right': boxes_r, 'dim_orien': dim, 'kpts': kpts}
 
 
-def class_detections(det, j=1, thresh=0.05, nms_thresh=None):
-    """demo.py:231-257 for class j: score > thresh, stable descending sort, NMS on the LEFT boxes,
-    gather.  Returns dict(dets_left (k,5), dets_right (k,5), dim_orien (k,5), kpts (k,5), keep_idx (k,))
-    where keep_idx are row indices into the 300 rois, in descending score order."""
+def class_nms_device(det, j=1, thresh=0.05, nms_thresh=None):
+    """Device-only part of demo.py:231-257: returns (keep_idx (n) int32, -1 padded, descending score
+    order; num (1) int32) without any host synchronisation."""
     if nms_thresh is None:
         nms_thresh = cfg.TEST.NMS
     scores = det['scores']
     n, n_cls = int(scores.shape[0]), int(scores.shape[1])
     dev = scores.device
     keep_idx = torch.empty((n,), dtype=torch.int32, device=dev)
-    num = torch.zeros((1,), dtype=torch.int32, device=dev)
+    num = torch.empty((1,), dtype=torch.int32, device=dev)
     L = _lib.lib()
     ws = _lib.workspace(L.srcnn_class_nms_workspace_bytes(n), dev, "class_nms")
     _lib.check(L.srcnn_class_nms(scores.data_ptr(), n, n_cls, j, det['boxes_left'].data_ptr(), float(thresh),
                                  float(nms_thresh), keep_idx.data_ptr(), num.data_ptr(), ws.data_ptr(), ws.numel(),
                                  _lib.stream()), "srcnn_class_nms")
+    return keep_idx, num
+
+
+def class_detections(det, j=1, thresh=0.05, nms_thresh=None):
+    """demo.py:231-257 for class j: score > thresh, stable descending sort, NMS on the LEFT boxes,
+    gather.  Returns dict(dets_left (k,5), dets_right (k,5), dim_orien (k,5), kpts (k,5), keep_idx (k,))
+    where keep_idx are row indices into the 300 rois, in descending score order."""
+    keep_idx, num = class_nms_device(det, j, thresh, nms_thresh)
+    scores = det['scores']
     k = int(num[0])                                 # the one host sync, same place as nms_gpu.py:11
     idx = keep_idx[:k].long()
     sc = scores[idx, j].unsqueeze(1)

@@ -1,0 +1,79 @@
+"""CPU: the N>1 path (pair sharding + detection gather) with the gloo backend, world_size 2."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from stereo_rcnn_amd import distributed as sdist
+
+
+def test_shard_indices_partition():
+    for world in (1, 2, 3, 8):
+        parts = [sdist.shard_indices(3769, r, world) for r in range(world)]     # KITTI val list size
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(3769))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    k = 7
+    det = {'dets_left': torch.rand(k, 5), 'dets_right': torch.rand(k, 5), 'dim_orien': torch.rand(k, 5),
+           'kpts': torch.rand(k, 5), 'keep_idx': torch.arange(k, dtype=torch.int32) * 3}
+    rec = sdist.pack_records(det)
+    assert rec.shape == (301, sdist.REC_COLS)
+    u = sdist.unpack_records(rec)
+    assert torch.equal(u['boxes_left'], det['dets_left'][:, :4]) and torch.equal(u['scores'], det['dets_left'][:, 4])
+    assert u['roi_index'].tolist() == [0, 3, 6, 9, 12, 15, 18]
+    # device-style packing (no host sync) gives the same record
+    full = {'scores': torch.zeros(300, 2), 'boxes_left': torch.zeros(300, 8), 'boxes_right': torch.zeros(300, 8),
+            'dim_orien': torch.zeros(300, 10), 'kpts': torch.zeros(300, 5)}
+    idx = det['keep_idx'].long()
+    full['scores'][idx, 1] = det['dets_left'][:, 4]
+    full['boxes_left'][idx, 4:8] = det['dets_left'][:, :4]
+    full['boxes_right'][idx, 4:8] = det['dets_right'][:, :4]
+    full['dim_orien'][idx, 5:10] = det['dim_orien']
+    full['kpts'][idx] = det['kpts']
+    keep = torch.full((300,), -1, dtype=torch.int32)
+    keep[:k] = det['keep_idx']
+    rec2 = sdist.pack_records_device(full, keep, torch.tensor([k], dtype=torch.int32), 1)
+    assert torch.allclose(rec2, rec)
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mine = sdist.shard_indices(10, rank, world)
+    rec = torch.zeros(301, sdist.REC_COLS)
+    rec[0, 0] = len(mine)
+    rec[1:1 + len(mine), 0] = torch.tensor(mine, dtype=torch.float32)
+    out, work = sdist.gather_detections(rec)
+    if work is not None:
+        work.wait()
+    got = []
+    for r in range(world):
+        k = int(out[r, 0, 0])
+        got += out[r, 1:1 + k, 0].long().tolist()
+    q.put((rank, sorted(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, got in res:
+        assert got == list(range(10))      # every rank sees every pair's record exactly once
