@@ -45,7 +45,9 @@ def cpu_baseline(seed, height, width):
     from oracle import net as onet
     from oracle import postprocess as opost
     from stereo_rcnn_amd import fixture
-    cores = os.cpu_count() or 1
+    # oneDNN scales poorly past a few dozen threads on this network (measured on the 256-core GPU
+    # host: 8-16 threads are fastest, 256 threads are ~100x slower), so the baseline uses <= 16.
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     sd = fixture.make_state_dict(seed)
     l, r, info = fixture.make_inputs(seed, height, width)

@@ -45,7 +45,7 @@ def prep_stem(w, bn, device='cuda'):
     """7x7/2 stem (resnet.py:109) as 7 row-taps of 32 floats = 8 pixels x NHWC4 (see srcnn_stem_pack)."""
     wf, bf = fold_bn(w, bn)
     cout = wf.shape[0]
-    wt = torch.zeros(cout, 7, 8, 4)
+    wt = torch.zeros(cout, 7, 8, 4, device=wf.device)
     wt[:, :, :7, :3] = wf.permute(0, 2, 3, 1)          # (co, kh, kw, c)
     cw = ConvW(wt.view(cout, 7, 1, 32).to(device), bf.to(device), 7, 1, 2, 0, True)
     cw.alg_k = 3 * 7 * 7

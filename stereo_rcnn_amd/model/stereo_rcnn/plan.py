@@ -26,7 +26,9 @@ class Weights(object):
     """Engine-ready weights built from a reference-schema state_dict (CPU tensors)."""
 
     def __init__(self, sd, device):
-        sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        # re-layout / BN folding run on the device (load-time plumbing; float64 fold is cheap there)
+        sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in sd.items()
+              if not k.endswith('num_batches_tracked')}
         self.device = device
         self.stem = engine.prep_stem(sd['RCNN_layer0.0.weight'], _bn_dict(sd, 'RCNN_layer0.1'), device)
         self.layers = []

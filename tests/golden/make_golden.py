@@ -31,7 +31,7 @@ def sample_positions(numel, k, seed):
 
 
 def network_case(name, height, width, target_short, seed=3):
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 16))
     sd = fixture.make_state_dict(seed)
     l, r, info = fixture.make_inputs(seed, height, width, target_short=target_short)
     t = time.time()

@@ -43,7 +43,7 @@ def _build_model(dev, seed=3):
 def small(dev):
     from oracle import net as onet
     from stereo_rcnn_amd import fixture
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 16))
     m, sd = _build_model(dev)
     l, r, info = fixture.make_inputs(3, 120, 400, target_short=192)
     ref = onet.forward(sd, l, r, info, keep=True)

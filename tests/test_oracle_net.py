@@ -83,7 +83,7 @@ def test_decode_matches_hand_computation():
 def test_small_network_matches_golden():
     """Regression pin of the whole oracle (trunk, FPN, RPN, proposals, ROIAlign, heads, decode)."""
     g = np.load(os.path.join(GOLD, 'small_r101_seed3.npz'))
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 16))
     sd = fixture.make_state_dict(3)
     l, r, info = fixture.make_inputs(3, 120, 400, target_short=192)
     assert list(l.shape) == list(g['input_shape'])
