@@ -160,6 +160,21 @@ SRCNN_API int srcnn_class_nms(const float *scores, int n, int n_cls, int j, cons
                     float score_thresh, float nms_thresh, int *keep_idx, int *num_keep,
                     void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
 
+/* ------------------------------------------------------------ dense alignment (A15-A16)
+ * Replaces lib/model/dense_align/dense_align.py:13-69,175-300 + box_3d.py:12-106 (align_parallel).
+ * im_left/right: (3, H, W) planar float32 network-input tensors; the 2x align_corners bilinear
+ * upsample of dense_align.py:256-257 is done inside (workspace).  boxes (R,4) and borders (R,2)
+ * in ORIGINAL-image pixels (borders = keypoints[:,3:5]), poses (R,7) [x,y,z,w,h,l,theta].
+ * scale = im_info[0,2]; p2_00/p2_02/p2_12 = P2 focal/cx/cy; p2_03_minus_p3_03 = P2[0,3]-P3[0,3]
+ * (host doubles, as in the reference).  max_pixels bounds the per-object sample count (extra
+ * samples are dropped).  Outputs status (R) and best_dis (R) float32 on the device. */
+SRCNN_API size_t srcnn_dense_align_workspace_bytes(int H, int W, int R, int max_pixels);
+SRCNN_API int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W, double scale,
+                      double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03,
+                      const float *boxes, const float *borders, const float *poses, int R, int max_pixels,
+                      float *status, float *best_dis, void *workspace, size_t workspace_bytes,
+                      srcnn_stream_t stream);
+
 /* ------------------------------------------------------------------ profiling hooks
  * When enabled, every conv-engine launch is bracketed by hipEvents on its stream; the
  * accumulated kernel time / algorithmic flops / launch count are read back with

@@ -1,0 +1,43 @@
+"""`align_parallel` - reference lib/model/dense_align/dense_align.py:240-300, one native call."""
+import torch
+
+from ... import _lib
+
+MAX_PIXELS = 8192    # per-object sample bound (the reference's lattice is <= ~45 x 113 points)
+
+
+def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses):
+    """Dense alignment for multiple objects, depth enumeration in parallel.
+
+    Inputs (as the reference):
+        calib: object with `.p2`, `.p3` (3x4, kitti_utils.read_obj_calibration)
+        scale: H_im_left / H_origin_img (im_info[0,2])
+        im_left, im_right: 1 x 3 x H x W network inputs (device)
+        box_left: rois x 4 in the origin image
+        keypoints: rois x 5 (kpt, kpt_type, prob, left_border, right_border in the origin image)
+        poses: rois x 7 (x, y, z, w, h, l, theta)
+    Returns:
+        solve_status: 1 = success, 0 = failed (no valid pixel)   (rois)
+        best_dis: aligned disparity in the origin image          (rois)
+    """
+    assert im_left.is_cuda, "device tensors required (no CPU path)"
+    dev = im_left.device
+    f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    im_l, im_r = f(im_left), f(im_right)
+    _, _, H, W = im_l.shape
+    boxes = f(box_left)
+    borders = f(keypoints[:, 3:5])
+    poses = f(poses[:, 0:7])
+    R = int(boxes.shape[0])
+    status = torch.zeros((R,), dtype=torch.float32, device=dev)
+    best_dis = torch.zeros((R,), dtype=torch.float32, device=dev)
+    if R == 0:
+        return status, best_dis
+    L = _lib.lib()
+    ws = _lib.workspace(L.srcnn_dense_align_workspace_bytes(H, W, R, MAX_PIXELS), dev, "dense_align")
+    _lib.check(L.srcnn_dense_align(im_l.data_ptr(), im_r.data_ptr(), H, W, float(scale),
+                                   float(calib.p2[0, 0]), float(calib.p2[0, 2]), float(calib.p2[1, 2]),
+                                   float(calib.p2[0, 3] - calib.p3[0, 3]), boxes.data_ptr(), borders.data_ptr(),
+                                   poses.data_ptr(), R, MAX_PIXELS, status.data_ptr(), best_dis.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_dense_align")
+    return status, best_dis

@@ -98,3 +98,26 @@ def test_small_network_matches_golden():
         assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
     e = out['proposal_extra']
     assert len(e['keep'][0]) == len(g['keep'])
+
+
+def test_dense_align_oracle_recovers_planted_disparity():
+    """Pins oracle/dense_align.py without any reference fixture: a constant planted disparity."""
+    from oracle import dense_align as oda
+    rng = np.random.default_rng(0)
+    H, W, d0 = 120, 400, 12.0
+    tex = 0.6 * fixture._smooth_noise(rng, H, W + 64, 16) + 0.4 * fixture._smooth_noise(rng, H, W + 64, 4)
+    left = np.clip(np.rint(tex[:, :W] * 255), 0, 255).astype(np.uint8)
+    right = np.clip(np.rint(tex[:, int(d0):W + int(d0)] * 255), 0, 255).astype(np.uint8)
+    tl, s = fixture.preprocess(left, target_short=H)       # scale 1
+    tr, _ = fixture.preprocess(right, target_short=H)
+    calib = oda.Calib([200.0, 0, 200.0, 0, 0, 200.0, 60.0, 0, 0, 0, 1, 0], [200.0, 0, 200.0, -100.0, 0, 200.0, 60.0, 0, 0, 0, 1, 0])
+    fb = 100.0
+    z = fb / d0
+    pose = torch.tensor([[0.0, 1.2, z + 1.5, 1.6, 1.5, 2.0, 0.0]])
+    box = torch.tensor([oda.project_box(calib, [0.0, 1.2, z, 1.6, 1.5, 2.0, 0.0])], dtype=torch.float32)
+    kp = torch.zeros(1, 5)
+    kp[:, 3], kp[:, 4] = box[:, 0], box[:, 2]
+    st, dis, ex = oda.align_parallel(calib, s, tl, tr, box, kp, pose, return_extra=True)
+    assert st.tolist() == [1.0] and ex['weight'].sum() > 50
+    z_star = fb / d0 + 1.0            # front face is l/2 = 1 m in front of the centre
+    assert abs(float(dis[0]) - (fb / z_star + 0.5)) < 0.5, float(dis[0])
