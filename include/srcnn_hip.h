@@ -87,7 +87,8 @@ SRCNN_API int srcnn_pyramid_roi_align(const float *const *maps_host, const int *
 /* ------------------------------------------------- convolution engine (A1-A3, A9, A10)
  * Replaces the cuDNN calls behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear in
  * stereo_rcnn/resnet.py:66-146,243-286, rpn/stereo_rpn.py:32-40.  Implicit GEMM on the
- * fp32 MFMA (v_mfma_f32_32x32x2_f32): y = act(conv(x, w) + bias + residual).
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32) or, with desc.precision = 1, on the f16 MFMA with an
+ * error-compensated 3-term split: y = act(conv(x, w) + bias + residual).
  * x: (B,H,W,*) NHWC with pixel stride x_cstride floats, Cin must be a multiple of 32.
  * w: (Cout, KH, KW, Cin) float32 (K-contiguous rows).  Frozen BN is folded by the caller.
  */
@@ -103,6 +104,12 @@ typedef struct srcnn_conv_desc {
     int y_cstride, y_coffset, res_cstride;
     int relu;
     int mode;              /* 0 = conv; 1 = ConvTranspose2d(k=2,s=2): Cout = 4*Cq ordered (i,j,co) */
+    /* precision 0: fp32 MFMA, `w` is float32.
+     * precision 1: error-compensated 3xf16 MFMA (fp32-class result): `w` = hi halves and `w_lo` = lo
+     *   halves of (weight * 2^k), both (Cout, KH, KW, Cin) _Float16; w_inv_scale = 2^-k. */
+    int precision;
+    const void *w_lo;
+    float w_inv_scale;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);

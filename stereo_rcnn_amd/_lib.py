@@ -24,7 +24,8 @@ class ConvDesc(ctypes.Structure):
                 ("OH", c_int), ("OW", c_int), ("Cout", c_int),
                 ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int),
                 ("y_cstride", c_int), ("y_coffset", c_int), ("res_cstride", c_int),
-                ("relu", c_int), ("mode", c_int)]
+                ("relu", c_int), ("mode", c_int),
+                ("precision", c_int), ("w_lo", c_void_p), ("w_inv_scale", c_float)]
 
 
 _SIGNATURES = {

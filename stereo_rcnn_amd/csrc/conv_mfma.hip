@@ -25,28 +25,9 @@
 //     the grid still covers the chip (partials in the caller's workspace, deterministic reduce).
 //   * epilogue fuses folded-BN bias, residual add, ReLU, channel-offset writes (concat in place)
 //     and the ConvTranspose2d(2,2) pixel scatter.
-#include "common.h"
+#include "conv_common.h"
 
 namespace srcnn {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;          // floats per K tile (128 B)
-constexpr int LDS_ROW = BK + 4; // padded row (floats)
-
-struct ConvArgs {
-    const float *x, *w, *bias, *res;
-    float *y, *partial;
-    int H, W, Cin, xcs;
-    int OH, OW, Cout;
-    int KH, KW, stride, pad;
-    int ycs, yco, rcs, relu, mode;
-    int M, K;
-    int ctiles;       // Cin / 32
-    int nkt;          // K tiles in total
-    int kt_per_split; // K tiles per grid.y slice
-    int mtiles, ntiles;
-};
 
 template <int MR, int NR>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p)
@@ -227,12 +208,9 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
     }
 }
 
-struct Plan {
-    int mr, nr, splits, kt_per_split;
-};
-
-static Plan make_plan(int M, int N, int nkt, int mode)
+static Plan make_plan(int M, int N, int nkt, int mode, int precision)
 {
+    (void)precision;
     static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
     Plan pl{1, 1, 1, nkt};
     const long target = 512;   // >= 2 workgroups per CU
@@ -273,6 +251,9 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     SRCNN_REQUIRE(d->mode == 0 || (d->mode == 1 && d->Cout % 4 == 0 && d->KH == 1 && d->KW == 1 && !d->residual),
                   "bad mode");
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->residual; a.y = d->y; a.partial = nullptr;
+    SRCNN_REQUIRE(d->precision == 0 || (d->precision == 1 && d->w_lo), "bad precision / missing w_lo");
+    a.w_lo = d->w_lo;
+    a.out_scale = d->precision == 1 ? d->w_inv_scale : 1.0f;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.xcs = d->x_cstride;
     a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
@@ -301,7 +282,7 @@ size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d)
     using namespace srcnn;
     ConvArgs a;
     if (fill_args(d, a) != SRCNN_OK) return 0;
-    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode);
+    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
     if (pl.splits <= 1) return 256;
     return align_up((size_t)pl.splits * a.M * a.Cout * sizeof(float), 256);
 }
@@ -312,7 +293,7 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     ConvArgs a;
     int rc = fill_args(d, a);
     if (rc != SRCNN_OK) return rc;
-    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode);
+    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
     a.kt_per_split = pl.kt_per_split;
     a.mtiles = cdiv(a.M, 64 * pl.mr);
     a.ntiles = cdiv(a.Cout, 64 * pl.nr);
@@ -327,7 +308,8 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     hipStream_t st = as_stream(stream);
     const bool prof = prof_enabled();
     if (prof) prof_begin(st);
-    if (pl.mr == 2 && pl.nr == 2) launch<2, 2>(a, pl.splits, st);
+    if (d->precision == 1) launch_conv_f16x3(a, pl, st);
+    else if (pl.mr == 2 && pl.nr == 2) launch<2, 2>(a, pl.splits, st);
     else if (pl.mr == 2 && pl.nr == 1) launch<2, 1>(a, pl.splits, st);
     else if (pl.mr == 1 && pl.nr == 2) launch<1, 2>(a, pl.splits, st);
     else launch<1, 1>(a, pl.splits, st);

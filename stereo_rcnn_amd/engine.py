@@ -21,6 +21,23 @@ class ConvW(object):
         self.cin = int(weight.numel() // (weight.shape[0] * kh * kw))
         self.kh, self.kw, self.stride, self.pad, self.relu, self.mode = kh, kw, stride, pad, int(relu), mode
         self.alg_k = self.cin * kh * kw      # algorithmic K (the stem pads 147 -> 224; see prep_stem)
+        self.w_hi = self.w_lo = None         # f16x3 engine operands (see split_f16x3)
+        self.inv_scale = 1.0
+
+    def split_f16x3(self):
+        """Error-compensated split for the f16 MFMA engine (csrc/conv_f16x3.hip):
+        w * 2^k = hi + lo with hi = f16(w 2^k), lo = f16(w 2^k - hi); k puts max|w| near 2^14 so
+        that lo stays out of the f16 subnormal range.  Exact power-of-two scaling, undone in the epilogue."""
+        if self.w_hi is None:
+            import math
+            m = float(self.weight.abs().max())
+            k = math.floor(math.log2(16384.0 / m)) if m > 0 else 0
+            ws = self.weight * (2.0 ** k)
+            self.w_hi = ws.half()
+            self.w_lo = (ws - self.w_hi.float()).half().contiguous()
+            self.w_hi = self.w_hi.contiguous()
+            self.inv_scale = 2.0 ** (-k)
+        return self
 
 
 def fold_bn(w, bn, eps=1e-5):
@@ -77,13 +94,21 @@ class FlopCounter(object):
     launches = 0
 
 
+PRECISION = 'f32'     # default engine: 'f32' (exact fp32 MFMA) or 'f16x3' (3-term split on the f16 MFMA)
+
+
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
-           res_cstride=None, x_offset_elems=0, relu=None):
+           res_cstride=None, x_offset_elems=0, relu=None, precision=None):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory)."""
     L = _lib.lib()
     d = _lib.ConvDesc()
     d.x = x.data_ptr() + 4 * x_offset_elems
-    d.w = cw.weight.data_ptr()
+    precision = PRECISION if precision is None else precision
+    if precision == 'f16x3':
+        cw.split_f16x3()
+        d.w, d.w_lo, d.w_inv_scale, d.precision = cw.w_hi.data_ptr(), cw.w_lo.data_ptr(), cw.inv_scale, 1
+    else:
+        d.w, d.w_lo, d.w_inv_scale, d.precision = cw.weight.data_ptr(), None, 1.0, 0
     d.bias = cw.bias.data_ptr() if cw.bias is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
     d.y = y.data_ptr()

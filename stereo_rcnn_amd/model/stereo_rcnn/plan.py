@@ -146,7 +146,7 @@ class Plan(object):
         self.kpts_prob = e(R, 4 * G)
         self.left_prob = e(R, G)
         self.right_prob = e(R, G)
-        self.graph = None
+        self.graphs = {}
 
     # ------------------------------------------------------------------ stages
     def trunk(self):
@@ -273,18 +273,24 @@ class Plan(object):
         self.im_right.copy_(im_right, non_blocking=True)
         self.im_info.copy_(im_info.view(self.B, 3), non_blocking=True)
 
-    def run(self, use_graph=False):
-        if not use_graph:
-            self.launch_all()
-            return
-        if self.graph is None:
-            self.launch_all()                 # warm-up: sizes every workspace before capture
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+    def run(self, use_graph=False, precision='f32'):
+        """precision: 'f32' (exact fp32 MFMA engine) or 'f16x3' (3-term split on the f16 MFMA)."""
+        prev = engine.PRECISION
+        engine.PRECISION = precision
+        try:
+            if not use_graph:
                 self.launch_all()
-            self.graph = g
-        self.graph.replay()
+                return
+            if precision not in self.graphs:
+                self.launch_all()                 # warm-up: sizes every workspace, splits weights, before capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.launch_all()
+                self.graphs[precision] = g
+            self.graphs[precision].replay()
+        finally:
+            engine.PRECISION = prev
 
     def outputs(self):
         w, B = self.w, self.B

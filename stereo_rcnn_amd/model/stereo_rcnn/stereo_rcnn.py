@@ -36,6 +36,7 @@ class _StereoRCNN(nn.Module):
         self.RCNN_roi_align = RoIAlignAvg(cfg.POOLING_SIZE, cfg.POOLING_SIZE, 1.0 / 16.0)
         self.RCNN_roi_kpts_align = RoIAlignAvg(cfg.POOLING_SIZE * 2, cfg.POOLING_SIZE * 2, 1.0 / 16.0)
         self.use_graph = False            # replay the forward as one hipGraph (see plan.py)
+        self.precision = 'f32'            # conv engine: 'f32' (exact) or 'f16x3' (error-compensated f16 MFMA)
         self._weights = None
         self._plans = {}
 
@@ -128,7 +129,7 @@ class _StereoRCNN(nn.Module):
         B, _, H, W = im_left_data.shape
         plan = self._get_plan(int(B), int(H), int(W))
         plan.set_inputs(im_left_data, im_right_data, im_info)
-        plan.run(self.use_graph)
+        plan.run(self.use_graph, self.precision)
         o = plan.outputs()
         self.RCNN_loss_cls = 0
         self.RCNN_loss_bbox = 0

@@ -225,3 +225,52 @@ def test_decode_and_class_nms_isolated(small, dev):
     assert torch.equal(cls['keep_idx'].cpu().long(), ref_idx)
     assert torch.equal(cls['dets_left'].cpu(), rcls['dets_left'])
     assert torch.equal(cls['kpts'].cpu(), rcls['kpts'])
+
+
+def test_f16x3_engine_end_to_end_small(small, dev):
+    """The error-compensated f16 engine must pass the SAME end-to-end tolerances as the fp32 engine."""
+    m, ref = small['m'], small['ref']
+    l, r, info = [t.to(dev) for t in small['inputs']]
+    m.precision = 'f16x3'
+    try:
+        with torch.no_grad():
+            out = m(l, r, info)
+        torch.cuda.synchronize()
+        plan = small['plan']
+        for i in range(4):
+            assert _relerr(_nchw(plan.c[i], 0), ref['c_left'][i][0]) < 2e-4
+        for i, buf in enumerate((plan.p2, plan.p3, plan.p4, plan.p5, plan.p6)):
+            assert _relerr(_nchw(buf, 1), ref['p_right'][i][0]) < 2e-4
+        assert float((plan.probs.cpu() - ref['rpn_probs']).abs().max()) < 1e-4
+    finally:
+        m.precision = 'f32'
+    frac, errs = _check_end_to_end(out, ref['rois_left'][0], ref['rois_right'][0], ref, 0.95)
+    print('f16x3: matched fraction', frac, errs)
+    assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4
+    for k, v in errs.items():
+        assert v < 2e-3, (k, v)
+
+
+def test_f16x3_engine_full_size_vs_golden(dev):
+    from stereo_rcnn_amd import fixture
+    g = np.load(os.path.join(GOLD, 'full_r101_seed3.npz'))
+    m, _ = _build_model(dev)
+    m.precision = 'f16x3'
+    l, r, info = fixture.make_inputs(3, 375, 1242)
+    with torch.no_grad():
+        out = m(l.to(dev), r.to(dev), info.to(dev))
+    torch.cuda.synchronize()
+    plan = m._get_plan(1, l.shape[2], l.shape[3])
+    worst = 0.0
+    for key, bufs, side in (('c_left', plan.c, 0), ('p_right', (plan.p2, plan.p3, plan.p4, plan.p5, plan.p6), 1)):
+        for i, buf in enumerate(bufs):
+            got = _nchw(buf, side).reshape(-1)[torch.from_numpy(g['%s%d_pos' % (key, i)])]
+            e = _relerr(got, torch.from_numpy(g['%s%d_val' % (key, i)]))
+            worst = max(worst, e)
+            assert e < 2e-4, (key, i, e)
+    ref_out = {k: torch.from_numpy(g[k]) for k in ('cls_prob', 'bbox_pred', 'dim_orien_pred', 'kpts_prob',
+                                                   'left_border_prob', 'right_border_prob')}
+    frac, errs = _check_end_to_end(out, torch.from_numpy(g['rois_left'])[0], torch.from_numpy(g['rois_right'])[0],
+                                   ref_out, 0.90)
+    print('f16x3 full-size: worst feature rel err %.2e, matched proposals %.3f, head errs %s' % (worst, frac, errs))
+    assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4

@@ -132,7 +132,7 @@ def test_pyramid_roi_align_fused(dev, A):
     assert np.array_equal(got, ref.numpy()), float(np.abs(got - ref.numpy()).max())
 
 
-def _conv_case(dev, B, H, W, cin, cout, k, stride, pad, relu, res, bn, seed):
+def _conv_case(dev, B, H, W, cin, cout, k, stride, pad, relu, res, bn, seed, precision='f32'):
     from stereo_rcnn_amd import engine
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, cin, H, W, generator=g)
@@ -155,7 +155,7 @@ def _conv_case(dev, B, H, W, cin, cout, k, stride, pad, relu, res, bn, seed):
     xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
     rd = r.to(dev).permute(0, 2, 3, 1).contiguous() if res else None
     y = torch.empty((B, OH, OW, cout), device=dev)
-    engine.conv2d(cw, xd, B, H, W, y, OH, OW, residual=rd)
+    engine.conv2d(cw, xd, B, H, W, y, OH, OW, residual=rd, precision=precision)
     got = y.permute(0, 3, 1, 2).cpu()
     err = float((got - ref).abs().max())
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
@@ -173,11 +173,14 @@ def _conv_case(dev, B, H, W, cin, cout, k, stride, pad, relu, res, bn, seed):
     (1, 7, 9, 2048, 512, 1, 1, 0, False, False, False),      # small M, long K -> split-K
     (3, 14, 14, 256, 256, 3, 1, 1, True, False, False),      # kpts tower
 ])
-def test_conv_engine_vs_torch_cpu(dev, case):
-    _conv_case(dev, *case, seed=hash(case) % 1000)
+@pytest.mark.parametrize("precision", ['f32', 'f16x3'])
+def test_conv_engine_vs_torch_cpu(dev, case, precision):
+    """Both engines must meet the SAME tolerance (the f16x3 split is fp32-class by construction)."""
+    _conv_case(dev, *case, seed=hash(case) % 1000, precision=precision)
 
 
-def test_conv_stem_vs_torch_cpu(dev):
+@pytest.mark.parametrize("precision", ['f32', 'f16x3'])
+def test_conv_stem_vs_torch_cpu(dev, precision):
     from stereo_rcnn_amd import engine
     g = torch.Generator().manual_seed(1)
     B, H, W = 2, 75, 131
@@ -193,7 +196,7 @@ def test_conv_stem_vs_torch_cpu(dev):
     engine.stem_pack(x.to(dev), packed)
     OH, OW = ref.shape[2:]
     y = torch.empty((B, OH, OW, 64), device=dev)
-    engine.conv2d(cw, packed, B, H + 6, W + 8, y, OH, OW, x_cstride=4)
+    engine.conv2d(cw, packed, B, H + 6, W + 8, y, OH, OW, x_cstride=4, precision=precision)
     assert float((y.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 1e-4
     PH, PW = refp.shape[2:]
     p = torch.empty((B, PH, PW, 64), device=dev)
@@ -201,7 +204,8 @@ def test_conv_stem_vs_torch_cpu(dev):
     assert float((p.permute(0, 3, 1, 2).cpu() - refp).abs().max()) < 1e-4
 
 
-def test_deconv2x2_vs_torch_cpu(dev):
+@pytest.mark.parametrize("precision", ['f32', 'f16x3'])
+def test_deconv2x2_vs_torch_cpu(dev, precision):
     from stereo_rcnn_amd import engine
     g = torch.Generator().manual_seed(2)
     x = torch.randn(5, 256, 14, 14, generator=g)
@@ -210,7 +214,7 @@ def test_deconv2x2_vs_torch_cpu(dev):
     ref = F.relu(F.conv_transpose2d(x, w, b, 2))
     cw = engine.prep_deconv2x2(w, b, device=dev)
     y = torch.empty((5, 28, 28, 256), device=dev)
-    engine.conv2d(cw, x.to(dev).permute(0, 2, 3, 1).contiguous(), 5, 14, 14, y, 14, 14)
+    engine.conv2d(cw, x.to(dev).permute(0, 2, 3, 1).contiguous(), 5, 14, 14, y, 14, 14, precision=precision)
     assert float((y.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 2e-5
 
 

@@ -24,6 +24,9 @@ SHAPES = [
     ('box.top3 GEMM 300x2048x2048', 300, 1, 1, 2048, 2048, 1, 1, 0),
     ('kpts 3x3 256 (300x14x14)', 300, 14, 14, 256, 256, 3, 1, 1),
 ]
+PREC = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+engine.PRECISION = PREC
+print('precision', PREC)
 for name, B, H, W, cin, cout, k, s, p in SHAPES:
     x = torch.randn(B, H, W, cin, device=dev)
     w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5

@@ -9,6 +9,10 @@ dev = torch.device('cuda:0')
 m = resnet(('__background__', 'Car'), 101); m.create_architecture()
 m.load_state_dict(fixture.make_state_dict(3)); m.cuda(); m.eval()
 l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 375, 1242)]
+m.precision = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+print('precision', m.precision)
+from stereo_rcnn_amd import engine
+engine.PRECISION = m.precision
 for mode in (False, True):
     m.use_graph = mode
     for _ in range(3):
