@@ -24,7 +24,12 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# MI355X_MICROARCH.md dense MFMA peaks (TFLOP/s) for the dtype each conv engine issues
+PEAKS = {'f32': 157.3, 'f16x3': 2500.0}
+ENGINE_DESC = {
+    'f32': 'conv_mfma_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32, exact fp32)',
+    'f16x3': 'conv_f16x3_kernel (implicit-GEMM conv, 3x v_mfma_f32_32x32x16_f16 error-compensated split, fp32 accumulate)',
+}
 
 
 def parse():
@@ -34,6 +39,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f16x3',
+                    help="conv engine: f16x3 = fp32-class error-compensated split on the f16 MFMA (default, "
+                         "passes the same parity tests), f32 = exact fp32 MFMA")
     ap.add_argument('--height', type=int, default=375)
     ap.add_argument('--width', type=int, default=1242)
     return ap.parse_args()
@@ -85,6 +93,7 @@ def main():
     model.cuda()
     model.eval()
     model.use_graph = not args.no_graph
+    model.precision = args.precision
     # every rank works on its own synthetic pair (weak scaling: per-GPU work is fixed)
     im_l, im_r, im_info = [t.to(dev) for t in fixture.make_inputs(3 + rank, args.height, args.width)]
     gather_stream = torch.cuda.Stream() if world > 1 else None
@@ -142,9 +151,12 @@ def main():
             engine.FlopCounter.enabled = False
             alg = engine.FlopCounter.flops
             achieved = alg / (ms.value * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (fp32 implicit-GEMM conv engine)',
-                        'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            peak = PEAKS[args.precision]
+            issued = 3.0 if args.precision == 'f16x3' else 1.0     # MFMA flops issued per algorithmic flop
+            roofline = {'bound': 'mfma', 'kernel': ENGINE_DESC[args.precision],
+                        'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / peak, 4), 'traffic': None,
+                        'issued_mfma_frac': round(achieved * issued / peak, 4),
                         'launches_per_step': int(cnt.value // nprof),
                         'avg_launch_ms': round(ms.value / max(cnt.value, 1), 5),
                         'algorithmic_gflop_per_step': round(alg / nprof / 1e9, 1),
@@ -157,11 +169,14 @@ def main():
             'metric': 'stereo pairs/sec @1242x375 ResNet-101', 'value': round(pairs / elapsed, 3),
             'unit': 'stereo pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'f32' else 'f32 result via 3xf16 split MFMA (f32 accumulate)',
+            'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: ResNet-101 FPN, batch=1 stereo pair per GPU, %dx%d synthetic '
                                    '(network input %dx%d), 300 proposals, forward + decode + class NMS, no dense-align'
                                    % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
                        'weights': 'seeded random init, reference state_dict schema', 'hipgraph': not args.no_graph,
+                       'conv_engine': args.precision,
                        'parallelism': 'pairs sharded 1/GPU, RCCL all_gather of detections' if world > 1 else 'single GPU'},
             'roofline': roofline,
         }

@@ -110,6 +110,10 @@ typedef struct srcnn_conv_desc {
     int precision;
     const void *w_lo;
     float w_inv_scale;
+    /* launch plan override (0 = built-in heuristic): workgroup tile = (64*tile_mr) x (64*tile_nr),
+     * tile_mr/tile_nr in {1,2}; splits = number of K slices (deterministic workspace reduction).
+     * Lets the host autotune each layer shape on the device it runs on. */
+    int tile_mr, tile_nr, splits;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);

@@ -25,7 +25,8 @@ class ConvDesc(ctypes.Structure):
                 ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int),
                 ("y_cstride", c_int), ("y_coffset", c_int), ("res_cstride", c_int),
                 ("relu", c_int), ("mode", c_int),
-                ("precision", c_int), ("w_lo", c_void_p), ("w_inv_scale", c_float)]
+                ("precision", c_int), ("w_lo", c_void_p), ("w_inv_scale", c_float),
+                ("tile_mr", c_int), ("tile_nr", c_int), ("splits", c_int)]
 
 
 _SIGNATURES = {

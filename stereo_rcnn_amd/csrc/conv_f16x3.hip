@@ -14,9 +14,11 @@
 //
 // Same structure as conv_mfma.hip (implicit GEMM, NHWC, K tile = 32 channels of one tap,
 // register prefetch, double-buffered LDS, XCD-aware tile map, split-K, fused epilogue); what
-// changes: LDS holds four f16 panels (A_hi, A_lo, B_hi, B_lo) with 80-byte rows (conflict-free
-// ds_read_b128), one ds_read_b128 = the 8-half operand of one MFMA, 3 MFMAs per operand pair
-// interleaved over the wave's independent accumulators.
+// changes: LDS holds four f16 panels (A_hi, A_lo, B_hi, B_lo) of 64-byte rows whose 16-byte
+// chunks are XOR-swizzled with (row>>2)&3 (conflict-free ds_read_b128 / ds_write without padding,
+// so two 128x128 workgroups fit one CU's 160 KB), one ds_read_b128 = the 8-half operand of one
+// MFMA, 3 MFMAs per operand pair issued round-robin over independent accumulators (small tiles
+// keep the cross terms in their own accumulators so no MFMA waits on its predecessor).
 #include "conv_common.h"
 
 namespace srcnn {
@@ -24,7 +26,7 @@ namespace srcnn {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr int HROW = BK + 8;   // halves per LDS row: 64 B data + 16 B pad = 80 B
+constexpr int HROW = BK;       // halves per LDS row (64 B, no pad: chunks are XOR-swizzled)
 
 template <int MR, int NR>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
@@ -80,13 +82,26 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
         bl_ptr[i] = reinterpret_cast<const _Float16 *>(p.w_lo) + off;
     }
 
+    // swizzled LDS column offsets (halves): 16-B chunk index ^ ((row >> 2) & 3)
+    const int a_sw = ((((t & 7) >> 1) ^ ((lrow >> 2) & 3)) << 3) + ((t & 1) << 2);
+    const int b_sw = ((t & 3) ^ ((brow >> 2) & 3)) << 3;
     float4 ra[A_LD];
     uint4 rbh[B_LD], rbl[B_LD];
+    // (kh, kw, c0) of the tile being loaded, advanced incrementally (no divisions in the loop)
+    int ld_kh, ld_kw, ld_c0;
+    {
+        const int tap = kt_begin / p.ctiles;
+        ld_c0 = (kt_begin - tap * p.ctiles) * BK;
+        ld_kh = tap / p.KW;
+        ld_kw = tap - ld_kh * p.KW;
+    }
     auto load_tile = [&](int kt) {
-        const int tap = kt / p.ctiles;
-        const int c0 = (kt - tap * p.ctiles) * BK;
-        const int kh = tap / p.KW;
-        const int kw = tap - kh * p.KW;
+        const int kh = ld_kh, kw = ld_kw, c0 = ld_c0;
+        ld_c0 += BK;
+        if (ld_c0 == p.Cin) {
+            ld_c0 = 0;
+            if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
+        }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
@@ -115,13 +130,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
                 hi[e] = (_Float16)v[e];                       // round to nearest even
                 lo[e] = (_Float16)(v[e] - (float)hi[e]);      // residual is exact in fp32
             }
-            const int o = (lrow + 32 * i) * HROW + lcol;
+            const int o = (lrow + 32 * i) * HROW + a_sw;
             *reinterpret_cast<half4 *>(sah + o) = hi;
             *reinterpret_cast<half4 *>(sal + o) = lo;
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            const int o = (brow + 64 * i) * HROW + bcol;
+            const int o = (brow + 64 * i) * HROW + b_sw;
             *reinterpret_cast<uint4 *>(sbh + o) = rbh[i];
             *reinterpret_cast<uint4 *>(sbl + o) = rbl[i];
         }
@@ -130,13 +145,23 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
     const int wave = t >> 6, lane = t & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lg = lane >> 5;
+    const int r_sw = (lg ^ ((li >> 2) & 3)) << 3;     // chunk kk*2+lg swizzled; kk=1 flips bit 4 (halves)
+    // XACC: small tiles keep the two cross terms in their own accumulators -> every MFMA in the
+    // round-robin below targets a different accumulator than its predecessor.
+    constexpr bool XACC = (MR * NR <= 2);
+    constexpr int NX = XACC ? (MR * NR == 1 ? 2 : 1) : 0;
     floatx16 acc[MR][NR];
+    floatx16 accx[NX > 0 ? NX : 1][MR][NR];
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+#pragma unroll
+                for (int x = 0; x < (NX > 0 ? NX : 1); ++x) accx[x][i][j][e] = 0.f;
+            }
 
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
@@ -147,34 +172,38 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
         const int buf = (kt - kt_begin) & 1;
         const bool more = kt + 1 < kt_end;
         if (more) load_tile(kt + 1);
-        const _Float16 *sah = smem[buf] + (wm * 32 * MR + li) * HROW + lg * 8;
+        const _Float16 *sah = smem[buf] + (wm * 32 * MR + li) * HROW + r_sw;
         const _Float16 *sal = sah + PANEL_A;
-        const _Float16 *sbh = smem[buf] + 2 * PANEL_A + (wn * 32 * NR + li) * HROW + lg * 8;
+        const _Float16 *sbh = smem[buf] + 2 * PANEL_A + (wn * 32 * NR + li) * HROW + r_sw;
         const _Float16 *sbl = sbh + PANEL_B;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
+            const int ko = kk ? ((r_sw ^ 16) - r_sw) : 0;
             half8 ah[MR], al[MR], bh[NR], bl[NR];
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
-                ah[i] = *reinterpret_cast<const half8 *>(sah + i * 32 * HROW + kk * 16);
-                al[i] = *reinterpret_cast<const half8 *>(sal + i * 32 * HROW + kk * 16);
+                ah[i] = *reinterpret_cast<const half8 *>(sah + i * 32 * HROW + ko);
+                al[i] = *reinterpret_cast<const half8 *>(sal + i * 32 * HROW + ko);
             }
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-                bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * HROW + kk * 16);
-                bl[j] = *reinterpret_cast<const half8 *>(sbl + j * 32 * HROW + kk * 16);
+                bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * HROW + ko);
+                bl[j] = *reinterpret_cast<const half8 *>(sbl + j * 32 * HROW + ko);
             }
-            // consecutive MFMAs hit different accumulators (no back-to-back dependency)
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NR; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NR; ++j) {
+                    floatx16 &d = NX > 0 ? accx[0][i][j] : acc[i][j];
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], d, 0, 0, 0);
+                }
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NR; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NR; ++j) {
+                    floatx16 &d = NX > 1 ? accx[1][i][j] : (NX > 0 ? accx[0][i][j] : acc[i][j]);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], d, 0, 0, 0);
+                }
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -183,6 +212,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
+    }
+    if (NX > 0) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float xs = accx[0][i][j][e];
+                    if (NX > 1) xs += accx[1][i][j][e];
+                    acc[i][j][e] += xs;       // small cross terms first, then into the main sum
+                }
     }
 
     // ---- epilogue (identical to the fp32 engine apart from the power-of-two rescale)

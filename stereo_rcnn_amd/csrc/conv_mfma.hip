@@ -242,6 +242,21 @@ static Plan make_plan(int M, int N, int nkt, int mode, int precision)
     return pl;
 }
 
+static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
+{
+    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
+    if (d->tile_mr >= 1 && d->tile_mr <= 2 && d->tile_nr >= 1 && d->tile_nr <= 2) {
+        pl.mr = d->tile_mr;
+        pl.nr = d->tile_nr;
+        int s = d->splits >= 1 ? d->splits : 1;
+        if (a.mode != 0) s = 1;
+        s = min(s, a.nkt);
+        pl.kt_per_split = cdiv(a.nkt, s);
+        pl.splits = cdiv(a.nkt, pl.kt_per_split);
+    }
+    return pl;
+}
+
 static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
 {
     SRCNN_REQUIRE(d && d->x && d->w && d->y, "null pointer");
@@ -282,7 +297,7 @@ size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d)
     using namespace srcnn;
     ConvArgs a;
     if (fill_args(d, a) != SRCNN_OK) return 0;
-    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
+    Plan pl = plan_for(d, a);
     if (pl.splits <= 1) return 256;
     return align_up((size_t)pl.splits * a.M * a.Cout * sizeof(float), 256);
 }
@@ -293,7 +308,7 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     ConvArgs a;
     int rc = fill_args(d, a);
     if (rc != SRCNN_OK) return rc;
-    Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
+    Plan pl = plan_for(d, a);
     a.kt_per_split = pl.kt_per_split;
     a.mtiles = cdiv(a.M, 64 * pl.mr);
     a.ntiles = cdiv(a.Cout, 64 * pl.nr);

@@ -96,6 +96,57 @@ class FlopCounter(object):
 
 PRECISION = 'f32'     # default engine: 'f32' (exact fp32 MFMA) or 'f16x3' (3-term split on the f16 MFMA)
 
+# ---- per-shape launch-plan autotuning ("measure, don't guess"): every distinct conv shape is timed
+# once on the device it runs on over the legal (tile, split-K) plans; the winner is cached.
+AUTOTUNE = True
+_TUNED = {}
+_CANDIDATES = [(2, 2), (2, 1), (1, 2), (1, 1)]
+
+
+def _shape_key(cw, B, H, W, OH, OW, x_cstride, precision):
+    return (precision, B, H, W, OH, OW, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, cw.mode, x_cstride)
+
+
+def _tune(d, key, device):
+    """Times each candidate plan with HIP events on the current stream (3 runs, best of)."""
+    L = _lib.lib()
+    M = d.B * d.OH * d.OW
+    nkt = d.KH * d.KW * d.Cin // 32
+    cands = []
+    for mr, nr in _CANDIDATES:
+        if nr == 2 and d.Cout <= 64:
+            continue
+        if mr == 2 and M <= 64:
+            continue
+        blocks = -(-M // (64 * mr)) * -(-d.Cout // (64 * nr))
+        splits = [1]
+        if d.mode == 0:
+            for s in (2, 3, 4, 6, 8, 12, 16):
+                if blocks * s <= 4096 and nkt // s >= 4 and blocks < 1024:
+                    splits.append(s)
+        for s in splits:
+            cands.append((mr, nr, s))
+    best, best_t = (0, 0, 0), None
+    st = _lib.stream()
+    for mr, nr, s in cands:
+        d.tile_mr, d.tile_nr, d.splits = mr, nr, s
+        need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
+        ws = _lib.workspace(need, device, "conv")
+        t_best = None
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), st), "srcnn_conv2d(tune)")
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if rep > 0 and (t_best is None or t < t_best):
+                t_best = t
+        if best_t is None or t_best < best_t:
+            best, best_t = (mr, nr, s), t_best
+    _TUNED[key] = best
+    return best
+
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
            res_cstride=None, x_offset_elems=0, relu=None, precision=None):
@@ -125,6 +176,15 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
+    if AUTOTUNE:
+        key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision)
+        plan = _TUNED.get(key)
+        if plan is None:
+            if torch.cuda.is_current_stream_capturing():
+                plan = (0, 0, 0)          # never time inside a graph capture; warm-up runs tune first
+            else:
+                plan = _tune(d, key, x.device)
+        d.tile_mr, d.tile_nr, d.splits = plan
     need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _lib.workspace(need, x.device, "conv")
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")

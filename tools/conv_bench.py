@@ -44,4 +44,5 @@ for name, B, H, W, cin, cout, k, s, p in SHAPES:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * B * OH * OW * cout * cin * k * k
-    print('%-34s M=%7d N=%5d K=%6d  %8.3f ms  %7.1f TFLOP/s' % (name, B * OH * OW, cout, cin * k * k, ms, fl / ms / 1e9), flush=True)
+    plan = [v for kk, v in engine._TUNED.items() if kk[0] == PREC][-1] if engine._TUNED else None
+    print('%-34s M=%7d N=%5d K=%6d  %8.3f ms  %7.1f TFLOP/s  plan(mr,nr,splits)=%s' % (name, B * OH * OW, cout, cin * k * k, ms, fl / ms / 1e9, plan), flush=True)
