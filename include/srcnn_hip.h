@@ -34,6 +34,9 @@ extern "C" {
 #define SRCNN_ERR_HIP (-2)
 #define SRCNN_ERR_WORKSPACE (-3)
 
+#define SRCNN_FMT_F32 0
+#define SRCNN_FMT_SPLIT16 1
+
 typedef void *srcnn_stream_t; /* hipStream_t */
 
 #define SRCNN_API __attribute__((visibility("default")))
@@ -82,7 +85,11 @@ SRCNN_API int roi_align_forward_cuda(int aligned_height, int aligned_width, floa
  * channels [out_coffset, out_coffset+C) are written (lets left|right be concatenated in place). */
 SRCNN_API int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, const int *mw_host,
                             int channels, float im_height, const float *rois, int num_rois, int A,
-                            float *out, int out_cstride, int out_coffset, srcnn_stream_t stream);
+                            float *out, int out_cstride, int out_coffset, int maps_format, int out_format,
+                            srcnn_stream_t stream);
+/* format conversion of an NHWC activation tensor (pixels x C): F32 <-> SPLIT16 (API edge / tests) */
+SRCNN_API int srcnn_act_convert(const void *x, int x_format, void *y, int y_format, long long pixels, int C,
+                      srcnn_stream_t stream);
 
 /* ------------------------------------------------- convolution engine (A1-A3, A9, A10)
  * Replaces the cuDNN calls behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear in
@@ -114,6 +121,11 @@ typedef struct srcnn_conv_desc {
      * tile_mr/tile_nr in {1,2}; splits = number of K slices (deterministic workspace reduction).
      * Lets the host autotune each layer shape on the device it runs on. */
     int tile_mr, tile_nr, splits;
+    /* activation formats (SRCNN_FMT_*).  SPLIT16: per pixel, each group of 8 channels is stored as
+     * [8 x f16 hi][8 x f16 lo] (hi = f16(v), lo = f16(v - hi); same bytes as float32, channel strides
+     * are still given in float32-equivalents).  With precision 1 and x_format SPLIT16 both GEMM
+     * operands are DMA'd straight into LDS (global_load_lds).  fp32 engine: all formats must be F32. */
+    int x_format, y_format, res_format;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
@@ -123,10 +135,10 @@ SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t wor
 SRCNN_API int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, srcnn_stream_t stream);
 /* MaxPool2d(3, stride 2, pad 0, ceil_mode) NHWC (resnet.py:113). */
 SRCNN_API int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y, int OH, int OW,
-                            srcnn_stream_t stream);
+                            int y_format, srcnn_stream_t stream);
 /* _upsample_add (stereo_rcnn.py:91-108): y = bilinear_align_corners(top -> (H,W)) + lateral, NHWC. */
 SRCNN_API int srcnn_upsample_add(const float *top, int TH, int TW, const float *lateral, int B, int H, int W, int C,
-                       float *y, srcnn_stream_t stream);
+                       float *y, int top_format, int y_format /* lateral is always F32 */, srcnn_stream_t stream);
 /* MaxPool2d(1, stride 2) (stereo_rcnn.py:39,168): y[b,i,j,:] = x[b,2i,2j,:]. */
 SRCNN_API int srcnn_subsample2(const float *x, int B, int H, int W, int C, float *y, int OH, int OW, srcnn_stream_t stream);
 /* layout edge helpers */

@@ -13,6 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrcnn_hip.so")
 
+FMT_F32, FMT_SPLIT16 = 0, 1     # SRCNN_FMT_* (include/srcnn_hip.h)
+
 c_int, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_double,
                                                 ctypes.c_void_p, ctypes.c_size_t)
 
@@ -26,7 +28,8 @@ class ConvDesc(ctypes.Structure):
                 ("y_cstride", c_int), ("y_coffset", c_int), ("res_cstride", c_int),
                 ("relu", c_int), ("mode", c_int),
                 ("precision", c_int), ("w_lo", c_void_p), ("w_inv_scale", c_float),
-                ("tile_mr", c_int), ("tile_nr", c_int), ("splits", c_int)]
+                ("tile_mr", c_int), ("tile_nr", c_int), ("splits", c_int),
+                ("x_format", c_int), ("y_format", c_int), ("res_format", c_int)]
 
 
 _SIGNATURES = {
@@ -42,12 +45,15 @@ _SIGNATURES = {
     "roi_align_forward_cuda": (c_int, [c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_int,
                                        c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_pyramid_roi_align": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
-                                        c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+                                        c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_void_p]),
+    "srcnn_act_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
     "srcnn_conv2d_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "srcnn_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_size_t, c_void_p]),
     "srcnn_stem_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "srcnn_maxpool3x3s2_ceil": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
-    "srcnn_upsample_add": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "srcnn_maxpool3x3s2_ceil": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "srcnn_upsample_add": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                   c_int, c_void_p]),
     "srcnn_subsample2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "srcnn_nhwc_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -14,6 +14,8 @@ struct ConvArgs {
     float *y, *partial;
     const void *w_lo;   // f16x3 engine: w = hi halves, w_lo = lo halves (both (Cout, K) _Float16)
     float out_scale;    // f16x3 engine: 1 / (power-of-two weight scale)
+    const void *zero_page;        // >= 256 zero bytes in HBM (padding source of the direct-to-LDS loads)
+    int x_fmt, y_fmt, res_fmt;    // SRCNN_FMT_F32 / SRCNN_FMT_SPLIT16
     int H, W, Cin, xcs;
     int OH, OW, Cout;
     int KH, KW, stride, pad;
@@ -26,10 +28,81 @@ struct ConvArgs {
 };
 
 
+// ---- "split16" activation format: per pixel, every group of 8 channels is stored as
+// [8 x f16 hi][8 x f16 lo] (32 B, same footprint as fp32) with hi = f16(v), lo = f16(v - hi).
+// A K tile of 32 channels is one contiguous 128-B run whose 16-B chunks are exactly the MFMA
+// operand chunks, so the conv engine can DMA them straight into LDS (global_load_lds).
+__device__ __forceinline__ size_t split16_byte_off(size_t pixel, int cstride, int ch)
+{
+    return pixel * (size_t)cstride * 4 + (size_t)(ch >> 3) * 32 + (size_t)(ch & 7) * 2;
+}
+
+__device__ __forceinline__ float act_load(const void *base, int fmt, size_t pixel, int cstride, int ch)
+{
+    if (fmt == 0) return reinterpret_cast<const float *>(base)[pixel * (size_t)cstride + ch];
+    const char *p = reinterpret_cast<const char *>(base) + split16_byte_off(pixel, cstride, ch);
+    return (float)*reinterpret_cast<const _Float16 *>(p) + (float)*reinterpret_cast<const _Float16 *>(p + 16);
+}
+
+__device__ __forceinline__ void act_store(void *base, int fmt, size_t pixel, int cstride, int ch, float v)
+{
+    if (fmt == 0) {
+        reinterpret_cast<float *>(base)[pixel * (size_t)cstride + ch] = v;
+        return;
+    }
+    char *p = reinterpret_cast<char *>(base) + split16_byte_off(pixel, cstride, ch);
+    const _Float16 hi = (_Float16)v;
+    *reinterpret_cast<_Float16 *>(p) = hi;
+    *reinterpret_cast<_Float16 *>(p + 16) = (_Float16)(v - (float)hi);
+}
+
+// 8-channel group accessors (32 B in either format): the unit the HBM-bound helper kernels work on.
+struct float8 {
+    float v[8];
+};
+
+__device__ __forceinline__ float8 act_load8(const void *base, int fmt, size_t pixel, int cstride, int group)
+{
+    const char *p = reinterpret_cast<const char *>(base) + (pixel * (size_t)cstride + (size_t)group * 8) * 4;
+    float8 r;
+    if (fmt == 0) {
+        const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 16);
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+        r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    } else {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 hi = *reinterpret_cast<const h8 *>(p), lo = *reinterpret_cast<const h8 *>(p + 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[e] = (float)hi[e] + (float)lo[e];
+    }
+    return r;
+}
+
+__device__ __forceinline__ void act_store8(void *base, int fmt, size_t pixel, int cstride, int group, const float8 &r)
+{
+    char *p = reinterpret_cast<char *>(base) + (pixel * (size_t)cstride + (size_t)group * 8) * 4;
+    if (fmt == 0) {
+        *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        *reinterpret_cast<float4 *>(p + 16) = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    } else {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hi[e] = (_Float16)r.v[e];
+            lo[e] = (_Float16)(r.v[e] - (float)hi[e]);
+        }
+        *reinterpret_cast<h8 *>(p) = hi;
+        *reinterpret_cast<h8 *>(p + 16) = lo;
+    }
+}
+
 struct Plan {
     int mr, nr, splits, kt_per_split;
 };
 
-void launch_conv_f16x3(const ConvArgs &a, const Plan &pl, hipStream_t st);
+void launch_conv_f16x3(const ConvArgs &a, const Plan &pl, hipStream_t st);   // A operand fp32 in HBM
+void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st);    // A operand split16 in HBM
+const void *zero_page();
 
 }  // namespace srcnn

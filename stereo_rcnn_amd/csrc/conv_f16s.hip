@@ -1,0 +1,259 @@
+// Convolution engine, 3xf16 split form with BOTH operands DMA'd straight into LDS.
+//
+// Arithmetic is the error-compensated split of conv_f16x3.hip (x.w = xh.wh + xh.wl + xl.wh on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32-class result).  The difference is where the
+// split happens: activations live in HBM in the "split16" format (conv_common.h: per pixel, each
+// group of 8 channels = [8 x f16 hi][8 x f16 lo], same bytes as fp32) written ONCE by the
+// producing kernel's epilogue, so a K tile of a row is one 128-B run made of the exact 16-B MFMA
+// operand chunks.  Both the A (activation) and B (weight) panels are then filled with
+// global_load_lds_dwordx4 -- no VGPR staging, no conversions, no ds_write: per K tile a wave
+// issues 2*(MR+NR) DMA loads, 4*(MR+NR) ds_read_b128 and 12*MR*NR MFMAs.
+//   * the LDS image of a DMA is lane-linear (wave base + lane*16), so the XOR chunk swizzle that
+//     keeps ds_read_b128 conflict-free is applied on the SOURCE side: lane (row=l>>2, slot=l&3)
+//     fetches chunk slot ^ ((row>>2)&3) of its row;
+//   * zero padding (image borders, M/N tails) = lanes pointed at a zero page in HBM;
+//   * loads for tile t+1 are issued before the MFMAs of tile t and land in the other LDS stage;
+//     the single barrier per K tile also drains them (hipcc places vmcnt(0) there).
+#include "conv_common.h"
+
+namespace srcnn {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int SROW = BK;   // halves per LDS row (64 B), chunks XOR-swizzled
+
+// one global_load_lds_dwordx4: every lane moves 16 B from its own global address to
+// (wave-uniform LDS base) + lane*16.  Device-only builtin, hence the guard for the host pass.
+__device__ __forceinline__ void dma16(const void *gsrc, _Float16 *lds_wave_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 16, 0, 0);
+#else
+    (void)gsrc;
+    (void)lds_wave_base;
+#endif
+}
+
+template <int MR, int NR, bool OUT_SPLIT>
+__global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
+{
+    constexpr int BM = 64 * MR, BN = 64 * NR;
+    constexpr int PANEL_A = BM * SROW, PANEL_B = BN * SROW;   // halves
+    constexpr int STAGE = 2 * PANEL_A + 2 * PANEL_B;
+    __shared__ __attribute__((aligned(1024))) _Float16 smem[2 * STAGE];
+
+    const int t = threadIdx.x;
+    const int nblk = p.mtiles * p.ntiles;
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int mt = logical / p.ntiles, nt = logical - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_end = min(p.nkt, kt_begin + p.kt_per_split);
+
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    // ---- DMA geometry: wave w fills rows [w*16*MR, +16*MR) of the A panels and
+    //      [w*16*NR, +16*NR) of the B panels, 16 rows x 4 chunks per instruction.
+    const int drow = lane >> 2;                               // row inside the 16-row group
+    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);         // source chunk (swizzle on the source side)
+    const char *zero = reinterpret_cast<const char *>(p.zero_page) + (lane & 3) * 16;
+    int a_ih0[MR], a_iw0[MR];
+    const char *a_base[MR];
+#pragma unroll
+    for (int g = 0; g < MR; ++g) {
+        const int m = m0 + wave * 16 * MR + g * 16 + drow;
+        if (m < p.M) {
+            const int ohw = p.OH * p.OW;
+            const int b = m / ohw;
+            const int rem = m - b * ohw;
+            const int oh = rem / p.OW;
+            const int ow = rem - oh * p.OW;
+            a_ih0[g] = oh * p.stride - p.pad;
+            a_iw0[g] = ow * p.stride - p.pad;
+            a_base[g] = reinterpret_cast<const char *>(p.x) +
+                        ((size_t)((b * p.H + a_ih0[g]) * p.W + a_iw0[g]) * p.xcs) * 4 + dchunk * 32;
+        } else {
+            a_ih0[g] = -(1 << 28);
+            a_iw0[g] = 0;
+            a_base[g] = zero;
+        }
+    }
+    const char *bh_base[NR], *bl_base[NR];
+    bool b_ok[NR];
+#pragma unroll
+    for (int g = 0; g < NR; ++g) {
+        const int n = n0 + wave * 16 * NR + g * 16 + drow;
+        b_ok[g] = n < p.Cout;
+        const size_t off = ((size_t)(b_ok[g] ? n : 0) * p.K + dchunk * 8) * 2;
+        bh_base[g] = reinterpret_cast<const char *>(p.w) + off;
+        bl_base[g] = reinterpret_cast<const char *>(p.w_lo) + off;
+    }
+
+    int ld_kh, ld_kw, ld_c0;
+    {
+        const int tap = kt_begin / p.ctiles;
+        ld_c0 = (kt_begin - tap * p.ctiles) * BK;
+        ld_kh = tap / p.KW;
+        ld_kw = tap - ld_kh * p.KW;
+    }
+    auto dma_tile = [&](int kt, int stage) {
+        const int kh = ld_kh, kw = ld_kw, c0 = ld_c0;
+        ld_c0 += BK;
+        if (ld_c0 == p.Cin) {
+            ld_c0 = 0;
+            if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
+        }
+        _Float16 *sa_hi = smem + stage * STAGE + (wave * 16 * MR) * SROW;
+        _Float16 *sb_hi = smem + stage * STAGE + 2 * PANEL_A + (wave * 16 * NR) * SROW;
+        const size_t tap_off = ((size_t)(kh * p.W + kw) * p.xcs + c0) * 4;   // wave-uniform byte offset
+#pragma unroll
+        for (int g = 0; g < MR; ++g) {
+            const int ih = a_ih0[g] + kh, iw = a_iw0[g] + kw;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const char *src = ok ? a_base[g] + tap_off : zero;
+            dma16(src, sa_hi + g * 16 * SROW);
+            dma16(ok ? src + 16 : zero, sa_hi + PANEL_A + g * 16 * SROW);
+        }
+        const size_t kb = (size_t)kt * BK * 2;
+#pragma unroll
+        for (int g = 0; g < NR; ++g) {
+            dma16(b_ok[g] ? bh_base[g] + kb : zero, sb_hi + g * 16 * SROW);
+            dma16(b_ok[g] ? bl_base[g] + kb : zero, sb_hi + PANEL_B + g * 16 * SROW);
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lg = lane >> 5;
+    const int r_sw = (lg ^ ((li >> 2) & 3)) << 3;
+    constexpr bool XACC = (MR * NR <= 2);
+    constexpr int NX = XACC ? (MR * NR == 1 ? 2 : 1) : 0;
+    floatx16 acc[MR][NR];
+    floatx16 accx[NX > 0 ? NX : 1][MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+#pragma unroll
+                for (int x = 0; x < (NX > 0 ? NX : 1); ++x) accx[x][i][j][e] = 0.f;
+            }
+
+    if (kt_begin < kt_end) dma_tile(kt_begin, 0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int stage = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) dma_tile(kt + 1, stage ^ 1);
+        const _Float16 *sah = smem + stage * STAGE + (wm * 32 * MR + li) * SROW + r_sw;
+        const _Float16 *sal = sah + PANEL_A;
+        const _Float16 *sbh = smem + stage * STAGE + 2 * PANEL_A + (wn * 32 * NR + li) * SROW + r_sw;
+        const _Float16 *sbl = sbh + PANEL_B;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int ko = kk ? ((r_sw ^ 16) - r_sw) : 0;
+            half8 ah[MR], al[MR], bh[NR], bl[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                ah[i] = *reinterpret_cast<const half8 *>(sah + i * 32 * SROW + ko);
+                al[i] = *reinterpret_cast<const half8 *>(sal + i * 32 * SROW + ko);
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * SROW + ko);
+                bl[j] = *reinterpret_cast<const half8 *>(sbl + j * 32 * SROW + ko);
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    floatx16 &d = NX > 0 ? accx[0][i][j] : acc[i][j];
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], d, 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    floatx16 &d = NX > 1 ? accx[NX > 1 ? 1 : 0][i][j] : (NX > 0 ? accx[0][i][j] : acc[i][j]);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], d, 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (NX > 0) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float xs = accx[0][i][j][e];
+                    if (NX > 1) xs += accx[NX > 1 ? 1 : 0][i][j][e];
+                    acc[i][j][e] += xs;
+                }
+    }
+
+    // ---- epilogue
+    const bool split = gridDim.y > 1;
+    const float os = p.out_scale;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + li;
+            if (col >= p.Cout) continue;
+            const float bv = (!split && p.bias) ? p.bias[p.mode == 1 ? col % (p.Cout >> 2) : col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wm * MR + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e] * os;
+                if (split) {
+                    p.partial[((size_t)blockIdx.y * p.M + row) * p.Cout + col] = v;
+                    continue;
+                }
+                v += bv;
+                if (p.mode == 0) {
+                    if (p.res) v += act_load(p.res, p.res_fmt, (size_t)row, p.rcs, col);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    act_store(p.y, OUT_SPLIT ? 1 : 0, (size_t)row, p.ycs, p.yco + col, v);
+                } else {
+                    const int cq = p.Cout >> 2;
+                    const int ij = col / cq, co = col - ij * cq;
+                    const int ohw = p.OH * p.OW;
+                    const int b = row / ohw, rem = row - b * ohw;
+                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    const size_t opix = ((size_t)b * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    act_store(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, p.yco + co, v);
+                }
+            }
+        }
+    }
+}
+
+template <int MR, int NR>
+static void launch(const ConvArgs &a, int splits, hipStream_t st)
+{
+    if (a.y_fmt == 1)
+        hipLaunchKernelGGL((conv_f16s_kernel<MR, NR, true>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_f16s_kernel<MR, NR, false>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
+}
+
+void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st)
+{
+    if (pl.mr == 2 && pl.nr == 2) launch<2, 2>(a, pl.splits, st);
+    else if (pl.mr == 2 && pl.nr == 1) launch<2, 1>(a, pl.splits, st);
+    else if (pl.mr == 1 && pl.nr == 2) launch<1, 2>(a, pl.splits, st);
+    else launch<1, 1>(a, pl.splits, st);
+}
+
+}  // namespace srcnn

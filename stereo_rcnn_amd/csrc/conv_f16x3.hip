@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
-                    floatx16 &d = NX > 1 ? accx[1][i][j] : (NX > 0 ? accx[0][i][j] : acc[i][j]);
+                    floatx16 &d = NX > 1 ? accx[NX > 1 ? 1 : 0][i][j] : (NX > 0 ? accx[0][i][j] : acc[i][j]);
                     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], d, 0, 0, 0);
                 }
 #pragma unroll
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float xs = accx[0][i][j][e];
-                    if (NX > 1) xs += accx[1][i][j][e];
+                    if (NX > 1) xs += accx[NX > 1 ? 1 : 0][i][j][e];
                     acc[i][j][e] += xs;       // small cross terms first, then into the main sum
                 }
     }

@@ -202,9 +202,9 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
         float v = 0.f;
         for (int s = 0; s < splits; ++s) v += p.partial[(size_t)s * total + idx];
         if (p.bias) v += p.bias[col];
-        if (p.res) v += p.res[(size_t)row * p.rcs + col];
+        if (p.res) v += act_load(p.res, p.res_fmt, (size_t)row, p.rcs, col);
         if (p.relu) v = fmaxf(v, 0.f);
-        p.y[(size_t)row * p.ycs + p.yco + col] = v;
+        act_store(p.y, p.y_fmt, (size_t)row, p.ycs, p.yco + col, v);
     }
 }
 
@@ -269,6 +269,18 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     SRCNN_REQUIRE(d->precision == 0 || (d->precision == 1 && d->w_lo), "bad precision / missing w_lo");
     a.w_lo = d->w_lo;
     a.out_scale = d->precision == 1 ? d->w_inv_scale : 1.0f;
+    a.x_fmt = d->x_format; a.y_fmt = d->y_format; a.res_fmt = d->res_format;
+    SRCNN_REQUIRE((unsigned)a.x_fmt <= 1 && (unsigned)a.y_fmt <= 1 && (unsigned)a.res_fmt <= 1, "bad format");
+    if (d->precision == 0)
+        SRCNN_REQUIRE(a.x_fmt == 0 && a.y_fmt == 0 && (a.res_fmt == 0 || !d->residual), "fp32 engine needs F32 formats");
+    if (a.x_fmt == 1) SRCNN_REQUIRE(d->x_cstride % 8 == 0, "SPLIT16 needs channel strides that are multiples of 8");
+    if (a.y_fmt == 1) SRCNN_REQUIRE(d->y_cstride % 8 == 0 && d->y_coffset % 8 == 0, "SPLIT16 output alignment");
+    if (d->precision == 1 && a.x_fmt == 0) SRCNN_REQUIRE(a.y_fmt == 0 && a.res_fmt == 0, "f16x3 with F32 input writes F32");
+    a.zero_page = nullptr;
+    if (d->precision == 1 && a.x_fmt == 1) {
+        a.zero_page = zero_page();
+        SRCNN_REQUIRE(a.zero_page != nullptr, "zero page allocation failed");
+    }
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.xcs = d->x_cstride;
     a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
@@ -323,7 +335,8 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     hipStream_t st = as_stream(stream);
     const bool prof = prof_enabled();
     if (prof) prof_begin(st);
-    if (d->precision == 1) launch_conv_f16x3(a, pl, st);
+    if (d->precision == 1 && a.x_fmt == 1) launch_conv_f16s(a, pl, st);
+    else if (d->precision == 1) launch_conv_f16x3(a, pl, st);
     else if (pl.mr == 2 && pl.nr == 2) launch<2, 2>(a, pl.splits, st);
     else if (pl.mr == 2 && pl.nr == 1) launch<2, 1>(a, pl.splits, st);
     else if (pl.mr == 1 && pl.nr == 2) launch<1, 2>(a, pl.splits, st);

@@ -1,5 +1,5 @@
 // Library core: error text, version, conv-engine profiling hooks.
-#include "common.h"
+#include "conv_common.h"
 #include <mutex>
 #include <vector>
 
@@ -47,6 +47,19 @@ void prof_end(hipStream_t s, double flops)
     g_prof.flops.resize(g_prof.used + 1);
     g_prof.flops[g_prof.used] = flops;
     g_prof.used++;
+}
+
+// library-owned, never freed: 4 KB of zeros that padded conv taps DMA from (conv_f16s.hip)
+const void *zero_page()
+{
+    static void *page = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!page) {
+        if (hipMalloc(&page, 4096) != hipSuccess) return nullptr;
+        (void)hipMemset(page, 0, 4096);
+    }
+    return page;
 }
 
 }  // namespace srcnn

@@ -5,7 +5,7 @@
 // Reference semantics: resnet.py:113 (MaxPool2d(3,2,0,ceil_mode=True)),
 // stereo_rcnn.py:91-108 (_upsample_add; torch-0.3 bilinear == align_corners=True),
 // stereo_rcnn.py:39,168 (MaxPool2d(1, stride=2)).
-#include "common.h"
+#include "conv_common.h"
 
 namespace srcnn {
 
@@ -31,46 +31,49 @@ __global__ void stem_pack_kernel(const float *__restrict__ im, int B, int H, int
     }
 }
 
-__global__ void maxpool3x3s2_kernel(const float4 *__restrict__ x, int B, int H, int W, int C4, float4 *__restrict__ y,
-                                    int OH, int OW)
+// works on 8-channel groups; input F32, output F32 or SPLIT16
+__global__ void maxpool3x3s2_kernel(const float *__restrict__ x, int B, int H, int W, int C, float *__restrict__ y,
+                                    int OH, int OW, int yfmt)
 {
-    const size_t total = (size_t)B * OH * OW * C4;
+    const int G = C / 8;
+    const size_t total = (size_t)B * OH * OW * G;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C4);
-        size_t r = idx / C4;
+        const int g = (int)(idx % G);
+        size_t r = idx / G;
         const int ow = (int)(r % OW);
         r /= OW;
         const int oh = (int)(r % OH);
         const int b = (int)(r / OH);
         const int h0 = oh * 2, w0 = ow * 2;
         const int h1 = min(h0 + 3, H), w1 = min(w0 + 3, W);   // ceil_mode windows are clipped at the edge
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        float8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m.v[e] = -INFINITY;
         for (int h = h0; h < h1; ++h)
             for (int w = w0; w < w1; ++w) {
-                const float4 v = x[(((size_t)b * H + h) * W + w) * C4 + c];
-                m.x = fmaxf(m.x, v.x);
-                m.y = fmaxf(m.y, v.y);
-                m.z = fmaxf(m.z, v.z);
-                m.w = fmaxf(m.w, v.w);
+                const float8 v = act_load8(x, 0, ((size_t)b * H + h) * W + w, C, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m.v[e] = fmaxf(m.v[e], v.v[e]);
             }
-        y[idx] = m;
+        act_store8(y, yfmt, ((size_t)b * OH + oh) * OW + ow, C, g, m);
     }
 }
 
 // y = bilinear(top, align_corners=True -> (H,W)) + lateral.  Index/weight arithmetic follows
 // ATen's upsample_bilinear2d (area_pixel_compute_scale: (in-1)/(out-1); h1 = (int)h1r;
 // lambda = h1r - h1), accumulation order w0*(... ) as written there.
-__global__ void upsample_add_kernel(const float4 *__restrict__ top, int TH, int TW, const float4 *__restrict__ lat,
-                                    int B, int H, int W, int C4, float4 *__restrict__ y)
+__global__ void upsample_add_kernel(const float *__restrict__ top, int TH, int TW, const float *__restrict__ lat,
+                                    int B, int H, int W, int C, float *__restrict__ y, int top_fmt, int yfmt)
 {
     const float rh = H > 1 ? (float)(TH - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(TW - 1) / (float)(W - 1) : 0.f;
-    const size_t total = (size_t)B * H * W * C4;
+    const int G = C / 8;
+    const size_t total = (size_t)B * H * W * G;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C4);
-        size_t r = idx / C4;
+        const int g = (int)(idx % G);
+        size_t r = idx / G;
         const int w = (int)(r % W);
         r /= W;
         const int h = (int)(r % H);
@@ -83,16 +86,31 @@ __global__ void upsample_add_kernel(const float4 *__restrict__ top, int TH, int 
         const int w1 = (int)w1r;
         const int w1p = (w1 < TW - 1) ? 1 : 0;
         const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-        const float4 *t0 = top + (((size_t)b * TH + h1) * TW + w1) * C4 + c;
-        const float4 a = t0[0], bb = t0[(size_t)w1p * C4];
-        const float4 cc = t0[(size_t)h1p * TW * C4], d = t0[((size_t)h1p * TW + w1p) * C4];
-        const float4 l = lat[idx];
-        float4 o;
-        o.x = (h0l * (w0l * a.x + w1l * bb.x) + h1l * (w0l * cc.x + w1l * d.x)) + l.x;
-        o.y = (h0l * (w0l * a.y + w1l * bb.y) + h1l * (w0l * cc.y + w1l * d.y)) + l.y;
-        o.z = (h0l * (w0l * a.z + w1l * bb.z) + h1l * (w0l * cc.z + w1l * d.z)) + l.z;
-        o.w = (h0l * (w0l * a.w + w1l * bb.w) + h1l * (w0l * cc.w + w1l * d.w)) + l.w;
-        y[idx] = o;
+        const size_t t0 = ((size_t)b * TH + h1) * TW + w1;
+        const float8 a = act_load8(top, top_fmt, t0, C, g), bb = act_load8(top, top_fmt, t0 + w1p, C, g);
+        const float8 cc = act_load8(top, top_fmt, t0 + (size_t)h1p * TW, C, g);
+        const float8 d = act_load8(top, top_fmt, t0 + (size_t)h1p * TW + w1p, C, g);
+        const size_t pix = ((size_t)b * H + h) * W + w;
+        const float8 l = act_load8(lat, 0, pix, C, g);
+        float8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o.v[e] = (h0l * (w0l * a.v[e] + w1l * bb.v[e]) + h1l * (w0l * cc.v[e] + w1l * d.v[e])) + l.v[e];
+        act_store8(y, yfmt, pix, C, g, o);
+    }
+}
+
+// NHWC activation format conversion on 8-channel groups
+__global__ void act_convert_kernel(const void *__restrict__ x, int xfmt, void *__restrict__ y, int yfmt, size_t pixels,
+                                   int C)
+{
+    const int G = C / 8;
+    const size_t total = pixels * G;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = idx / G;
+        const int g = (int)(idx - pix * G);
+        act_store8(y, yfmt, pix, C, g, act_load8(x, xfmt, pix, C, g));
     }
 }
 
@@ -147,28 +165,42 @@ int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, srcnn
     return check_launch("srcnn_stem_pack");
 }
 
-int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y, int OH, int OW,
+int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y, int OH, int OW, int y_format,
                             srcnn_stream_t stream)
 {
     using namespace srcnn;
-    SRCNN_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
+    SRCNN_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     SRCNN_REQUIRE((OH - 1) * 2 < H && (OW - 1) * 2 < W, "output too large for input");
-    const size_t total = (size_t)B * OH * OW * (C / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4 *>(x), B, H, W, C / 4, reinterpret_cast<float4 *>(y), OH, OW);
+    SRCNN_REQUIRE((unsigned)y_format <= 1, "bad format");
+    const size_t total = (size_t)B * OH * OW * (C / 8);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, B, H, W, C,
+                       y, OH, OW, y_format);
     return check_launch("srcnn_maxpool3x3s2_ceil");
 }
 
 int srcnn_upsample_add(const float *top, int TH, int TW, const float *lateral, int B, int H, int W, int C, float *y,
-                       srcnn_stream_t stream)
+                       int top_format, int y_format, srcnn_stream_t stream)
 {
     using namespace srcnn;
-    SRCNN_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
-    const size_t total = (size_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4 *>(top), TH, TW, reinterpret_cast<const float4 *>(lateral), B, H,
-                       W, C / 4, reinterpret_cast<float4 *>(y));
+    SRCNN_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
+    SRCNN_REQUIRE((unsigned)top_format <= 1 && (unsigned)y_format <= 1, "bad format");
+    const size_t total = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), top, TH, TW,
+                       lateral, B, H, W, C, y, top_format, y_format);
     return check_launch("srcnn_upsample_add");
+}
+
+int srcnn_act_convert(const void *x, int x_format, void *y, int y_format, long long pixels, int C,
+                      srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(x && y && pixels >= 0 && C > 0 && C % 8 == 0, "bad args (C must be a multiple of 8)");
+    SRCNN_REQUIRE((unsigned)x_format <= 1 && (unsigned)y_format <= 1, "bad format");
+    if (pixels == 0) return SRCNN_OK;
+    const size_t total = (size_t)pixels * (C / 8);
+    hipLaunchKernelGGL(act_convert_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, x_format, y,
+                       y_format, (size_t)pixels, C);
+    return check_launch("srcnn_act_convert");
 }
 
 int srcnn_subsample2(const float *x, int B, int H, int W, int C, float *y, int OH, int OW, srcnn_stream_t stream)

@@ -14,7 +14,7 @@
 //     channel slice of the head's GEMM operand.
 // The float/double promotion pattern of the reference kernel (its `1.` literals) is
 // reproduced operation by operation; the library is built with -ffp-contract=off.
-#include "common.h"
+#include "conv_common.h"
 
 namespace srcnn {
 
@@ -85,7 +85,7 @@ struct PyramidArgs {
 // grid (A, n); block = C threads (C multiple of 64, <= 1024). One output row per block.
 template <int A>
 __global__ void pyramid_roi_align_kernel(PyramidArgs pa, int channels, const float *__restrict__ rois,
-                                         float *__restrict__ out, int out_cstride, int out_coffset)
+                                         float *__restrict__ out, int out_cstride, int out_coffset, int mfmt, int ofmt)
 {
     const int n = blockIdx.y, py = blockIdx.x, c = threadIdx.x;
     const float *r = rois + (size_t)n * 5;
@@ -98,8 +98,9 @@ __global__ void pyramid_roi_align_kernel(PyramidArgs pa, int channels, const flo
     const int l = __builtin_amdgcn_readfirstlane((int)lv - 2);   // same roi for the whole block
     const int height = pa.mh[l], width = pa.mw[l];
     RoiGeom g = roi_geom(r, pa.scale[l], A + 1, A + 1);
-    const float *base = pa.maps[l] + (size_t)g.batch * height * width * channels + c;
-    auto at = [&](int y, int x) { return base[((size_t)y * width + x) * channels]; };
+    const float *base = pa.maps[l];
+    const size_t img = (size_t)g.batch * height * width;
+    auto at = [&](int y, int x) { return act_load(base, mfmt, img + (size_t)y * width + x, channels, c); };
     float top[A + 1], bot[A + 1];
     const float h0 = (float)py * g.bin_h + g.start_h;
     const float h1 = (float)(py + 1) * g.bin_h + g.start_h;
@@ -109,14 +110,13 @@ __global__ void pyramid_roi_align_kernel(PyramidArgs pa, int channels, const flo
         top[px] = lattice_point(h0, w, height, width, at);
         bot[px] = lattice_point(h1, w, height, width, at);
     }
-    float *o = out + ((size_t)(n * A + py) * A) * out_cstride + out_coffset + c;
 #pragma unroll
     for (int px = 0; px < A; ++px) {
         float s = top[px];
         s = s + top[px + 1];
         s = s + bot[px];
         s = s + bot[px + 1];
-        o[(size_t)px * out_cstride] = s * 0.25f;
+        act_store(out, ofmt, (size_t)(n * A + py) * A + px, out_cstride, out_coffset + c, s * 0.25f);
     }
 }
 
@@ -147,11 +147,13 @@ int roi_align_forward_cuda(int aligned_height, int aligned_width, float spatial_
 
 int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, const int *mw_host, int channels,
                             float im_height, const float *rois, int num_rois, int A, float *out, int out_cstride,
-                            int out_coffset, srcnn_stream_t stream)
+                            int out_coffset, int maps_format, int out_format, srcnn_stream_t stream)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(channels % 64 == 0 && channels <= 1024, "channels must be a multiple of 64, <= 1024");
     SRCNN_REQUIRE(A == 7 || A == 14, "A must be 7 or 14");
+    SRCNN_REQUIRE((unsigned)maps_format <= 1 && (unsigned)out_format <= 1, "bad format");
+    if (out_format == 1) SRCNN_REQUIRE(out_cstride % 8 == 0 && out_coffset % 8 == 0, "SPLIT16 output alignment");
     if (num_rois == 0) return SRCNN_OK;
     PyramidArgs pa;
     for (int l = 0; l < 4; ++l) {
@@ -164,10 +166,10 @@ int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, c
     dim3 grid(A, num_rois), block(channels);
     if (A == 7)
         hipLaunchKernelGGL(pyramid_roi_align_kernel<7>, grid, block, 0, as_stream(stream), pa, channels, rois, out,
-                           out_cstride, out_coffset);
+                           out_cstride, out_coffset, maps_format, out_format);
     else
         hipLaunchKernelGGL(pyramid_roi_align_kernel<14>, grid, block, 0, as_stream(stream), pa, channels, rois,
-                           out, out_cstride, out_coffset);
+                           out, out_cstride, out_coffset, maps_format, out_format);
     return check_launch("srcnn_pyramid_roi_align");
 }
 

@@ -103,8 +103,8 @@ _TUNED = {}
 _CANDIDATES = [(2, 2), (2, 1), (1, 2), (1, 1)]
 
 
-def _shape_key(cw, B, H, W, OH, OW, x_cstride, precision):
-    return (precision, B, H, W, OH, OW, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, cw.mode, x_cstride)
+def _shape_key(cw, B, H, W, OH, OW, x_cstride, precision, fmts=(0, 0, 0)):
+    return (precision, B, H, W, OH, OW, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, cw.mode, x_cstride) + tuple(fmts)
 
 
 def _tune(d, key, device):
@@ -149,8 +149,9 @@ def _tune(d, key, device):
 
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
-           res_cstride=None, x_offset_elems=0, relu=None, precision=None):
-    """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory)."""
+           res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0):
+    """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
+    *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h)."""
     L = _lib.lib()
     d = _lib.ConvDesc()
     d.x = x.data_ptr() + 4 * x_offset_elems
@@ -173,11 +174,12 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     d.res_cstride = cw.cout if res_cstride is None else res_cstride
     d.relu = cw.relu if relu is None else int(relu)
     d.mode = cw.mode
+    d.x_format, d.y_format, d.res_format = x_fmt, y_fmt, res_fmt
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
     if AUTOTUNE:
-        key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision)
+        key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt))
         plan = _TUNED.get(key)
         if plan is None:
             if torch.cuda.is_current_stream_capturing():
@@ -198,14 +200,25 @@ def stem_pack(im_nchw, out, batch_offset=0):
     _lib.check(L.srcnn_stem_pack(_lib.ptr(im_nchw), B, H, W, out.data_ptr() + off, _lib.stream()), "srcnn_stem_pack")
 
 
-def maxpool3x3s2_ceil(x, B, H, W, C, y, OH, OW):
-    _lib.check(_lib.lib().srcnn_maxpool3x3s2_ceil(x.data_ptr(), B, H, W, C, y.data_ptr(), OH, OW, _lib.stream()),
-               "srcnn_maxpool3x3s2_ceil")
+def maxpool3x3s2_ceil(x, B, H, W, C, y, OH, OW, y_fmt=0):
+    _lib.check(_lib.lib().srcnn_maxpool3x3s2_ceil(x.data_ptr(), B, H, W, C, y.data_ptr(), OH, OW, y_fmt,
+                                                  _lib.stream()), "srcnn_maxpool3x3s2_ceil")
 
 
-def upsample_add(top, TH, TW, lateral, B, H, W, C, y):
+def upsample_add(top, TH, TW, lateral, B, H, W, C, y, top_fmt=0, y_fmt=0):
     _lib.check(_lib.lib().srcnn_upsample_add(top.data_ptr(), TH, TW, lateral.data_ptr(), B, H, W, C, y.data_ptr(),
-                                             _lib.stream()), "srcnn_upsample_add")
+                                             top_fmt, y_fmt, _lib.stream()), "srcnn_upsample_add")
+
+
+def act_convert(x, x_fmt, y_fmt):
+    """NHWC activation tensor (.., C) F32 <-> SPLIT16 (same shape / byte size; the SPLIT16 tensor is an
+    opaque float32-typed buffer)."""
+    C = int(x.shape[-1])
+    pixels = x.numel() // C
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().srcnn_act_convert(_lib.ptr(x), x_fmt, y.data_ptr(), y_fmt, pixels, C, _lib.stream()),
+               "srcnn_act_convert")
+    return y
 
 
 def subsample2(x, B, H, W, C, y, OH, OW):

@@ -147,6 +147,7 @@ class Plan(object):
         self.left_prob = e(R, G)
         self.right_prob = e(R, G)
         self.graphs = {}
+        self.fmt = 0            # activation format of the internal buffers for the current/last run
 
     # ------------------------------------------------------------------ stages
     def trunk(self):
@@ -157,21 +158,23 @@ class Plan(object):
         sh, sw = self.stem_hw
         engine.conv2d(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, x_cstride=4)
         ph, pw = self.c1_hw
-        engine.maxpool3x3s2_ceil(self.stem_out, N, sh, sw, 64, self.c1, ph, pw)
+        f = self.fmt
+        engine.maxpool3x3s2_ceil(self.stem_out, N, sh, sw, 64, self.c1, ph, pw, y_fmt=f)
         x, xh, xw = self.c1, ph, pw
         for li, blocks in enumerate(w.layers):
             h, w_ = self.layer_hw[li]
             bufs = self.layer_bufs[li]
             cur, nxt = bufs['a'], bufs['b']
             for bi, blk in enumerate(blocks):
-                engine.conv2d(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_)
-                engine.conv2d(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_)
+                engine.conv2d(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, x_fmt=f, y_fmt=f)
+                engine.conv2d(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, x_fmt=f, y_fmt=f)
                 if blk['down'] is not None:
-                    engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_)
+                    engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f)
                     res = nxt
                 else:
                     res = x
-                engine.conv2d(blk['conv3'], bufs['m2'], N, h, w_, cur, h, w_, residual=res)
+                engine.conv2d(blk['conv3'], bufs['m2'], N, h, w_, cur, h, w_, residual=res, x_fmt=f, y_fmt=f,
+                              res_fmt=f)
                 x, xh, xw = cur, h, w_
                 cur, nxt = nxt, cur
             self.c[li] = x
@@ -180,14 +183,15 @@ class Plan(object):
         w, N = self.w, self.N
         (h2, w2), (h3, w3), (h4, w4), (h5, w5) = self.layer_hw
         c2, c3, c4, c5 = self.c
-        engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5)
+        f = self.fmt
+        engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, x_fmt=f, y_fmt=f)
         tops = [(self.p5, h5, w5), None, None]
         for i, (cin, (h, w_), out) in enumerate(((c4, (h4, w4), self.p4), (c3, (h3, w3), self.p3),
                                                  (c2, (h2, w2), self.p2))):
             top, th, tw = tops[i]
-            engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_)
-            engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i])     # stereo_rcnn.py:91-108
-            engine.conv2d(w.smooth[i], self.summed[i], N, h, w_, out, h, w_)
+            engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)         # lateral stays F32
+            engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i], top_fmt=f, y_fmt=f)   # stereo_rcnn.py:91-108
+            engine.conv2d(w.smooth[i], self.summed[i], N, h, w_, out, h, w_, x_fmt=f, y_fmt=f)
             if i + 1 < 3:
                 tops[i + 1] = (out, h, w_)
         h6, w6 = self.rpn_shapes[4]
@@ -201,10 +205,11 @@ class Plan(object):
         st = _lib.stream()
         for l, (h, w_) in enumerate(self.rpn_shapes):
             cat, hd = self.rpn_cat[l], self.rpn_hd[l]
-            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0)
+            f = self.fmt
+            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f)
             engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
-                          x_offset_elems=B * h * w_ * 256)
-            engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_)
+                          x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f)
+            engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_, x_fmt=f)
             _lib.check(L.srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(), self.deltas.data_ptr(),
                                          off, self.A, st), "srcnn_rpn_score")
             off += 3 * h * w_
@@ -231,8 +236,8 @@ class Plan(object):
         mh = (ctypes.c_int * 4)(*[h for h, _ in hw])
         mw = (ctypes.c_int * 4)(*[w_ for _, w_ in hw])
         _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, 256, float(self.H), rois.data_ptr(), self.R, A,
-                                                      out.data_ptr(), cstride, coffset, _lib.stream()),
-                   "srcnn_pyramid_roi_align")
+                                                      out.data_ptr(), cstride, coffset, self.fmt, self.fmt,
+                                                      _lib.stream()), "srcnn_pyramid_roi_align")
 
     def heads(self):
         w, R = self.w, self.R
@@ -241,9 +246,10 @@ class Plan(object):
         st = _lib.stream()
         self._pyramid(False, self.rois_left, P, self.sem, 512, 0)        # stereo_rcnn.py:248-249
         self._pyramid(True, self.rois_right, P, self.sem, 512, 256)
-        engine.conv2d(w.top0, self.sem, R, 1, 1, self.h1, 1, 1)           # 7x7/7 conv == GEMM (resnet.py:257)
-        engine.conv2d(w.top3, self.h1, R, 1, 1, self.h2, 1, 1)
-        engine.conv2d(w.fc, self.h2, R, 1, 1, self.fc, 1, 1)
+        f = self.fmt
+        engine.conv2d(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, x_fmt=f, y_fmt=f)   # 7x7/7 conv == GEMM (resnet.py:257)
+        engine.conv2d(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, x_fmt=f, y_fmt=f)
+        engine.conv2d(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, x_fmt=f)
         ncol = w.fc.cout
         _lib.check(L.srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, ncol,
                                         self.cls_prob.data_ptr(), st), "srcnn_softmax_rows")
@@ -252,11 +258,11 @@ class Plan(object):
         s = 2 * P
         for i, cw in enumerate(w.kpts):
             y = self.kp_a if i % 2 == 0 else self.kp_b
-            engine.conv2d(cw, x, R, s, s, y, s, s)
+            engine.conv2d(cw, x, R, s, s, y, s, s, x_fmt=f, y_fmt=f)
             x = y
-        engine.conv2d(w.kpts_up, x, R, s, s, self.kp_up, s, s)
+        engine.conv2d(w.kpts_up, x, R, s, s, self.kp_up, s, s, x_fmt=f, y_fmt=f)
         G = cfg.KPTS_GRID
-        engine.conv2d(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G)
+        engine.conv2d(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, x_fmt=f)
         _lib.check(L.srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, self.kpts_prob.data_ptr(),
                                      self.left_prob.data_ptr(), self.right_prob.data_ptr(), st), "srcnn_kpts_tail")
 
@@ -277,6 +283,9 @@ class Plan(object):
         """precision: 'f32' (exact fp32 MFMA engine) or 'f16x3' (3-term split on the f16 MFMA)."""
         prev = engine.PRECISION
         engine.PRECISION = precision
+        # the f16x3 engine keeps activations in the SPLIT16 format between convolutions so that
+        # both GEMM operands are DMA'd into LDS (csrc/conv_f16s.hip); the fp32 engine uses F32
+        self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
         try:
             if not use_graph:
                 self.launch_all()
@@ -291,6 +300,10 @@ class Plan(object):
             self.graphs[precision].replay()
         finally:
             engine.PRECISION = prev
+
+    def as_f32(self, buf):
+        """fp32 NHWC copy of an internal activation buffer (whatever format the last run used)."""
+        return engine.act_convert(buf, self.fmt, _lib.FMT_F32) if self.fmt else buf
 
     def outputs(self):
         w, B = self.w, self.B

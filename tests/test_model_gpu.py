@@ -238,9 +238,9 @@ def test_f16x3_engine_end_to_end_small(small, dev):
         torch.cuda.synchronize()
         plan = small['plan']
         for i in range(4):
-            assert _relerr(_nchw(plan.c[i], 0), ref['c_left'][i][0]) < 2e-4
+            assert _relerr(_nchw(plan.as_f32(plan.c[i]), 0), ref['c_left'][i][0]) < 2e-4
         for i, buf in enumerate((plan.p2, plan.p3, plan.p4, plan.p5, plan.p6)):
-            assert _relerr(_nchw(buf, 1), ref['p_right'][i][0]) < 2e-4
+            assert _relerr(_nchw(plan.as_f32(buf), 1), ref['p_right'][i][0]) < 2e-4
         assert float((plan.probs.cpu() - ref['rpn_probs']).abs().max()) < 1e-4
     finally:
         m.precision = 'f32'
@@ -264,7 +264,7 @@ def test_f16x3_engine_full_size_vs_golden(dev):
     worst = 0.0
     for key, bufs, side in (('c_left', plan.c, 0), ('p_right', (plan.p2, plan.p3, plan.p4, plan.p5, plan.p6), 1)):
         for i, buf in enumerate(bufs):
-            got = _nchw(buf, side).reshape(-1)[torch.from_numpy(g['%s%d_pos' % (key, i)])]
+            got = _nchw(plan.as_f32(buf), side).reshape(-1)[torch.from_numpy(g['%s%d_pos' % (key, i)])]
             e = _relerr(got, torch.from_numpy(g['%s%d_val' % (key, i)]))
             worst = max(worst, e)
             assert e < 2e-4, (key, i, e)

@@ -125,7 +125,7 @@ def test_pyramid_roi_align_fused(dev, A):
     mh = (ctypes.c_int * 4)(*[h for h, _ in hw]); mw = (ctypes.c_int * 4)(*[w for _, w in hw])
     tr = torch.from_numpy(rois).to(dev)
     _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, C, 600.0, tr.data_ptr(), n, A, out.data_ptr(), 2 * C, C,
-                                                  _lib.stream()))
+                                                  0, 0, _lib.stream()))
     got = out[:, :, :, C:].permute(0, 3, 1, 2).cpu().numpy()
     lv_dev = onet.roi_levels(torch.from_numpy(rois))
     assert float(out[:, :, :, :C].abs().sum()) == 0.0          # other channel slice untouched
@@ -155,7 +155,14 @@ def _conv_case(dev, B, H, W, cin, cout, k, stride, pad, relu, res, bn, seed, pre
     xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
     rd = r.to(dev).permute(0, 2, 3, 1).contiguous() if res else None
     y = torch.empty((B, OH, OW, cout), device=dev)
-    engine.conv2d(cw, xd, B, H, W, y, OH, OW, residual=rd, precision=precision)
+    if precision == 'f16s':      # f16x3 arithmetic, SPLIT16 activations in HBM, both operands DMA'd to LDS
+        fo = 1 if cout % 8 == 0 else 0
+        xs = engine.act_convert(xd, 0, 1)
+        rs = engine.act_convert(rd, 0, 1) if res else None
+        engine.conv2d(cw, xs, B, H, W, y, OH, OW, residual=rs, precision='f16x3', x_fmt=1, y_fmt=fo, res_fmt=1 if res else 0)
+        y = engine.act_convert(y, fo, 0) if fo else y
+    else:
+        engine.conv2d(cw, xd, B, H, W, y, OH, OW, residual=rd, precision=precision)
     got = y.permute(0, 3, 1, 2).cpu()
     err = float((got - ref).abs().max())
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
@@ -173,7 +180,7 @@ def _conv_case(dev, B, H, W, cin, cout, k, stride, pad, relu, res, bn, seed, pre
     (1, 7, 9, 2048, 512, 1, 1, 0, False, False, False),      # small M, long K -> split-K
     (3, 14, 14, 256, 256, 3, 1, 1, True, False, False),      # kpts tower
 ])
-@pytest.mark.parametrize("precision", ['f32', 'f16x3'])
+@pytest.mark.parametrize("precision", ['f32', 'f16x3', 'f16s'])
 def test_conv_engine_vs_torch_cpu(dev, case, precision):
     """Both engines must meet the SAME tolerance (the f16x3 split is fp32-class by construction)."""
     _conv_case(dev, *case, seed=hash(case) % 1000, precision=precision)
@@ -204,7 +211,20 @@ def test_conv_stem_vs_torch_cpu(dev, precision):
     assert float((p.permute(0, 3, 1, 2).cpu() - refp).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("precision", ['f32', 'f16x3'])
+def test_act_convert_roundtrip(dev):
+    from stereo_rcnn_amd import engine
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(3, 5, 7, 64, generator=g) * torch.tensor([1e-2, 1.0, 300.0, 30.0]).repeat(16)).to(dev)
+    s = engine.act_convert(x, 0, 1)
+    back = engine.act_convert(s, 1, 0)
+    # hi + lo reproduces the value to ~2^-22 relative while lo is a normal f16 (|x| >~ 0.1); below that
+    # lo is subnormal-limited to an ABSOLUTE error of 2^-25 ~ 3e-8
+    err = (back - x).abs()
+    assert float((err / x.abs().clamp(min=0.125)).max()) < 5e-7, float((err / x.abs().clamp(min=0.125)).max())
+    assert torch.equal(engine.act_convert(engine.act_convert(back, 0, 1), 1, 0), back)   # idempotent
+
+
+@pytest.mark.parametrize("precision", ['f32', 'f16x3', 'f16s'])
 def test_deconv2x2_vs_torch_cpu(dev, precision):
     from stereo_rcnn_amd import engine
     g = torch.Generator().manual_seed(2)
@@ -214,7 +234,12 @@ def test_deconv2x2_vs_torch_cpu(dev, precision):
     ref = F.relu(F.conv_transpose2d(x, w, b, 2))
     cw = engine.prep_deconv2x2(w, b, device=dev)
     y = torch.empty((5, 28, 28, 256), device=dev)
-    engine.conv2d(cw, x.to(dev).permute(0, 2, 3, 1).contiguous(), 5, 14, 14, y, 14, 14, precision=precision)
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    if precision == 'f16s':
+        engine.conv2d(cw, engine.act_convert(xd, 0, 1), 5, 14, 14, y, 14, 14, precision='f16x3', x_fmt=1, y_fmt=1)
+        y = engine.act_convert(y, 1, 0)
+    else:
+        engine.conv2d(cw, xd, 5, 14, 14, y, 14, 14, precision=precision)
     assert float((y.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 2e-5
 
 

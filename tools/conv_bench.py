@@ -25,22 +25,29 @@ SHAPES = [
     ('kpts 3x3 256 (300x14x14)', 300, 14, 14, 256, 256, 3, 1, 1),
 ]
 PREC = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+SPLIT = PREC == 'f16s'          # f16x3 arithmetic with SPLIT16 activations (DMA-to-LDS kernel)
+if SPLIT:
+    PREC = 'f16x3'
 engine.PRECISION = PREC
-print('precision', PREC)
+print('precision', PREC, 'split16 activations' if SPLIT else '')
 for name, B, H, W, cin, cout, k, s, p in SHAPES:
     x = torch.randn(B, H, W, cin, device=dev)
     w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
     cw = engine.prep_conv(w, torch.zeros(cout), s, p, True, device=dev)
     OH, OW = engine.conv_out_hw(H, W, k, k, s, p)
     y = torch.empty(B, OH, OW, cout, device=dev)
+    kw = {}
+    if SPLIT:
+        x = engine.act_convert(x, 0, 1)
+        kw = dict(x_fmt=1, y_fmt=1 if cout % 8 == 0 else 0)
     for _ in range(3):
-        engine.conv2d(cw, x, B, H, W, y, OH, OW)
+        engine.conv2d(cw, x, B, H, W, y, OH, OW, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 10
     e0.record()
     for _ in range(n):
-        engine.conv2d(cw, x, B, H, W, y, OH, OW)
+        engine.conv2d(cw, x, B, H, W, y, OH, OW, **kw)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * B * OH * OW * cout * cin * k * k
