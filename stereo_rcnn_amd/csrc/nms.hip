@@ -6,10 +6,9 @@
 //     (:31-39) so the keep list is bit-identical.  Tiles below the diagonal are skipped:
 //     the greedy pass never reads them (:139-142 starts at j = nblock).
 //   * greedy_scan_kernel replaces the HOST loop (:117-144): the reference copies the whole
-//     mask to the CPU and reduces it serially; here one wavefront per problem walks the
-//     column blocks, resolves the 64 boxes of a block against the diagonal tile with
-//     wave shuffles, and ORs the kept rows into per-lane `removed` words.  No D2H copy,
-//     no sync, no malloc: graph-capturable.
+//     mask to the CPU and reduces it serially; here one workgroup per problem walks the
+//     column blocks on the device (see the kernel's comment).  No D2H copy, no sync, no
+//     malloc: graph-capturable.
 #include "common.h"
 #include <mutex>
 
@@ -59,68 +58,75 @@ __global__ __launch_bounds__(64) void pair_mask_kernel(const float *__restrict__
     }
 }
 
-// One wavefront per problem. Lane l owns removed-words j = l + 64*s, s < WPL.
-template <int WPL>
-__global__ __launch_bounds__(64) void greedy_scan_kernel(const unsigned long long *__restrict__ mask, int n,
-                                                         int col_blocks, const int *__restrict__ n_valid,
-                                                         int *__restrict__ keep_out, int *__restrict__ num_out)
+// One workgroup per problem, one wavefront per 64 mask words (column blocks): lane l of wave w owns
+// the `removed` word of column block j = 64*w + l.  For each block b of 64 boxes (in score order):
+//   1. every lane issues the loads of ALL 64 candidate rows' word j up front (64 independent loads
+//      in flight: the walk pays ~one L2 round trip per block instead of one per kept row);
+//   2. meanwhile the block's 64 boxes are resolved against the diagonal tile on the scalar unit:
+//      only KEPT boxes cost an iteration (find-first-set on the availability mask + one readlane);
+//   3. the rows of the kept boxes are OR-ed into the lane's word, the word of block b+1.. is
+//      published through LDS for the next step.
+// Waves of a workgroup stay in lockstep (two barriers per step); every wave resolves the diagonal
+// redundantly so no cross-wave broadcast of the kept mask is needed.
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane)
 {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(v & 0xFFFFFFFFULL), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void greedy_scan_kernel(const unsigned long long *__restrict__ mask, int n,
+                                                          int col_blocks, const int *__restrict__ n_valid,
+                                                          int *__restrict__ keep_out, int *__restrict__ num_out)
+{
+    __shared__ unsigned long long removed[256];
     const int prob = blockIdx.x;
     const unsigned long long *m = mask + (size_t)prob * n * col_blocks;
     int *keep = keep_out + (size_t)prob * n;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int nv = n_valid ? min(n_valid[prob], n) : n;
-    unsigned long long removed[WPL];
-#pragma unroll
-    for (int s = 0; s < WPL; ++s) removed[s] = 0;
-    int count = 0;
     const int nblocks = (nv + 63) / 64;
+    const int j = min(tid, col_blocks - 1);           // my column block (clamped lanes do harmless work)
+    removed[tid] = 0ULL;
+    __syncthreads();
+    int count = 0;
     for (int b = 0; b < nblocks; ++b) {
         const int in_block = min(64, nv - b * 64);
-        // current removed word of this block lives in lane (b & 63), slot (b >> 6)
-        unsigned long long mine = 0;
+        // 1. all 64 rows' words for my column, unconditionally (rows clamped), 64 loads in flight
+        unsigned long long v[64];
+        const unsigned long long *col = m + (size_t)(b * 64) * col_blocks + j;
+        const int rmax = n - 1 - b * 64;
 #pragma unroll
-        for (int s = 0; s < WPL; ++s)
-            if ((b >> 6) == s) mine = removed[s];
-        unsigned long long cur = __shfl(mine, b & 63);
-        if (in_block < 64) cur |= ~0ULL << in_block;  // boxes past the end never get kept
-        // diagonal tile: lane t holds the word of box 64b+t against its own block
-        unsigned long long diag = (lane < in_block) ? m[(size_t)(b * 64 + lane) * col_blocks + b] : 0ULL;
-        unsigned long long kept = 0;
-        for (int t = 0; t < 64; ++t) {
-            unsigned long long d = __shfl(diag, t);
-            if (!((cur >> t) & 1ULL)) {  // wave-uniform
-                kept |= 1ULL << t;
-                cur |= d;
-            }
+        for (int t = 0; t < 64; ++t) v[t] = col[(size_t)min(t, rmax) * col_blocks];
+        // 2. diagonal resolve (wave-uniform; scalar unit)
+        const unsigned long long diag = (lane < in_block) ? m[(size_t)(b * 64 + lane) * col_blocks + b] : 0ULL;
+        unsigned long long cur = removed[b];
+        if (in_block < 64) cur |= ~0ULL << in_block;
+        unsigned cl = __builtin_amdgcn_readfirstlane((unsigned)(cur & 0xFFFFFFFFULL));
+        unsigned ch = __builtin_amdgcn_readfirstlane((unsigned)(cur >> 32));
+        cur = ((unsigned long long)ch << 32) | cl;
+        unsigned long long kept = 0, avail = ~cur;
+        while (avail) {
+            const int t = __ffsll((long long)avail) - 1;
+            kept |= 1ULL << t;
+            cur |= readlane64(diag, t);                 // bits > t only (kernel writes the upper triangle)
+            avail = ~cur & ~((2ULL << t) - 1ULL);
+            if (t == 63) break;
         }
-        if ((kept >> lane) & 1ULL)
-            keep[count + __popcll(kept & ((1ULL << lane) - 1ULL))] = b * 64 + lane;
+        if (tid < 64) {
+            if ((kept >> lane) & 1ULL) keep[count + __popcll(kept & ((1ULL << lane) - 1ULL))] = b * 64 + lane;
+        }
         count += __popcll(kept);
-        // OR the kept rows into the removed words of the later blocks (16 loads in flight)
+        // 3. OR the kept rows into my word
+        unsigned long long acc = 0;
 #pragma unroll
-        for (int s = 0; s < WPL; ++s) {
-            const int j = lane + 64 * s;
-            if (j > b && j < nblocks) {
-                unsigned long long acc = removed[s];
-                for (int t0 = 0; t0 < 64; t0 += 16) {
-                    if (((kept >> t0) & 0xFFFFULL) == 0) continue;  // wave-uniform skip
-                    // unconditional loads (row clamped) so 16 stay in flight; select on the value
-                    unsigned long long v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int r = min(b * 64 + t0 + u, n - 1);
-                        v[u] = m[(size_t)r * col_blocks + j];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u)
-                        if ((kept >> (t0 + u)) & 1ULL) acc |= v[u];
-                }
-                removed[s] = acc;
-            }
-        }
+        for (int t = 0; t < 64; ++t)
+            if ((kept >> t) & 1ULL) acc |= v[t];
+        __syncthreads();                                // everyone has read removed[b]
+        if (tid > b && tid < col_blocks) removed[tid] |= acc;
+        __syncthreads();
     }
-    if (lane == 0) num_out[prob] = count;
+    if (tid == 0) num_out[prob] = count;
 }
 
 static int launch_nms(int *keep_out, const float *dets, int *num_out, const int *n_valid, int nb, int n,
@@ -141,12 +147,8 @@ static int launch_nms(int *keep_out, const float *dets, int *num_out, const int 
     }
     auto *mask = static_cast<unsigned long long *>(ws);
     hipLaunchKernelGGL(pair_mask_kernel, dim3(cb, cb, nb), dim3(64), 0, st, dets, n, dim, thresh, mask, cb);
-    if (cb <= 64)
-        hipLaunchKernelGGL(greedy_scan_kernel<1>, dim3(nb), dim3(64), 0, st, mask, n, cb, n_valid, keep_out, num_out);
-    else if (cb <= 128)
-        hipLaunchKernelGGL(greedy_scan_kernel<2>, dim3(nb), dim3(64), 0, st, mask, n, cb, n_valid, keep_out, num_out);
-    else
-        hipLaunchKernelGGL(greedy_scan_kernel<4>, dim3(nb), dim3(64), 0, st, mask, n, cb, n_valid, keep_out, num_out);
+    const int waves = cdiv(cb, 64);                    // <= 4 (n <= 16384)
+    hipLaunchKernelGGL(greedy_scan_kernel, dim3(nb), dim3(64 * waves), 0, st, mask, n, cb, n_valid, keep_out, num_out);
     return check_launch("nms");
 }
 

@@ -7,9 +7,9 @@
 // What the reference does on the host (anchors in numpy every call + H2D, two NMS
 // round-trips with a 4.5 MB mask D2H each, np.intersect1d on the CPU) is here five
 // device launches with no host synchronisation:
-//   1. topk_sort_kernel     exact top-K by (score desc, index asc): radix select on the
-//                           order-preserving score key, tie-break select on the index,
-//                           compaction into LDS and an in-LDS bitonic sort (one CU / image).
+//   1. tk_* kernels         exact top-K by (score desc, index asc): chip-wide radix select on the
+//                           order-preserving score key, tie-break select on the index, compaction
+//                           and an in-LDS bitonic sort of the K survivors.
 //                           == torch.sort(descending, stable)[:K]  (proposal_layer.py:96,111-115)
 //   2. gather_decode_kernel anchors recomputed analytically in float64 (bit-equal to the
 //                           numpy anchors cast to float32), left/right decode + clip.
@@ -55,118 +55,141 @@ __device__ __forceinline__ unsigned score_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // larger float -> larger key
 }
 
-constexpr int TK_THREADS = 1024;
 constexpr int TK_MAXK = 8192;
+constexpr int TK_BINS = 2048;      // 11-bit radix digits
 
-// scores: probs[(b*A + i)*2 + 1].  order_out[b*K + r] = index of the r-th best anchor.
-__global__ __launch_bounds__(TK_THREADS) void topk_sort_kernel(const float *__restrict__ probs, int A, int K,
-                                                              int *__restrict__ order_out)
+// Exact top-K by (score desc, index asc) == torch.sort(descending, stable)[:K], as a short chain of
+// chip-wide launches (the first version ran the whole selection in ONE workgroup: 0.48 ms):
+//   3 x { tk_hist (grid-wide LDS histograms of an 11-bit digit of the order-preserving score key)
+//         -> tk_pick (one wave walks the 2048 bins from the top) }     -> key T of the K-th score
+//   2 x { tk_hist on the INDEX digits of the elements with key == T -> tk_pick from the bottom }
+//         (skipped on the device when every tie is taken)              -> largest tie index taken
+//   tk_compact (grid-wide, wave-aggregated append)  ->  tk_sort (in-LDS bitonic sort of <= 8192 keys)
+struct TkState {
+    unsigned prefix, remaining, ties, T, iprefix, idx_limit, need_tb, count;
+};
+
+__global__ void tk_set_remaining_kernel(TkState *state, int B, unsigned k)
 {
-    __shared__ unsigned long long cand[TK_MAXK];
-    __shared__ unsigned hist[16][256];
-    __shared__ unsigned s_prefix, s_remaining, s_ties, s_count;
-    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) state[b].remaining = k;
+}
+
+__global__ __launch_bounds__(256) void tk_hist_kernel(const float *__restrict__ probs, int A, const TkState *state,
+                                                      unsigned *__restrict__ hist, int kind, int shift, int width,
+                                                      unsigned mask_above)
+{
+    __shared__ unsigned lh[TK_BINS];
+    const int b = blockIdx.y;
+    const TkState st = state[b];
+    if (kind == 1 && !st.need_tb) return;
+    for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
     const float *sc = probs + (size_t)b * A * 2 + 1;
-    const int ksel = min(K, A);
+    const unsigned dmask = (1u << width) - 1u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A; i += gridDim.x * blockDim.x) {
+        const unsigned k = score_key(sc[(size_t)i * 2]);
+        if (kind == 0) {
+            if ((k & mask_above) == st.prefix) atomicAdd(&lh[(k >> shift) & dmask], 1u);
+        } else {
+            if (k == st.T && (((unsigned)i) & mask_above) == st.iprefix) atomicAdd(&lh[((unsigned)i >> shift) & dmask], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned *gh = hist + (size_t)b * TK_BINS;
+    for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
 
-    auto clear_hist = [&]() {
-        for (int i = tid; i < 16 * 256; i += TK_THREADS) (&hist[0][0])[i] = 0;
-    };
-    // picks the digit holding the `remaining`-th element counted from the top (desc) or bottom (asc)
-    auto pick_digit = [&](bool from_top, int shift) {
-        if (tid < 256) {   // fold the 16 sub-histograms
-            unsigned s = 0;
+// one wave per image: lane l owns bins [32l, 32l+32)
+__global__ __launch_bounds__(64) void tk_pick_kernel(TkState *state, unsigned *__restrict__ hist, int kind, int shift,
+                                                     int last, int K, int A)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    TkState st = state[b];
+    unsigned *gh = hist + (size_t)b * TK_BINS;
+    if (kind == 1 && !st.need_tb) return;
+    unsigned mine[32], sum = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += hist[r][tid];
-            hist[0][tid] = s;
+    for (int i = 0; i < 32; ++i) { mine[i] = gh[lane * 32 + i]; sum += mine[i]; gh[lane * 32 + i] = 0; }
+    // position of lane in walking order: kind 0 walks from the top bin down, kind 1 from the bottom up
+    const int ord = kind == 0 ? 63 - lane : lane;
+    unsigned before = 0;   // elements in lanes walked before mine
+    for (int o = 0; o < 64; ++o) {
+        const unsigned s_o = __shfl(sum, kind == 0 ? 63 - o : o);
+        if (o < ord) before += s_o;
+    }
+    const unsigned rem = st.remaining;
+    const bool here = before < rem && rem <= before + sum;
+    if (here) {
+        unsigned cum = before;
+        int d = 0;
+        unsigned h = 0;
+        for (int i = 0; i < 32; ++i) {
+            d = kind == 0 ? 31 - i : i;
+            h = mine[d];
+            if (cum + h >= rem) break;
+            cum += h;
         }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned rem = s_remaining, cum = 0;
-            int d = from_top ? 255 : 0;
-            for (int step = 0; step < 256; ++step, d += from_top ? -1 : 1) {
-                const unsigned h = hist[0][d];
-                if (cum + h >= rem) break;
-                cum += h;
+        const unsigned digit = (unsigned)(lane * 32 + d);
+        st.remaining = rem - cum;
+        st.ties = h;
+        if (kind == 0) {
+            st.prefix |= digit << shift;
+            if (last) {
+                st.T = st.prefix;
+                st.need_tb = st.remaining < st.ties ? 1u : 0u;
+                st.iprefix = 0;
+                st.idx_limit = 0xFFFFFFFFu;
             }
-            s_remaining = rem - cum;
-            s_prefix |= (unsigned)d << shift;
-            s_ties = hist[0][d];
+        } else {
+            st.iprefix |= digit << shift;
+            if (last) st.idx_limit = st.iprefix;
         }
-        __syncthreads();
-    };
+        state[b] = st;
+    }
+    (void)K; (void)A;
+}
 
-    if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)ksel; s_ties = 0; s_count = 0; }
-    __syncthreads();
-    // ---- phase 1: key of the ksel-th largest score
-    unsigned mask = 0;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        clear_hist();
-        __syncthreads();
-        const unsigned prefix = s_prefix;
-        for (int i = tid; i < A; i += TK_THREADS) {
-            const unsigned k = score_key(sc[(size_t)i * 2]);
-            if ((k & mask) == prefix) atomicAdd(&hist[tid & 15][(k >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        pick_digit(true, shift);
-        mask |= 0xFFu << shift;
-    }
-    const unsigned T = s_prefix;
-    const unsigned need_ties = s_remaining;   // how many elements with key == T are taken
-    const unsigned have_ties = s_ties;
-    __syncthreads();
-    // ---- phase 2: among key == T take the `need_ties` smallest indices
-    unsigned idx_limit = 0xFFFFFFFFu;
-    if (need_ties < have_ties) {
-        if (tid == 0) { s_prefix = 0; s_remaining = need_ties; }
-        __syncthreads();
-        unsigned imask = 0;
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            clear_hist();
-            __syncthreads();
-            const unsigned prefix = s_prefix;
-            for (int i = tid; i < A; i += TK_THREADS) {
-                if (score_key(sc[(size_t)i * 2]) == T && (((unsigned)i) & imask) == prefix)
-                    atomicAdd(&hist[tid & 15][((unsigned)i >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            pick_digit(false, shift);
-            imask |= 0xFFu << shift;
-        }
-        idx_limit = s_prefix;
-        __syncthreads();
-    }
-    // ---- compaction into LDS (arbitrary order; unique 64-bit keys make the sort total)
-    int np = 1;
-    while (np < ksel) np <<= 1;
-    for (int i = tid; i < np; i += TK_THREADS) cand[i] = 0ULL;
-    __syncthreads();
-    for (int i0 = 0; i0 < A; i0 += TK_THREADS) {
-        const int i = i0 + tid;
+__global__ __launch_bounds__(256) void tk_compact_kernel(const float *__restrict__ probs, int A, TkState *state,
+                                                         unsigned long long *__restrict__ cand, int cap)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const TkState st = state[b];
+    const float *sc = probs + (size_t)b * A * 2 + 1;
+    unsigned long long *out = cand + (size_t)b * cap;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < A; i0 += stride) {
+        const int i = i0 + threadIdx.x;
         bool take = false;
         unsigned k = 0;
         if (i < A) {
             k = score_key(sc[(size_t)i * 2]);
-            take = (k > T) || (k == T && (unsigned)i <= idx_limit);
+            take = (k > st.T) || (k == st.T && (unsigned)i <= st.idx_limit);
         }
         const unsigned long long bal = __ballot(take);
         unsigned base = 0;
-        const int lane = tid & 63;
-        if (lane == 0 && bal) base = atomicAdd(&s_count, (unsigned)__popcll(bal));
+        if (lane == 0 && bal) base = atomicAdd(&state[b].count, (unsigned)__popcll(bal));
         base = __shfl(base, 0);
         if (take) {
             const unsigned pos = base + __popcll(bal & ((1ULL << lane) - 1ULL));
-            if (pos < (unsigned)np) cand[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            if (pos < (unsigned)cap) out[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void tk_sort_kernel(const unsigned long long *__restrict__ cand_in, int cap, int ksel,
+                                                       int K, int *__restrict__ order_out)
+{
+    __shared__ unsigned long long cand[TK_MAXK];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int np = 1;
+    while (np < ksel) np <<= 1;
+    const unsigned long long *in = cand_in + (size_t)b * cap;
+    for (int i = tid; i < np; i += 1024) cand[i] = i < ksel ? in[i] : 0ULL;
     __syncthreads();
-    // ---- bitonic sort, descending
     for (int k = 2; k <= np; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np; i += TK_THREADS) {
+            for (int i = tid; i < np; i += 1024) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const unsigned long long a = cand[i], c = cand[ixj];
@@ -177,7 +200,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_sort_kernel(const float *__re
             __syncthreads();
         }
     }
-    for (int i = tid; i < ksel; i += TK_THREADS)
+    for (int i = tid; i < ksel; i += 1024)
         order_out[(size_t)b * K + i] = (int)(0xFFFFFFFFu - (unsigned)(cand[i] & 0xFFFFFFFFULL));
 }
 
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(1024) void intersect_pad_kernel(const int *__restri
 }
 
 struct ProposalLayout {
-    size_t order, dets, keep, num, nms, total;
+    size_t state, hist, cand, order, dets, keep, num, nms, total;
 };
 
 static ProposalLayout proposal_layout(int B, int n, int K)
@@ -305,6 +328,9 @@ static ProposalLayout proposal_layout(int B, int n, int K)
     ProposalLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    L.state = take((size_t)B * sizeof(TkState));
+    L.hist = take((size_t)B * TK_BINS * sizeof(unsigned));     // contiguous with state: zeroed by one memset
+    L.cand = take((size_t)B * TK_MAXK * sizeof(unsigned long long));
     L.order = take((size_t)B * K * sizeof(int));
     L.dets = take((size_t)B * 2 * n * 5 * sizeof(float));
     L.keep = take((size_t)B * 2 * n * sizeof(int));
@@ -376,7 +402,34 @@ int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num
     int *keep = reinterpret_cast<int *>(ws + L.keep);
     int *num = reinterpret_cast<int *>(ws + L.num);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(topk_sort_kernel, dim3(B), dim3(TK_THREADS), 0, st, probs, num_anchors, n, order);
+    SRCNN_REQUIRE(num_anchors < (1 << 22), "more than 4M anchors not supported");
+    {
+        TkState *state = reinterpret_cast<TkState *>(ws + L.state);
+        unsigned *hist = reinterpret_cast<unsigned *>(ws + L.hist);
+        unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + L.cand);
+        SRCNN_HIP_TRY(hipMemsetAsync(ws + L.state, 0, L.cand - L.state, st));
+        const int ksel = n;
+        const int G = 256;
+        static const int sshift[3] = {21, 10, 0}, swidth[3] = {11, 11, 10};
+        static const unsigned smask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
+        hipLaunchKernelGGL(tk_set_remaining_kernel, dim3(1), dim3(64), 0, st, state, B, (unsigned)ksel);
+        for (int p = 0; p < 3; ++p) {
+            hipLaunchKernelGGL(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, 0,
+                               sshift[p], swidth[p], smask[p]);
+            hipLaunchKernelGGL(tk_pick_kernel, dim3(B), dim3(64), 0, st, state, hist, 0, sshift[p], p == 2, ksel,
+                               num_anchors);
+        }
+        static const int ishift[2] = {11, 0};
+        static const unsigned imask[2] = {0u, 0xFFFFF800u};
+        for (int p = 0; p < 2; ++p) {
+            hipLaunchKernelGGL(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, 1,
+                               ishift[p], 11, imask[p]);
+            hipLaunchKernelGGL(tk_pick_kernel, dim3(B), dim3(64), 0, st, state, hist, 1, ishift[p], p == 1, ksel,
+                               num_anchors);
+        }
+        hipLaunchKernelGGL(tk_compact_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, cand, TK_MAXK);
+        hipLaunchKernelGGL(tk_sort_kernel, dim3(B), dim3(1024), 0, st, cand, TK_MAXK, ksel, n, order);
+    }
     hipLaunchKernelGGL(gather_decode_kernel, dim3(cdiv(B * n, 256)), dim3(256), 0, st, probs, deltas, num_anchors, B,
                        n, n, order, lt, im_info, dets);
     int rc = check_launch("proposal: select/decode");

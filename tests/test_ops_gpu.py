@@ -257,3 +257,25 @@ def test_upsample_add_subsample_layout(dev):
     s = torch.empty((2, 10, 32, 256), device=dev)
     engine.subsample2(td, 2, 19, 63, 256, s, 10, 32)
     assert torch.equal(engine.nhwc_to_nchw(s).cpu(), top[:, :, ::2, ::2])
+
+
+@pytest.mark.parametrize("pre_nms,quant", [(500, 0.01), (1000, 0.001), (6000, 0.05), (300, 1.0)])
+def test_proposal_layer_ties_and_selection(dev, pre_nms, quant):
+    """Top-K with massive score ties (scores quantised so that the K-th value is shared by many anchors):
+    the stable (score desc, index asc) order must match the oracle's stable sort exactly."""
+    from oracle import proposal as oprop
+    from stereo_rcnn_amd.model.rpn.proposal_layer import _ProposalLayer
+    g = torch.Generator().manual_seed(pre_nms)
+    shapes = [[38, 125], [19, 63], [10, 32], [5, 16], [3, 8]]
+    A = sum(3 * h * w for h, w in shapes)
+    sc = torch.rand(1, A, generator=g)
+    sc = torch.round(sc / quant) * quant if quant < 1.0 else torch.full_like(sc, 0.75)     # quant=1: ALL tied
+    probs = torch.stack((1 - sc, sc), 2).contiguous()
+    deltas = (torch.randn(1, A, 6, generator=g) * 0.3).contiguous()
+    info = torch.tensor([[600.0, 1987.0, 1.6]])
+    rl_ref, rr_ref, extra = oprop.proposal_layer(probs, deltas, info, shapes, pre_nms_top_n=pre_nms, post_nms_top_n=120)
+    layer = _ProposalLayer(16, [0.5, 1, 2])
+    rl, rr = layer.run(probs.to(dev), deltas.to(dev), info.to(dev), shapes, pre_nms, 120, 0.7)
+    assert int(layer.last_num_valid[0]) == min(120, len(extra['keep'][0]))
+    assert float((rl.cpu() - rl_ref).abs().max()) < 2e-3
+    assert float((rr.cpu() - rr_ref).abs().max()) < 2e-3
