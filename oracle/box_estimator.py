@@ -1,0 +1,211 @@
+"""CPU oracle: 3-D box solvers (TEST INFRASTRUCTURE ONLY).
+
+Restates lib/model/utils/box_estimator.py of the reference:
+  BB2Viewpoint :15-41, viewpoint2vertex :43-124, kpt2vertex :126-148, kpt2alpha :150-167,
+  solve_x_y_z_theta_from_kpt :169-385 (4-DoF), solve_x_y_theta_from_kpt :387-545 (3-DoF).
+Both minimise a sum of squared re-projection residuals with scipy's Newton-CG and an analytic
+gradient, exactly as the reference does (`minimize(..., method='Newton-CG', jac=...)`, :381,:544).
+
+The residuals and gradient are written here as a residual vector r(x) and its Jacobian, so the
+reference's cost is r.r and its gradient 2 J^T r -- with ONE deliberate exception that reproduces a
+quirk of the reference: the keypoint residual is doubled (:264) but its hand-written gradient
+(:311-316) lacks the matching factor 2, i.e. the reference's gradient weights that term by 1/2.
+`kpt_grad_weight=0.5` keeps the quirk (default); the stationary point scipy converges to is the one
+the quirk defines.
+Parity status: unpinned by the reference (no tests upstream); scipy version here is 1.15.
+"""
+import math
+
+import numpy as np
+from scipy.optimize import minimize
+
+TRUNCATE_BORDER = 10
+
+
+def bb2viewpoint(alpha):
+    """:15-41 - continuous viewpoint angle -> one of 8 discrete viewpoints (-1 if none)."""
+    a = alpha * 180.0 / math.pi
+    if a > 360:
+        a -= 360
+    elif a < -360:
+        a += 360
+    t = 4.0
+    if -90.0 - t <= a <= -90.0 + t:
+        return 0
+    if -180.0 + t <= a <= -90.0 - t:
+        return 1
+    if a >= 180.0 - t or a <= -180.0 + t:
+        return 2
+    if 90.0 + t <= a <= 180.0 - t:
+        return 3
+    if 90.0 - t <= a <= 90.0 + t:
+        return 4
+    if 0.0 + t <= a <= 90.0 - t:
+        return 5
+    if 0.0 - t <= a <= 0.0 + t:
+        return 6
+    if -90.0 + t <= a <= 0.0 - t:
+        return 7
+    return -1
+
+
+# (left, right, bottom) vertex signs (x = +-w/2, z = +-l/2) per viewpoint, :92-122 (the else branch is 7 and -1)
+_VIEW_VERTS = {
+    0: ((-1, -1), (1, -1), (1, -1)), 1: ((-1, 1), (1, -1), (-1, -1)), 2: ((-1, 1), (-1, -1), (-1, -1)),
+    3: ((1, 1), (-1, -1), (-1, 1)), 4: ((1, 1), (-1, 1), (-1, 1)), 5: ((1, -1), (-1, 1), (1, 1)),
+    6: ((1, -1), (1, 1), (1, 1)), 7: ((-1, -1), (1, 1), (1, -1)),
+}
+_KPT_VERTS = {0: (-1, -1), 1: (-1, 1), 2: (1, 1), 3: (1, -1)}        # :138-146
+
+
+def viewpoint_vertices(view_point, w, l):
+    v = _VIEW_VERTS.get(view_point, _VIEW_VERTS[7])
+    return [(sx * w / 2.0, sz * l / 2.0) for sx, sz in v]
+
+
+def kpt2alpha(kpt_pos, kpt_type, box):
+    """:150-167."""
+    r = max(min(1, (kpt_pos - box[0]) / (box[2] - box[0])), -1)
+    base = {0: -math.pi / 2, 1: math.pi, 2: math.pi / 2, 3: 0.0}[kpt_type]
+    return base - math.asin(r)
+
+
+class _Problem(object):
+    """Shared set-up of both solvers: normalised observations, vertex choice, residual masks."""
+
+    def __init__(self, im_shape, calib, alpha, dim, box_left, box_right, kpts, use_right):
+        self.h_max, self.w_max = im_shape[0], im_shape[1]
+        self.w, self.h, self.l = float(dim[0]), float(dim[1]), float(dim[2])
+        ul, ur, vt, vb = [float(box_left[i]) for i in (0, 2, 1, 3)]
+        self.f = calib.p2[0, 0]
+        cx, cy = calib.p2[0, 2], calib.p2[1, 2]
+        self.bl = (calib.p2[0, 3] - calib.p3[0, 3]) / self.f
+        kpt_pos, kpt_type = float(kpts[0]), int(kpts[1])
+        self.left_u, self.right_u = (ul - cx) / self.f, (ur - cx) / self.f
+        self.top_v, self.bottom_v = (vt - cy) / self.f, (vb - cy) / self.f
+        self.kpt_u = (kpt_pos - cx) / self.f
+        self.trunc = ul < 2.0 * TRUNCATE_BORDER or ur > self.w_max - 2.0 * TRUNCATE_BORDER
+        if not self.trunc:
+            alpha = kpt2alpha(kpt_pos, kpt_type, box_left)
+        self.alpha = alpha
+        (self.lw, self.ll), (self.rw, self.rl), (self.bw, self.bll) = viewpoint_vertices(bb2viewpoint(alpha), self.w, self.l)
+        ks = _KPT_VERTS[kpt_type]
+        self.kw, self.kl = ks[0] * self.w / 2.0, ks[1] * self.l / 2.0
+        # which residuals are active (:254-276 / :464-480)
+        self.on = {'ul': ul >= 2.0 * TRUNCATE_BORDER, 'ur': ur <= self.w_max - 2.0 * TRUNCATE_BORDER,
+                   'uk': not self.trunc, 'vb': vb <= self.h_max - TRUNCATE_BORDER, 'vt': vt >= TRUNCATE_BORDER,
+                   'alpha': self.trunc, 'ul_r': False, 'ur_r': False}
+        if use_right:
+            ul_r, ur_r = float(box_right[0]), float(box_right[2])
+            self.left_u_r, self.right_u_r = (ul_r - cx) / self.f, (ur_r - cx) / self.f
+            self.on['ul_r'] = self.trunc and ul_r >= 2.0 * TRUNCATE_BORDER
+            self.on['ur_r'] = self.trunc and ur_r <= self.w_max - 2.0 * TRUNCATE_BORDER
+
+    def residuals(self, x, y, z, th, with_jac):
+        """-> list of (name, r, dr/dx, dr/dy, dr/dz, dr/dth) for the ACTIVE residuals."""
+        c, s = math.cos(th), math.sin(th)
+        out = []
+
+        def u_term(name, vw, vl, obs, shift, scale):
+            num = x - shift + c * vw + s * vl
+            den = z - s * vw + c * vl
+            r = scale * (num / den - obs)
+            if not with_jac:
+                return out.append((name, r))
+            dnum = -s * vw + c * vl          # d num / d theta
+            dden = -c * vw - s * vl          # d den / d theta
+            out.append((name, r, scale / den, 0.0, -scale * num / den ** 2, scale * (dnum / den - num * dden / den ** 2)))
+
+        if self.on['ul']:
+            u_term('ul', self.lw, self.ll, self.left_u, 0.0, 1.0)
+        if self.on['ur']:
+            u_term('ur', self.rw, self.rl, self.right_u, 0.0, 1.0)
+        if self.on['uk']:
+            u_term('uk', self.kw, self.kl, self.kpt_u, 0.0, 2.0)        # res_uk = 2*res_uk (:264)
+        if self.on['vb']:
+            den = z - s * self.bw + c * self.bll
+            r = y / den - self.bottom_v
+            dden = -c * self.bw - s * self.bll
+            out.append(('vb', r, 0.0, 1.0 / den, -y / den ** 2, -y * dden / den ** 2) if with_jac else ('vb', r))
+        if self.on['vt']:
+            den = z + s * self.bw - c * self.bll
+            r = (y - self.h) / den - self.top_v
+            dden = c * self.bw + s * self.bll
+            out.append(('vt', r, 0.0, 1.0 / den, -(y - self.h) / den ** 2, -(y - self.h) * dden / den ** 2)
+                       if with_jac else ('vt', r))
+        if self.on['ul_r']:
+            u_term('ul_r', self.lw, self.ll, self.left_u_r, self.bl, 1.0)
+        if self.on['ur_r']:
+            u_term('ur_r', self.rw, self.rl, self.right_u_r, self.bl, 1.0)
+        if self.on['alpha']:
+            r = th - math.pi / 2 + math.atan2(-x, z) - self.alpha
+            q = 1.0 + (-x / z) ** 2
+            out.append(('alpha', r, (-1.0 / z) / q, 0.0, (x / (z * z)) / q, 1.0) if with_jac else ('alpha', r))
+        return out
+
+
+def _cost_and_grad(prob, kpt_grad_weight):
+    def cost(x, y, z, th):
+        return sum(t[1] ** 2 for t in prob.residuals(x, y, z, th, False))
+
+    def grad(x, y, z, th):
+        g = np.zeros(4)
+        for t in prob.residuals(x, y, z, th, True):
+            wgt = kpt_grad_weight if t[0] == 'uk' else 1.0    # the reference's gradient quirk (:311-316)
+            g += 2.0 * wgt * t[1] * np.array(t[2:6])
+        return g
+    return cost, grad
+
+
+def solve_x_y_z_theta_from_kpt(im_shape, calib, alpha, dim, box_left, box_right, kpts, kpt_grad_weight=0.5):
+    """4-DoF initial 3-D box (:169-385).  Returns (status, state[x,y,z,theta])."""
+    if kpts[4] - kpts[3] < 3 or box_left[2] - box_left[0] < 10 or box_left[3] - box_left[1] < 10:
+        return 0, 0
+    p = _Problem(im_shape, calib, alpha, dim, box_left, box_right, kpts, True)
+    cost, grad = _cost_and_grad(p, kpt_grad_weight)
+    disparity = (box_left[0] + box_left[2]) / 2 - (box_right[0] + box_right[2]) / 2
+    z0 = p.f * p.bl / disparity
+    x0 = z0 * (p.left_u + p.right_u) / 2.0
+    y0 = z0 * (p.bottom_v + p.top_v) / 2.0 + p.h / 2.0
+    th0 = p.alpha + math.pi / 2 - math.atan2(-x0, z0)
+    res = minimize(lambda s: cost(*s), [x0, y0, z0, th0], method='Newton-CG', jac=lambda s: grad(*s),
+                   options={'disp': False})
+    if res.x[2] > 100:
+        return 0, res.x
+    return 1, res.x
+
+
+def solve_x_y_theta_from_kpt(im_shape, calib, alpha, dim, box_left, disparity, kpts, kpt_grad_weight=0.5):
+    """3-DoF rectification with z fixed by the aligned disparity (:387-545).  Returns (state[x,y,theta], z)."""
+    p = _Problem(im_shape, calib, alpha, dim, box_left, None, kpts, False)
+    z = p.f * p.bl / float(disparity)
+    cost, grad = _cost_and_grad(p, kpt_grad_weight)
+    x0 = z * (p.left_u + p.right_u) / 2.0
+    y0 = z * (p.bottom_v + p.top_v) / 2.0 + p.h / 2.0
+    th0 = p.alpha + math.pi / 2 - math.atan2(-x0, z)
+    res = minimize(lambda s: cost(s[0], s[1], z, s[2]), [x0, y0, th0], method='Newton-CG',
+                   jac=lambda s: grad(s[0], s[1], z, s[2])[[0, 1, 3]], options={'disp': False})
+    return res.x, z
+
+
+def project_observations(calib, pose, dim, kpt_type=None):
+    """Synthetic observations (left/right box, keypoint) of a 3-D box pose = (x, y, z, theta) - test helper."""
+    x, y, z, th = pose
+    w, h, l = dim
+    c, s = math.cos(th), math.sin(th)
+    f, cx, cy = calib.p2[0, 0], calib.p2[0, 2], calib.p2[1, 2]
+    bl = (calib.p2[0, 3] - calib.p3[0, 3]) / f
+    us, us_r, vs = [], [], []
+    corners = {}
+    for sx in (-1, 1):
+        for sz in (-1, 1):
+            X = x + c * sx * w / 2 + s * sz * l / 2
+            Z = z - s * sx * w / 2 + c * sz * l / 2
+            corners[(sx, sz)] = (X, Z)
+            for Y in (y, y - h):
+                us.append(f * X / Z + cx)
+                us_r.append(f * (X - bl) / Z + cx)
+                vs.append(f * Y / Z + cy)
+    box_l = [min(us), min(vs), max(us), max(vs)]
+    box_r = [min(us_r), min(vs), max(us_r), max(vs)]
+    return box_l, box_r, corners

@@ -1,0 +1,56 @@
+"""End-to-end flow (demo.py:137-326): HIP pipeline vs the CPU oracle pipeline on the same pair.
+The 4-DoF scipy solve is chaotic in depth (see model/utils/box_estimator.py), so the comparison is per matched
+object and statistical: same detections, same solver status, aligned disparities equal up to one fine depth
+step, rectified 3-D boxes close for most objects."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_detect_3d_matches_oracle_pipeline(dev):
+    from oracle import pipeline as opipe
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
+    sd = fixture.make_state_dict(3)
+    m = resnet(('__background__', 'Car'), 101)
+    m.create_architecture()
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    l, r, info = fixture.make_inputs(3, 200, 660, target_short=320)
+    im_shape = (200, 660, 3)
+    got = pipeline.detect_3d(m, l.to(dev), r.to(dev), info.to(dev), calib, im_shape)
+    ref = opipe.detect_3d(sd, l, r, info, calib, im_shape)
+    assert len(ref) > 0 and abs(len(got) - len(ref)) <= max(2, len(ref) // 10)
+    matched, dz, dxy, ddis = 0, [], [], []
+    for o in ref:
+        best = min(got, key=lambda g: np.abs(g['box_left'] - o['box_left']).max())
+        if np.abs(best['box_left'] - o['box_left']).max() > 0.05:
+            continue
+        matched += 1
+        assert abs(best['score'] - o['score']) < 1e-4 and np.abs(best['dim'] - o['dim']).max() < 1e-3
+        if best['aligned'] and o['aligned']:
+            ddis.append(abs(best['disparity'] - o['disparity']))
+            dz.append(abs(best['xyz'][2] - o['xyz'][2]) / max(1.0, abs(o['xyz'][2])))
+            dxy.append(np.abs(best['xyz'][:2] - o['xyz'][:2]).max())
+    assert matched >= 0.9 * len(ref)
+    if ddis:
+        print('aligned objects %d: median |d disparity| %.3g px, median rel dz %.3g, median dxy %.3g m'
+              % (len(ddis), np.median(ddis), np.median(dz), np.median(dxy)))
+        assert np.median(ddis) < 0.05 and np.median(dz) < 0.01
+
+
+def test_write_kitti_results(dev, tmp_path):
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import pipeline
+    from stereo_rcnn_amd.model.utils import kitti_utils
+    c = kitti_utils.FrameCalibrationData()
+    c.p2, c.p3 = calib.p2, calib.p3
+    c.t_cam2_cam0 = np.array([0.06, 0, 0])
+    objs = [{'box_left': np.array([1., 2, 3, 4]), 'xyz': np.array([1., 1.5, 20]), 'dim': np.array([1.6, 1.5, 4.0]),
+             'theta': 0.2, 'score': 0.8}]
+    pipeline.write_kitti_results(str(tmp_path), '000001', c, objs)
+    assert (tmp_path / 'data' / '000001.txt').read_text().startswith('Car -1 -1 ')

@@ -1,0 +1,135 @@
+"""CPU: the host-side rows of the path (A13 infer_boundary, A14/A17 3-D solvers, KITTI I/O):
+product implementation vs the oracle's independent restatement."""
+import math
+import os
+
+import numpy as np
+
+from oracle import box_estimator as obe
+from oracle import pipeline as opipe
+from oracle.dense_align import KITTI_DEMO_CALIB
+from stereo_rcnn_amd.model.utils import box_estimator as pbe
+from stereo_rcnn_amd.model.utils import kitti_utils
+
+IM_SHAPE = (375, 1242, 3)
+
+
+def _case(rng):
+    calib = KITTI_DEMO_CALIB
+    z = rng.uniform(8, 40); x = rng.uniform(-0.55, 0.55) * z; y = rng.uniform(1.4, 1.8); th = rng.uniform(-math.pi, math.pi)
+    dim = (1.6 * rng.uniform(0.9, 1.1), 1.5 * rng.uniform(0.9, 1.1), 4.0 * rng.uniform(0.9, 1.1))
+    bl, br, corners = obe.project_observations(calib, (x, y, z, th), dim)
+    types = {(-1, -1): 0, (-1, 1): 1, (1, 1): 2, (1, -1): 3}
+    k = min(corners, key=lambda c: corners[c][1])
+    ku = calib.p2[0, 0] * corners[k][0] / corners[k][1] + calib.p2[0, 2]
+    clip = lambda b: [max(0, min(1241, b[0])), max(0, b[1]), max(0, min(1241, b[2])), min(374, b[3])]
+    bl, br = clip(bl), clip(br)
+    kp = [ku, float(types[k]), 0.9, bl[0], bl[2]]
+    alpha = th - math.pi / 2 + math.atan2(-x, z)
+    return calib, (x, y, z, th), dim, bl, br, kp, alpha
+
+
+def test_cost_and_reference_gradient_agree_to_rounding():
+    """The well-defined parity for this row: cost and the reference's (quirky) gradient, evaluated at the
+    same points by the two independent restatements, agree to the last bits."""
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        calib, pose, dim, bl, br, kp, alpha = _case(rng)
+        p = obe._Problem(IM_SHAPE, calib, alpha, dim, bl, br, kp, True)
+        cost, grad = obe._cost_and_grad(p, 0.5)
+        t = pbe._Terms(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+        pt = np.array(pose) + rng.normal(0, [0.3, 0.05, 1.0, 0.05])
+        c2, g2 = t.evaluate(pt[0], pt[1], pt[2], pt[3], True)
+        assert abs(cost(*pt) - c2) < 1e-12 * max(1.0, c2)
+        assert np.abs(grad(*pt) - g2).max() < 1e-12
+        assert p.trunc == t.truncation and abs(p.alpha - t.alpha) < 1e-15
+
+
+def test_keypoint_gradient_quirk_is_reproduced():
+    """box_estimator.py:264 doubles the keypoint residual but :311-316 differentiate it without the 2."""
+    rng = np.random.default_rng(2)
+    calib, pose, dim, bl, br, kp, alpha = _case(rng)
+    while obe._Problem(IM_SHAPE, calib, alpha, dim, bl, br, kp, True).trunc:
+        calib, pose, dim, bl, br, kp, alpha = _case(rng)
+    t = pbe._Terms(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+    pt = np.array(pose) + 0.1
+    g = t.evaluate(*pt, True)[1]
+    eps = 1e-6
+    num = np.array([(t.evaluate(*(pt + eps * np.eye(4)[i]), False)[0] - t.evaluate(*(pt - eps * np.eye(4)[i]), False)[0]) / (2 * eps)
+                    for i in range(4)])
+    assert np.abs(g - num).max() > 1e-6          # NOT the true gradient ...
+    t.active['uk'] = False                       # ... but exact once the keypoint term is removed
+    g2 = t.evaluate(*pt, True)[1]
+    num2 = np.array([(t.evaluate(*(pt + eps * np.eye(4)[i]), False)[0] - t.evaluate(*(pt - eps * np.eye(4)[i]), False)[0]) / (2 * eps)
+                     for i in range(4)])
+    assert np.abs(g2 - num2).max() < 1e-6
+
+
+def test_solvers_recover_pose_and_agree_statistically():
+    """scipy's Newton-CG stops where its line search gives up (see box_estimator.py docstring): end points of
+    two bit-different but equivalent evaluations scatter, so agreement is statistical, not pointwise."""
+    rng = np.random.default_rng(3)
+    d4, d3, err = [], [], []
+    for _ in range(40):
+        calib, pose, dim, bl, br, kp, alpha = _case(rng)
+        s1, a = obe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+        s2, b = pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+        assert s1 == s2
+        if not s1:
+            continue
+        d4.append(np.abs(np.array(a) - np.array(b)).max())
+        err.append(abs(b[2] - pose[2]) / pose[2])
+        disp = calib.p2[0, 0] * ((calib.p2[0, 3] - calib.p3[0, 3]) / calib.p2[0, 0]) / pose[2]
+        r1, z1 = obe.solve_x_y_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, disp, kp)
+        r2, z2 = pbe.solve_x_y_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, disp, kp)
+        assert z1 == z2
+        d3.append(np.abs(r1 - r2).max())
+    assert np.median(d3) < 1e-4 and np.median(d4) < 5e-3
+    assert np.median(err) < 0.02                 # depth recovered to ~2 % on clean synthetic observations
+
+
+def test_early_outs():
+    calib = KITTI_DEMO_CALIB
+    assert pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, 0.0, (1.6, 1.5, 4.0), [100, 100, 105, 160], [90, 100, 95, 160],
+                                          [102, 0, 1, 100, 105]) == (0, 0)          # box narrower than 10 px
+    assert pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, 0.0, (1.6, 1.5, 4.0), [100, 100, 200, 160], [90, 100, 190, 160],
+                                          [150, 0, 1, 150, 152]) == (0, 0)          # borders closer than 3 px
+    for a in (-3.2, -1.6, -0.7, 0.0, 0.8, 1.57, 2.4, 3.1):
+        assert pbe.BB2Viewpoint(a) == obe.bb2viewpoint(a)
+
+
+def test_infer_boundary_matches_oracle():
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        n = rng.integers(1, 9)
+        x1 = rng.uniform(0, 1100, n); w = rng.uniform(20, 300, n); y2 = rng.uniform(150, 374, n)
+        boxes = np.stack([x1, y2 - rng.uniform(20, 120, n), np.minimum(x1 + w, 1241), y2, rng.uniform(0, 1, n)], 1).astype(np.float32)
+        a = kitti_utils.infer_boundary(IM_SHAPE, boxes)
+        b = opipe.infer_boundary(IM_SHAPE, boxes)
+        assert np.array_equal(a, b)
+    # an occluder in front hides the right part of the farther box
+    boxes = np.array([[100, 100, 300, 200, 0.9], [250, 100, 500, 300, 0.8]], np.float32)
+    lr = kitti_utils.infer_boundary(IM_SHAPE, boxes)
+    assert lr[0, 0] == 100 and lr[0, 1] < 300 and lr[1, 0] == 250 and lr[1, 1] == 500
+
+
+def test_calibration_reader_and_result_writer(tmp_path):
+    calib_txt = tmp_path / 'calib.txt'
+    rows = {'P0': [721.5377, 0, 609.5593, 0, 0, 721.5377, 172.854, 0, 0, 0, 1, 0],
+            'P1': [721.5377, 0, 609.5593, -387.5744, 0, 721.5377, 172.854, 0, 0, 0, 1, 0],
+            'P2': [721.5377, 0, 609.5593, 44.85728, 0, 721.5377, 172.854, 0.2163791, 0, 0, 1, 0.002745884],
+            'P3': [721.5377, 0, 609.5593, -339.5242, 0, 721.5377, 172.854, 2.199936, 0, 0, 1, 0.002729905],
+            'R0_rect': [1, 0, 0, 0, 1, 0, 0, 0, 1], 'Tr_velo_to_cam': list(range(12)), 'Tr_imu_to_velo': list(range(12))}
+    calib_txt.write_text('\n'.join('%s: %s' % (k, ' '.join('%.12e' % v for v in vals)) for k, vals in rows.items()) + '\n')
+    c = kitti_utils.read_obj_calibration(str(calib_txt))
+    assert c.p2.shape == (3, 4) and abs(c.p2[0, 3] - 44.85728) < 1e-9 and abs(c.p3[0, 3] + 339.5242) < 1e-9
+    assert abs(c.t_cam2_cam0[0] - 44.85728 / 721.5377) < 1e-12 and c.p2_3[0, 3] == c.p3[0, 3] - c.p2[0, 3]
+    assert np.allclose(c.p2, KITTI_DEMO_CALIB.p2) and np.allclose(c.p3, KITTI_DEMO_CALIB.p3)
+    kitti_utils.write_detection_results(str(tmp_path / 'res'), '000012', c, [10, 20, 110, 90], [1.0, 1.6, 20.0],
+                                        [1.6, 1.5, 4.0], 0.3, 0.91)
+    line = (tmp_path / 'res' / 'data' / '000012.txt').read_text().split()
+    assert line[0] == 'Car' and len(line) == 16
+    assert abs(float(line[11]) - (1.0 - c.t_cam2_cam0[0])) < 1e-5          # cam2 -> cam0 shift on x
+    assert abs(float(line[14]) - (0.3 - 1.57)) < 1e-5 and abs(float(line[15]) - 0.91) < 1e-6
+    assert abs(float(line[3]) - (0.3 - math.pi / 2 + math.atan2(-1.0, 20.0))) < 1e-5
+    kitti_utils.write_detection_results(None, 'x', c, [0] * 4, [0, 0, 1], [1, 1, 1], 0, 0)    # result_dir None: no-op
