@@ -130,6 +130,11 @@ typedef struct srcnn_conv_desc {
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
 
+/* A0 preprocessing (demo.py:103-129, blob.py:39-64): uint8 RGB (H,W,3) on the device -> float32 (3,OH,OW)
+ * BGR planes, PIXEL_MEANS subtracted, bilinear-resized by `scale` (OpenCV INTER_LINEAR geometry).
+ * OH/OW as cv2.resize computes them: round(H*scale), round(W*scale). */
+SRCNN_API int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, float scale, float *out_nchw, int OH, int OW,
+                     srcnn_stream_t stream);
 /* stem input repack: NCHW (B,3,H,W) -> zero-bordered NHWC4 (B, H+6, W+8, 4) so that the 7x7/2
  * stem (resnet.py:109) becomes 7 taps of 32 contiguous floats for the conv engine. */
 SRCNN_API int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, srcnn_stream_t stream);

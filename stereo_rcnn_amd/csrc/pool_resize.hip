@@ -114,6 +114,37 @@ __global__ void act_convert_kernel(const void *__restrict__ x, int xfmt, void *_
     }
 }
 
+// A0 (demo.py:103-129, blob.py:39-64): uint8 RGB (H, W, 3) -> float32 BGR planes, minus PIXEL_MEANS,
+// bilinear resize by `scale` with OpenCV INTER_LINEAR geometry (half-pixel centres, source = (dst+0.5)/scale-0.5,
+// border replicate).  Mean subtraction happens BEFORE the resize, as in the reference.
+__global__ void preprocess_kernel(const unsigned char *__restrict__ img, int H, int W, float *__restrict__ out, int OH,
+                                  int OW, float inv_scale, float m0, float m1, float m2)
+{
+    const size_t total = (size_t)OH * OW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % OW), oy = (int)(idx / OW);
+        // ATen upsample_bilinear2d(align_corners=False, given scale): src = scale*(dst+0.5)-0.5, clamped at 0
+        float sy = inv_scale * ((float)oy + 0.5f) - 0.5f;
+        float sx = inv_scale * ((float)ox + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const unsigned char *p00 = img + ((size_t)y0 * W + x0) * 3, *p01 = img + ((size_t)y0 * W + x1) * 3;
+        const unsigned char *p10 = img + ((size_t)y1 * W + x0) * 3, *p11 = img + ((size_t)y1 * W + x1) * 3;
+        const float mean[3] = {m0, m1, m2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {      // output channel c = B,G,R  <-  input channel 2-c
+            const int ic = 2 - c;
+            const float a = (float)p00[ic] - mean[c], b = (float)p01[ic] - mean[c];
+            const float cc = (float)p10[ic] - mean[c], d = (float)p11[ic] - mean[c];
+            out[(size_t)c * total + idx] = hy * (hx * a + lx * b) + ly * (hx * cc + lx * d);
+        }
+    }
+}
+
 __global__ void subsample2_kernel(const float4 *__restrict__ x, int B, int H, int W, int C4, float4 *__restrict__ y,
                                   int OH, int OW)
 {
@@ -201,6 +232,18 @@ int srcnn_act_convert(const void *x, int x_format, void *y, int y_format, long l
     hipLaunchKernelGGL(act_convert_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, x_format, y,
                        y_format, (size_t)pixels, C);
     return check_launch("srcnn_act_convert");
+}
+
+int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, float scale, float *out_nchw, int OH, int OW,
+                     srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(img_rgb && out_nchw && H > 0 && W > 0 && OH > 0 && OW > 0 && scale > 0.f, "bad args");
+    // PIXEL_MEANS (config.py:170), BGR, narrowed to float32 after the float32-minus-float64 subtraction of the reference
+    const size_t total = (size_t)OH * OW;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), img_rgb, H, W,
+                       out_nchw, OH, OW, 1.0f / scale, 102.9801f, 115.9465f, 122.7717f);
+    return check_launch("srcnn_preprocess");
 }
 
 int srcnn_subsample2(const float *x, int B, int H, int W, int C, float *y, int OH, int OW, srcnn_stream_t stream)

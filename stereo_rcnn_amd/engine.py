@@ -192,6 +192,22 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")
 
 
+def preprocess(img_rgb_u8, target_short=600, max_size=2484):
+    """A0 on the device: uint8 RGB (H, W, 3) device tensor -> (1, 3, OH, OW) float32 network input and im_scale
+    (demo.py:103-129: RGB->BGR, -PIXEL_MEANS, bilinear resize so that the short side is `target_short`)."""
+    assert img_rgb_u8.is_cuda and img_rgb_u8.dtype == torch.uint8 and img_rgb_u8.dim() == 3
+    img = img_rgb_u8.contiguous()
+    H, W = int(img.shape[0]), int(img.shape[1])
+    scale = float(target_short) / float(min(H, W))
+    OH, OW = int(H * scale), int(W * scale)          # floor, == cv2's round for the KITTI sizes; see tests
+    out = torch.empty((1, 3, OH, OW), dtype=torch.float32, device=img.device)
+    _lib.check(_lib.lib().srcnn_preprocess(img.data_ptr(), H, W, scale, out.data_ptr(), OH, OW, _lib.stream()),
+               "srcnn_preprocess")
+    if OW > max_size:
+        out = out[:, :, :, :max_size].contiguous()
+    return out, scale
+
+
 def stem_pack(im_nchw, out, batch_offset=0):
     B, C, H, W = im_nchw.shape
     assert C == 3

@@ -274,3 +274,30 @@ def test_f16x3_engine_full_size_vs_golden(dev):
                                    ref_out, 0.90)
     print('f16x3 full-size: worst feature rel err %.2e, matched proposals %.3f, head errs %s' % (worst, frac, errs))
     assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4
+
+
+def test_batch_of_two_pairs(dev):
+    """BASELINE configs[2] shape of the forward: B > 1 (rois carry the batch index, proposal_layer.py:139;
+    ROIAlign reads it, roi_align_kernel.cu:33,51).  Two different pairs in one batch == the oracle on the batch."""
+    from oracle import net as onet
+    from stereo_rcnn_amd import fixture
+    m, sd = _build_model(dev)
+    a = fixture.make_inputs(3, 120, 400, target_short=192)
+    b = fixture.make_inputs(4, 120, 400, target_short=192)
+    l = torch.cat((a[0], b[0]), 0); r = torch.cat((a[1], b[1]), 0); info = torch.cat((a[2], b[2]), 0)
+    ref = onet.forward(sd, l, r, info)
+    for precision in ('f32', 'f16x3'):
+        m.precision = precision
+        with torch.no_grad():
+            out = m(l.to(dev), r.to(dev), info.to(dev))
+        torch.cuda.synchronize()
+        assert out[0].shape == (2, 300, 5) and out[3].shape == (2, 300, 12) and out[5].shape == (600, 112)
+        for img in range(2):
+            assert float(out[0][img, :, 0].min()) == img and float(out[0][img, :, 0].max()) == img
+            ro = {k: (v[img:img + 1] if v.dim() == 3 else v[img * 300:(img + 1) * 300]) for k, v in ref.items()
+                  if torch.is_tensor(v)}
+            o_img = [out[0][img:img + 1], out[1][img:img + 1], out[2][img:img + 1], out[3][img:img + 1],
+                     out[4][img:img + 1], out[5][img * 300:(img + 1) * 300], out[6][img * 300:(img + 1) * 300],
+                     out[7][img * 300:(img + 1) * 300]]
+            frac, errs = _check_end_to_end(o_img, ro['rois_left'][0], ro['rois_right'][0], ro, 0.95)
+            assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (precision, img, errs)

@@ -279,3 +279,14 @@ def test_proposal_layer_ties_and_selection(dev, pre_nms, quant):
     assert int(layer.last_num_valid[0]) == min(120, len(extra['keep'][0]))
     assert float((rl.cpu() - rl_ref).abs().max()) < 2e-3
     assert float((rr.cpu() - rr_ref).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("hw,short", [((375, 1242), 600), ((120, 400), 192), ((370, 1224), 600)])
+def test_preprocess_kernel_vs_host(dev, hw, short):
+    """A0: device preprocessing == the host restatement (fixture.preprocess: torch bilinear, align_corners=False)."""
+    from stereo_rcnn_amd import engine, fixture
+    l, _ = fixture.synthetic_pair(7, hw[0], hw[1])
+    ref, s_ref = fixture.preprocess(l, short)
+    got, s = engine.preprocess(torch.from_numpy(l).to(dev), short)
+    assert s == s_ref and tuple(got.shape) == tuple(ref.shape)
+    assert float((got.cpu() - ref).abs().max()) < 2e-4      # values are up to 150; float32 interpolation rounding
