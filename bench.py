@@ -74,7 +74,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
+    use_dist = 'RANK' in os.environ          # launched by torch.distributed.run (any world size, incl. 1)
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl')
@@ -96,13 +97,13 @@ def main():
     model.precision = args.precision
     # every rank works on its own synthetic pair (weak scaling: per-GPU work is fixed)
     im_l, im_r, im_info = [t.to(dev) for t in fixture.make_inputs(3 + rank, args.height, args.width)]
-    gather_stream = torch.cuda.Stream() if world > 1 else None
+    gather_stream = torch.cuda.Stream() if use_dist else None
 
     def step():
         out = model(im_l, im_r, im_info)
         det = hpost.decode_detections(out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], im_info)
         keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
-        if world > 1:
+        if use_dist:
             rec = sdist.pack_records_device(det, keep_idx, num, 1)
             gather_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(gather_stream):      # xGMI gather overlaps the next pair's trunk
@@ -114,19 +115,19 @@ def main():
         for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el[0])
 
@@ -183,7 +184,7 @@ def main():
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(3, args.height, args.width)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

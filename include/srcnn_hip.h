@@ -188,6 +188,13 @@ SRCNN_API int srcnn_class_nms(const float *scores, int n, int n_cls, int j, cons
                     float score_thresh, float nms_thresh, int *keep_idx, int *num_keep,
                     void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
 
+/* fixed-size, zero-padded detection record of one image for the multi-GPU gather (new: the reference writes
+ * per-image txt files instead, kitti_utils.py:456-460): rec ((n+1), rec_cols>=20) float32, row 0 = [count],
+ * row 1+r = [score, left box 4, right box 4, dim_orien 5, kpts 5, roi index] of the r-th kept detection. */
+SRCNN_API int srcnn_pack_detections(const float *scores, const float *boxes_left, const float *boxes_right,
+                          const float *dim_orien, const float *kpts, const int *keep_idx, const int *num_keep,
+                          int n, int n_cls, int j, int rec_cols, float *rec, srcnn_stream_t stream);
+
 /* ------------------------------------------------------------ dense alignment (A15-A16)
  * Replaces lib/model/dense_align/dense_align.py:13-69,175-300 + box_3d.py:12-106 (align_parallel).
  * im_left/right: (3, H, W) planar float32 network-input tensors; the 2x align_corners bilinear

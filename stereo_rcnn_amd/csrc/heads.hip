@@ -194,6 +194,34 @@ __global__ void map_keep_kernel(const int *__restrict__ keep, const int *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) *num_keep = k;
 }
 
+// fixed-size detection record for the multi-GPU gather: row 0 = [count, 0...], row 1+r = r-th kept detection
+// [score, left box 4, right box 4, dim_orien 5, kpts 5, roi index, 0 0 0 0]; rows past the count are zero.
+__global__ void pack_detections_kernel(const float *__restrict__ scores, const float *__restrict__ boxes_l,
+                                       const float *__restrict__ boxes_r, const float *__restrict__ dim_orien,
+                                       const float *__restrict__ kpts, const int *__restrict__ keep_idx,
+                                       const int *__restrict__ num, int n, int ncls, int j, int cols,
+                                       float *__restrict__ rec)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;     // record row, 0..n
+    if (r > n) return;
+    float *o = rec + (size_t)r * cols;
+    for (int c = 0; c < cols; ++c) o[c] = 0.f;
+    const int k = *num;
+    if (r == 0) { o[0] = (float)k; return; }
+    if (r - 1 >= k) return;
+    const int i = keep_idx[r - 1];
+    o[0] = scores[(size_t)i * ncls + j];
+    for (int c = 0; c < 4; ++c) {
+        o[1 + c] = boxes_l[((size_t)i * ncls + j) * 4 + c];
+        o[5 + c] = boxes_r[((size_t)i * ncls + j) * 4 + c];
+    }
+    for (int c = 0; c < 5; ++c) {
+        o[9 + c] = dim_orien[((size_t)i * ncls + j) * 5 + c];
+        o[14 + c] = kpts[(size_t)i * 5 + c];
+    }
+    o[19] = (float)i;
+}
+
 struct ClassNmsLayout {
     size_t sorted_idx, dets, keep, num, count, nms, total;
 };
@@ -252,6 +280,18 @@ int srcnn_decode_detections(const float *rois_left, const float *rois_right, con
                        rois_right, bbox_pred, dim_orien_pred, kpts_prob, left_prob, right_prob, im_info, n, n_cls, G,
                        boxes_left, boxes_right, dim_orien, kpts);
     return check_launch("srcnn_decode_detections");
+}
+
+int srcnn_pack_detections(const float *scores, const float *boxes_left, const float *boxes_right,
+                          const float *dim_orien, const float *kpts, const int *keep_idx, const int *num_keep, int n,
+                          int n_cls, int j, int rec_cols, float *rec, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(scores && boxes_left && boxes_right && dim_orien && kpts && keep_idx && num_keep && rec, "null pointer");
+    SRCNN_REQUIRE(rec_cols >= 20 && n > 0 && j >= 0 && j < n_cls, "bad sizes (rec_cols >= 20)");
+    hipLaunchKernelGGL(pack_detections_kernel, dim3(cdiv(n + 1, 128)), dim3(128), 0, as_stream(stream), scores,
+                       boxes_left, boxes_right, dim_orien, kpts, keep_idx, num_keep, n, n_cls, j, rec_cols, rec);
+    return check_launch("srcnn_pack_detections");
 }
 
 size_t srcnn_class_nms_workspace_bytes(int n) { return srcnn::class_nms_layout(n > 0 ? n : 1).total; }

@@ -36,10 +36,21 @@ def pack_records(cls_det, max_det=300):
 
 
 def pack_records_device(det, keep_idx, num, j=1):
-    """Same record, built on the device from the -1 padded keep list with no host sync
-    (det: postprocess.decode_detections; keep_idx/num: postprocess.class_nms_device)."""
+    """Same record, built on the device by one native launch from the -1 padded keep list, no host sync
+    (det: postprocess.decode_detections; keep_idx/num: postprocess.class_nms_device).  CPU tensors (the gloo
+    tests) take an equivalent torch path."""
     n = int(keep_idx.shape[0])
     dev = keep_idx.device
+    if keep_idx.is_cuda:
+        from . import _lib
+        rec = torch.empty((n + 1, REC_COLS), dtype=torch.float32, device=dev)
+        n_cls = int(det['scores'].shape[1])
+        _lib.check(_lib.lib().srcnn_pack_detections(det['scores'].data_ptr(), det['boxes_left'].data_ptr(),
+                                                    det['boxes_right'].data_ptr(), det['dim_orien'].data_ptr(),
+                                                    det['kpts'].data_ptr(), keep_idx.data_ptr(), num.data_ptr(), n,
+                                                    n_cls, j, REC_COLS, rec.data_ptr(), _lib.stream()),
+                   "srcnn_pack_detections")
+        return rec
     idx = keep_idx.clamp(min=0).long()
     valid = (torch.arange(n, device=dev) < num.to(torch.int64)).float().unsqueeze(1)
     body = torch.zeros((n, REC_COLS), dtype=torch.float32, device=dev)
@@ -64,9 +75,9 @@ def unpack_records(rec):
 def gather_detections(rec, async_op=False):
     """all_gather of one fixed-size record per rank -> (world, max_det + 1, REC_COLS) on every rank.
     Works with the gloo backend on CPU tensors (tests) and nccl/RCCL on device tensors."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return rec.unsqueeze(0), None
+    world = dist.get_world_size()
     out = torch.empty((world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
     work = dist.all_gather_into_tensor(out.view(-1), rec.contiguous().view(-1), async_op=async_op) \
         if rec.is_cuda else dist.all_gather(list(out.unbind(0)), rec.contiguous(), async_op=async_op)

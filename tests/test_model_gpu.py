@@ -301,3 +301,18 @@ def test_batch_of_two_pairs(dev):
                      out[7][img * 300:(img + 1) * 300]]
             frac, errs = _check_end_to_end(o_img, ro['rois_left'][0], ro['rois_right'][0], ro, 0.95)
             assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (precision, img, errs)
+
+
+def test_pack_detections_kernel_matches_host_packing(small, dev):
+    from stereo_rcnn_amd import distributed as sdist
+    from stereo_rcnn_amd import postprocess as hpost
+    out = small['out']
+    info = small['inputs'][2].to(dev)
+    det = hpost.decode_detections(*out[:8], info)
+    keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
+    rec = sdist.pack_records_device(det, keep_idx, num, 1)
+    cls = hpost.class_detections(det, 1, 0.05)
+    ref = sdist.pack_records(cls)
+    assert torch.equal(rec.cpu(), ref.cpu())
+    u = sdist.unpack_records(rec.cpu())
+    assert torch.equal(u['boxes_left'], cls['dets_left'][:, :4].cpu())
