@@ -140,7 +140,8 @@ _workspaces = {}
 
 
 def workspace(nbytes, device, key="default"):
-    k = (str(device), key)
+    # one scratch buffer per (device, purpose, stream): forwards in flight on different streams never share scratch
+    k = (str(device), key, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     if k not in _workspaces:
         _workspaces[k] = Workspace()
     return _workspaces[k].get(nbytes, device)

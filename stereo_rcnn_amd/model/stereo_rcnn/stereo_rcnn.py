@@ -91,14 +91,14 @@ class _StereoRCNN(nn.Module):
     def _device(self):
         return self.RCNN_toplayer.weight.device
 
-    def _get_plan(self, B, H, W):
+    def _get_plan(self, B, H, W, slot=0):
         dev = self._device()
         if dev.type != 'cuda':
             raise RuntimeError("_StereoRCNN.forward needs the model on a GPU (call .cuda()); there is no CPU path")
         if self._weights is None or self._weights.device != dev:
             self._weights = Weights(self.state_dict(), dev)
             self._plans = {}
-        key = (B, H, W)
+        key = (B, H, W, slot)
         if key not in self._plans:
             self._plans[key] = Plan(self._weights, B, H, W)
         return self._plans[key]
@@ -122,13 +122,15 @@ class _StereoRCNN(nn.Module):
         return engine.nhwc_to_nchw(out)
 
     def forward(self, im_left_data, im_right_data, im_info, gt_boxes_left=None, gt_boxes_right=None,
-                gt_boxes_merge=None, gt_dim_orien=None, gt_kpts=None, num_boxes=None):
+                gt_boxes_merge=None, gt_dim_orien=None, gt_kpts=None, num_boxes=None, slot=0):
         """Reference signature and 15-tuple return (stereo_rcnn.py:141-142,322-324).
-        The gt_* / num_boxes arguments are accepted and ignored exactly as in eval mode."""
+        The gt_* / num_boxes arguments are accepted and ignored exactly as in eval mode.
+        `slot` (extension): independent buffer set, so that several pairs can be in flight on different HIP
+        streams (each stream uses its own slot)."""
         if self.training:
             raise NotImplementedError("training forward is out of scope; call .eval()")
         B, _, H, W = im_left_data.shape
-        plan = self._get_plan(int(B), int(H), int(W))
+        plan = self._get_plan(int(B), int(H), int(W), slot)
         plan.set_inputs(im_left_data, im_right_data, im_info)
         plan.run(self.use_graph, self.precision)
         o = plan.outputs()
