@@ -203,6 +203,57 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
     // ---- epilogue
     const bool split = gridDim.y > 1;
     const float os = p.out_scale;
+    // Fast path (every layer of the network except the 6-channel keypoint classifier and the deconv
+    // scatter): the accumulator tile is transposed through the now idle operand LDS so that each lane
+    // owns 8 consecutive channels of one pixel -> bias / residual / ReLU / SPLIT16 re-split on 8 values,
+    // residual read and result written with 16-byte accesses (2 per group instead of 16 two-byte ones).
+    if (p.mode == 0 && (p.Cout & 7) == 0 && (p.ycs & 7) == 0 && (p.yco & 7) == 0 && (!p.res || (p.rcs & 7) == 0)) {
+        float *tile = reinterpret_cast<float *>(smem);       // [BM][BN] floats <= the two operand stages
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = (wm * MR + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+                    tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
+                }
+        __syncthreads();
+        constexpr int GROUPS = BN / 8;
+        for (int gidx = t; gidx < BM * GROUPS; gidx += 256) {
+            const int r = gidx / GROUPS, g = gidx - r * GROUPS;
+            const int row = m0 + r, col = n0 + g * 8;
+            if (row >= p.M || col >= p.Cout) continue;
+            float8 v;
+            const float4 a = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8);
+            const float4 b = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8 + 4);
+            v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
+            v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+            if (split) {
+                float *dst = p.partial + ((size_t)blockIdx.y * p.M + row) * p.Cout + col;
+                *reinterpret_cast<float4 *>(dst) = a;
+                *reinterpret_cast<float4 *>(dst + 4) = b;
+                continue;
+            }
+            if (p.bias) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + col);
+                const float4 b1 = *reinterpret_cast<const float4 *>(p.bias + col + 4);
+                v.v[0] += b0.x; v.v[1] += b0.y; v.v[2] += b0.z; v.v[3] += b0.w;
+                v.v[4] += b1.x; v.v[5] += b1.y; v.v[6] += b1.z; v.v[7] += b1.w;
+            }
+            if (p.res) {
+                const float8 rr = act_load8(p.res, p.res_fmt, (size_t)row, p.rcs, col >> 3);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] += rr.v[e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+            }
+            act_store8(p.y, OUT_SPLIT ? 1 : 0, (size_t)row, p.ycs, (p.yco + col) >> 3, v);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
 #pragma unroll

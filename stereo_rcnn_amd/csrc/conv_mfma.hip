@@ -196,6 +196,40 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p)
 __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
 {
     const size_t total = (size_t)p.M * p.Cout;
+    if ((p.Cout & 7) == 0 && (p.ycs & 7) == 0 && (p.yco & 7) == 0 && (!p.res || (p.rcs & 7) == 0)) {
+        // 8 channels per thread: 32-byte reads of every slab, vector residual / store in either format
+        const int G = p.Cout >> 3;
+        const size_t groups = (size_t)p.M * G;
+        for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < groups;
+             gi += (size_t)gridDim.x * blockDim.x) {
+            const size_t row = gi / G;
+            const int g = (int)(gi - row * G);
+            float8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] = 0.f;
+            for (int s = 0; s < splits; ++s) {
+                const float *src = p.partial + (size_t)s * total + row * p.Cout + g * 8;
+                const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+                v.v[0] += a.x; v.v[1] += a.y; v.v[2] += a.z; v.v[3] += a.w;
+                v.v[4] += b.x; v.v[5] += b.y; v.v[6] += b.z; v.v[7] += b.w;
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] += p.bias[g * 8 + e];
+            }
+            if (p.res) {
+                const float8 rr = act_load8(p.res, p.res_fmt, row, p.rcs, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] += rr.v[e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+            }
+            act_store8(p.y, p.y_fmt, row, p.ycs, (p.yco >> 3) + g, v);
+        }
+        return;
+    }
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(idx / p.Cout), col = (int)(idx - (size_t)row * p.Cout);
