@@ -148,6 +148,11 @@ class Plan(object):
         self.right_prob = e(R, G)
         self.graphs = {}
         self.fmt = 0            # activation format of the internal buffers for the current/last run
+        # independent branches of the forward (FPN laterals, small RPN levels, box head vs keypoint head) are
+        # issued on side streams with event fork/join, so eager runs AND the captured hipGraph execute them
+        # concurrently with the critical path instead of serialising many small launches
+        self.overlap = True
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(2)]
 
     # ------------------------------------------------------------------ stages
     def trunk(self):
@@ -179,40 +184,90 @@ class Plan(object):
                 cur, nxt = nxt, cur
             self.c[li] = x
 
-    def fpn(self):
-        w, N = self.w, self.N
+    # ---- fork / join helpers (all capturable: event record + stream wait)
+    def _fork(self, side):
+        side.wait_stream(torch.cuda.current_stream())
+
+    def _join(self, side):
+        torch.cuda.current_stream().wait_stream(side)
+
+    def _rpn_level(self, l):
+        """RPN_Conv on left and right maps of level l into [left 512 | right 512], fused 1x1 heads, scoring."""
+        w, B, f = self.w, self.B, self.fmt
+        feats = [self.p2, self.p3, self.p4, self.p5, self.p6]
+        h, w_ = self.rpn_shapes[l]
+        cat, hd = self.rpn_cat[l], self.rpn_hd[l]
+        off = sum(3 * a * b for a, b in self.rpn_shapes[:l])
+        engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f)
+        engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
+                      x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f)
+        engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_, x_fmt=f)
+        _lib.check(_lib.lib().srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(),
+                                              self.deltas.data_ptr(), off, self.A, _lib.stream()), "srcnn_rpn_score")
+
+    def fpn_rpn(self):
+        """FPN top-down path (stereo_rcnn.py:161-168) with the stereo RPN head (stereo_rpn.py:73-95) of every
+        level started as soon as that level exists: laterals on side stream 0, RPN levels 6..3 on side stream 1,
+        the big P2 level on the main stream."""
+        w, N, f = self.w, self.N, self.fmt
         (h2, w2), (h3, w3), (h4, w4), (h5, w5) = self.layer_hw
         c2, c3, c4, c5 = self.c
-        f = self.fmt
+        s_lat, s_rpn = self.side
+        par = self.overlap
+        lat_done = []
+        if par:
+            self._fork(s_lat)
+            with torch.cuda.stream(s_lat):
+                for i, (cin, (h, w_)) in enumerate(((c4, (h4, w4)), (c3, (h3, w3)), (c2, (h2, w2)))):
+                    engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)     # lateral stays F32
+                    ev = torch.cuda.Event()
+                    ev.record(s_lat)
+                    lat_done.append(ev)
         engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, x_fmt=f, y_fmt=f)
+        h6, w6 = self.rpn_shapes[4]
+        engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                              # stereo_rcnn.py:168
+        if par:
+            self._fork(s_rpn)
+            with torch.cuda.stream(s_rpn):
+                self._rpn_level(4)
+                self._rpn_level(3)
+        else:
+            self._rpn_level(4)
+            self._rpn_level(3)
         tops = [(self.p5, h5, w5), None, None]
         for i, (cin, (h, w_), out) in enumerate(((c4, (h4, w4), self.p4), (c3, (h3, w3), self.p3),
                                                  (c2, (h2, w2), self.p2))):
             top, th, tw = tops[i]
-            engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)         # lateral stays F32
+            if par:
+                torch.cuda.current_stream().wait_event(lat_done[i])
+            else:
+                engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)
             engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i], top_fmt=f, y_fmt=f)   # stereo_rcnn.py:91-108
             engine.conv2d(w.smooth[i], self.summed[i], N, h, w_, out, h, w_, x_fmt=f, y_fmt=f)
             if i + 1 < 3:
                 tops[i + 1] = (out, h, w_)
-        h6, w6 = self.rpn_shapes[4]
-        engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                              # stereo_rcnn.py:168
+            level = 2 - i                        # p4 -> RPN level 2, p3 -> 1, p2 -> 0
+            if par and level > 0:
+                self._fork(s_rpn)                # side stream also waits for this level's smooth conv
+                with torch.cuda.stream(s_rpn):
+                    self._rpn_level(level)
+            else:
+                self._rpn_level(level)
+        if par:
+            self._join(s_lat)
+            self._join(s_rpn)
+
+    def fpn(self):
+        prev, self.overlap = self.overlap, False
+        try:
+            self.fpn_rpn()
+        finally:
+            self.overlap = prev
 
     def rpn(self):
-        w, B = self.w, self.B
-        L = _lib.lib()
-        feats = [self.p2, self.p3, self.p4, self.p5, self.p6]
-        off = 0
-        st = _lib.stream()
-        for l, (h, w_) in enumerate(self.rpn_shapes):
-            cat, hd = self.rpn_cat[l], self.rpn_hd[l]
-            f = self.fmt
-            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f)
-            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
-                          x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f)
-            engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_, x_fmt=f)
-            _lib.check(L.srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(), self.deltas.data_ptr(),
-                                         off, self.A, st), "srcnn_rpn_score")
-            off += 3 * h * w_
+        """(kept for stage timing tools) the RPN head alone, serial."""
+        for l in range(5):
+            self._rpn_level(l)
 
     def proposals(self):
         L = _lib.lib()
@@ -239,20 +294,20 @@ class Plan(object):
                                                       out.data_ptr(), cstride, coffset, self.fmt, self.fmt,
                                                       _lib.stream()), "srcnn_pyramid_roi_align")
 
-    def heads(self):
-        w, R = self.w, self.R
+    def box_head(self):
+        w, R, f = self.w, self.R, self.fmt
         P = cfg.POOLING_SIZE
-        L = _lib.lib()
-        st = _lib.stream()
         self._pyramid(False, self.rois_left, P, self.sem, 512, 0)        # stereo_rcnn.py:248-249
         self._pyramid(True, self.rois_right, P, self.sem, 512, 256)
-        f = self.fmt
         engine.conv2d(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, x_fmt=f, y_fmt=f)   # 7x7/7 conv == GEMM (resnet.py:257)
         engine.conv2d(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, x_fmt=f, y_fmt=f)
         engine.conv2d(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, x_fmt=f)
-        ncol = w.fc.cout
-        _lib.check(L.srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, ncol,
-                                        self.cls_prob.data_ptr(), st), "srcnn_softmax_rows")
+        _lib.check(_lib.lib().srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, w.fc.cout,
+                                                 self.cls_prob.data_ptr(), _lib.stream()), "srcnn_softmax_rows")
+
+    def kpts_head(self):
+        w, R, f = self.w, self.R, self.fmt
+        P = cfg.POOLING_SIZE
         self._pyramid(False, self.rois_left, 2 * P, self.kp_in, 256, 0)   # stereo_rcnn.py:260
         x = self.kp_in
         s = 2 * P
@@ -263,13 +318,26 @@ class Plan(object):
         engine.conv2d(w.kpts_up, x, R, s, s, self.kp_up, s, s, x_fmt=f, y_fmt=f)
         G = cfg.KPTS_GRID
         engine.conv2d(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, x_fmt=f)
-        _lib.check(L.srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, self.kpts_prob.data_ptr(),
-                                     self.left_prob.data_ptr(), self.right_prob.data_ptr(), st), "srcnn_kpts_tail")
+        _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, self.kpts_prob.data_ptr(),
+                                              self.left_prob.data_ptr(), self.right_prob.data_ptr(), _lib.stream()),
+                   "srcnn_kpts_tail")
+
+    def heads(self):
+        """Box head (M=300 GEMMs, poor chip fill on their own) runs beside the keypoint tower."""
+        if self.overlap:
+            side = self.side[0]
+            self._fork(side)
+            with torch.cuda.stream(side):
+                self.box_head()
+            self.kpts_head()
+            self._join(side)
+        else:
+            self.box_head()
+            self.kpts_head()
 
     def launch_all(self):
         self.trunk()
-        self.fpn()
-        self.rpn()
+        self.fpn_rpn()
         self.proposals()
         self.heads()
 

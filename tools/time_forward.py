@@ -28,7 +28,8 @@ for mode in (False, True):
 # per-stage timing (eager)
 m.use_graph = False
 plan = m._get_plan(1, l.shape[2], l.shape[3])
-for name in ('trunk', 'fpn', 'rpn', 'proposals', 'heads'):
+plan.fmt = 1 if m.precision == 'f16x3' else 0
+for name in ('trunk', 'fpn_rpn', 'proposals', 'heads'):
     fn = getattr(plan, name)
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,6 +38,13 @@ for name in ('trunk', 'fpn', 'rpn', 'proposals', 'heads'):
         fn()
     e1.record(); torch.cuda.synchronize()
     print('%-10s %.3f ms' % (name, e0.elapsed_time(e1) / 5), flush=True)
+for ov in (False, True):
+    plan.overlap = ov
+    for g in (False,):
+        for _ in range(3): plan.run(g, m.precision)
+        torch.cuda.synchronize(); t = time.time()
+        for _ in range(10): plan.run(g, m.precision)
+        torch.cuda.synchronize(); print('overlap=%s: %.2f ms/forward' % (ov, (time.time() - t) * 100), flush=True)
 L = _lib.lib()
 L.srcnn_prof_enable(1)
 plan.launch_all(); torch.cuda.synchronize()
