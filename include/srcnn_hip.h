@@ -118,7 +118,8 @@ typedef struct srcnn_conv_desc {
     const void *w_lo;
     float w_inv_scale;
     /* launch plan override (0 = built-in heuristic): workgroup tile = (64*tile_mr) x (64*tile_nr),
-     * tile_mr/tile_nr in {1,2}; splits = number of K slices (deterministic workspace reduction).
+     * tile_mr/tile_nr in {1,2} (tile_mr = 4 with tile_nr = 2: the 128x128 tile run by 8 wavefronts instead of 4,
+ * SPLIT16 f16x3 engine only); splits = number of K slices (deterministic workspace reduction).
      * Lets the host autotune each layer shape on the device it runs on. */
     int tile_mr, tile_nr, splits;
     /* activation formats (SRCNN_FMT_*).  SPLIT16: per pixel, each group of 8 channels is stored as

@@ -34,10 +34,16 @@ __device__ __forceinline__ void dma16(const void *gsrc, _Float16 *lds_wave_base)
 #endif
 }
 
-template <int MR, int NR, bool OUT_SPLIT>
-__global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
+// MR/NR: per-WAVE tile in 32x32 MFMA tiles; WM x 2 waves per workgroup -> workgroup tile (32*MR*WM) x (64*NR).
+// WM = 2: 4 waves (256 threads).  WM = 4: 8 waves (512 threads) on the same 128x128 tile -> twice the waves
+// per SIMD for the same LDS footprint (more latency hiding; more LDS read traffic per MFMA).
+template <int MR, int NR, bool OUT_SPLIT, int WM>
+__global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p)
 {
-    constexpr int BM = 64 * MR, BN = 64 * NR;
+    constexpr int NWAVES = 2 * WM, NTHREADS = 64 * NWAVES;
+    constexpr int BM = 32 * MR * WM, BN = 64 * NR;
+    constexpr int AG = BM / (16 * NWAVES), BG = BN / (16 * NWAVES);   // 16-row DMA groups per wave (A, B)
+    static_assert(AG >= 1 && BG >= 1 && BM % (16 * NWAVES) == 0 && BN % (16 * NWAVES) == 0, "tile / wave count mismatch");
     constexpr int PANEL_A = BM * SROW, PANEL_B = BN * SROW;   // halves
     constexpr int STAGE = 2 * PANEL_A + 2 * PANEL_B;
     __shared__ __attribute__((aligned(1024))) _Float16 smem[2 * STAGE];
@@ -59,11 +65,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
     const int drow = lane >> 2;                               // row inside the 16-row group
     const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);         // source chunk (swizzle on the source side)
     const char *zero = reinterpret_cast<const char *>(p.zero_page) + (lane & 3) * 16;
-    int a_ih0[MR], a_iw0[MR];
-    const char *a_base[MR];
+    int a_ih0[AG], a_iw0[AG];
+    const char *a_base[AG];
 #pragma unroll
-    for (int g = 0; g < MR; ++g) {
-        const int m = m0 + wave * 16 * MR + g * 16 + drow;
+    for (int g = 0; g < AG; ++g) {
+        const int m = m0 + wave * 16 * AG + g * 16 + drow;
         if (m < p.M) {
             const int ohw = p.OH * p.OW;
             const int b = m / ohw;
@@ -80,11 +86,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
             a_base[g] = zero;
         }
     }
-    const char *bh_base[NR], *bl_base[NR];
-    bool b_ok[NR];
+    const char *bh_base[BG], *bl_base[BG];
+    bool b_ok[BG];
 #pragma unroll
-    for (int g = 0; g < NR; ++g) {
-        const int n = n0 + wave * 16 * NR + g * 16 + drow;
+    for (int g = 0; g < BG; ++g) {
+        const int n = n0 + wave * 16 * BG + g * 16 + drow;
         b_ok[g] = n < p.Cout;
         const size_t off = ((size_t)(b_ok[g] ? n : 0) * p.K + dchunk * 8) * 2;
         bh_base[g] = reinterpret_cast<const char *>(p.w) + off;
@@ -105,11 +111,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
             ld_c0 = 0;
             if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
         }
-        _Float16 *sa_hi = smem + stage * STAGE + (wave * 16 * MR) * SROW;
-        _Float16 *sb_hi = smem + stage * STAGE + 2 * PANEL_A + (wave * 16 * NR) * SROW;
+        _Float16 *sa_hi = smem + stage * STAGE + (wave * 16 * AG) * SROW;
+        _Float16 *sb_hi = smem + stage * STAGE + 2 * PANEL_A + (wave * 16 * BG) * SROW;
         const size_t tap_off = ((size_t)(kh * p.W + kw) * p.xcs + c0) * 4;   // wave-uniform byte offset
 #pragma unroll
-        for (int g = 0; g < MR; ++g) {
+        for (int g = 0; g < AG; ++g) {
             const int ih = a_ih0[g] + kh, iw = a_iw0[g] + kw;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const char *src = ok ? a_base[g] + tap_off : zero;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
         }
         const size_t kb = (size_t)kt * BK * 2;
 #pragma unroll
-        for (int g = 0; g < NR; ++g) {
+        for (int g = 0; g < BG; ++g) {
             dma16(b_ok[g] ? bh_base[g] + kb : zero, sb_hi + g * 16 * SROW);
             dma16(b_ok[g] ? bl_base[g] + kb : zero, sb_hi + PANEL_B + g * 16 * SROW);
         }
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
                 }
         __syncthreads();
         constexpr int GROUPS = BN / 8;
-        for (int gidx = t; gidx < BM * GROUPS; gidx += 256) {
+        for (int gidx = t; gidx < BM * GROUPS; gidx += NTHREADS) {
             const int r = gidx / GROUPS, g = gidx - r * GROUPS;
             const int row = m0 + r, col = n0 + g * 8;
             if (row >= p.M || col >= p.Cout) continue;
@@ -290,21 +296,22 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const ConvArgs p)
     }
 }
 
-template <int MR, int NR>
+template <int MR, int NR, int WM>
 static void launch(const ConvArgs &a, int splits, hipStream_t st)
 {
     if (a.y_fmt == 1)
-        hipLaunchKernelGGL((conv_f16s_kernel<MR, NR, true>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_f16s_kernel<MR, NR, true, WM>), dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_f16s_kernel<MR, NR, false>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_f16s_kernel<MR, NR, false, WM>), dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), 0, st, a);
 }
 
 void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st)
 {
-    if (pl.mr == 2 && pl.nr == 2) launch<2, 2>(a, pl.splits, st);
-    else if (pl.mr == 2 && pl.nr == 1) launch<2, 1>(a, pl.splits, st);
-    else if (pl.mr == 1 && pl.nr == 2) launch<1, 2>(a, pl.splits, st);
-    else launch<1, 1>(a, pl.splits, st);
+    if (pl.mr == 4 && pl.nr == 2) launch<1, 2, 4>(a, pl.splits, st);       // 128x128 tile, 8 waves of 32x64
+    else if (pl.mr == 2 && pl.nr == 2) launch<2, 2, 2>(a, pl.splits, st);
+    else if (pl.mr == 2 && pl.nr == 1) launch<2, 1, 2>(a, pl.splits, st);
+    else if (pl.mr == 1 && pl.nr == 2) launch<1, 2, 2>(a, pl.splits, st);
+    else launch<1, 1, 2>(a, pl.splits, st);
 }
 
 }  // namespace srcnn

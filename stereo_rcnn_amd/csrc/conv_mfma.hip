@@ -279,7 +279,9 @@ static Plan make_plan(int M, int N, int nkt, int mode, int precision)
 static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
 {
     Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
-    if (d->tile_mr >= 1 && d->tile_mr <= 2 && d->tile_nr >= 1 && d->tile_nr <= 2) {
+    // tile_mr == 4 (with tile_nr == 2): the 128x128 tile run by 8 waves (f16 SPLIT16 engine only)
+    const bool wide8 = d->tile_mr == 4 && d->tile_nr == 2 && d->precision == 1 && d->x_format == 1;
+    if (wide8 || (d->tile_mr >= 1 && d->tile_mr <= 2 && d->tile_nr >= 1 && d->tile_nr <= 2)) {
         pl.mr = d->tile_mr;
         pl.nr = d->tile_nr;
         int s = d->splits >= 1 ? d->splits : 1;
@@ -356,7 +358,7 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     if (rc != SRCNN_OK) return rc;
     Plan pl = plan_for(d, a);
     a.kt_per_split = pl.kt_per_split;
-    a.mtiles = cdiv(a.M, 64 * pl.mr);
+    a.mtiles = cdiv(a.M, pl.mr == 4 ? 128 : 64 * pl.mr);
     a.ntiles = cdiv(a.Cout, 64 * pl.nr);
     if (pl.splits > 1) {
         const size_t need = (size_t)pl.splits * a.M * a.Cout * sizeof(float);

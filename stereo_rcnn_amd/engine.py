@@ -113,12 +113,15 @@ def _tune(d, key, device):
     M = d.B * d.OH * d.OW
     nkt = d.KH * d.KW * d.Cin // 32
     cands = []
-    for mr, nr in _CANDIDATES:
+    tiles = list(_CANDIDATES)
+    if d.precision == 1 and d.x_format == 1:
+        tiles.insert(0, (4, 2))          # 128x128 tile on 8 wavefronts (csrc/conv_f16s.hip, WM = 4)
+    for mr, nr in tiles:
         if nr == 2 and d.Cout <= 64:
             continue
         if mr == 2 and M <= 64:
             continue
-        blocks = -(-M // (64 * mr)) * -(-d.Cout // (64 * nr))
+        blocks = -(-M // (128 if mr == 4 else 64 * mr)) * -(-d.Cout // (64 * nr))
         splits = [1]
         if d.mode == 0:
             for s in (2, 3, 4, 6, 8, 12, 16):

@@ -316,3 +316,25 @@ def test_pack_detections_kernel_matches_host_packing(small, dev):
     assert torch.equal(rec.cpu(), ref.cpu())
     u = sdist.unpack_records(rec.cpu())
     assert torch.equal(u['boxes_left'], cls['dets_left'][:, :4].cpu())
+
+
+def test_resnet50_trunk_small(dev):
+    """BASELINE configs[4] model family: the ResNet-50 [3,4,6,3] trunk (an extension: the reference hard-codes
+    ResNet-101, resnet.py:229) through the same engine, vs the oracle."""
+    from oracle import net as onet
+    from stereo_rcnn_amd import fixture
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    sd = fixture.make_state_dict(5, layers=fixture.R50)
+    m = resnet(('__background__', 'Car'), 50)
+    m.create_architecture()
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    l, r, info = fixture.make_inputs(5, 120, 400, target_short=192)
+    ref = onet.forward(sd, l, r, info)
+    for precision in ('f16x3', 'f32'):
+        m.precision = precision
+        with torch.no_grad():
+            out = m(l.to(dev), r.to(dev), info.to(dev))
+        torch.cuda.synchronize()
+        frac, errs = _check_end_to_end(out, ref['rois_left'][0], ref['rois_right'][0], ref, 0.95)
+        assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (precision, errs)
