@@ -117,16 +117,18 @@ typedef struct srcnn_conv_desc {
     int precision;
     const void *w_lo;
     float w_inv_scale;
-    /* launch plan override (0 = built-in heuristic): workgroup tile = (64*tile_mr) x (64*tile_nr),
-     * tile_mr/tile_nr in {1,2} (tile_mr = 4 with tile_nr = 2: the 128x128 tile run by 8 wavefronts instead of 4,
- * SPLIT16 f16x3 engine only); splits = number of K slices (deterministic workspace reduction).
-     * Lets the host autotune each layer shape on the device it runs on. */
+    /* launch plan override (0 = built-in heuristic): workgroup tile = (64*tile_mr) x (64*tile_nr), tile_mr/tile_nr
+     * in {1,2}; splits = number of K slices (deterministic workspace reduction).  The SPLIT16 f16x3 engine also
+     * takes tile_waves (4 or 8 wavefronts per workgroup; 0 = 4) and tile_stages (LDS ring depth 2..4 = K tiles of
+     * DMA in flight + 1; 0 = 2), and with 8 waves tile_mr = 4 (256x128).  An override the engine does not
+     * implement falls back to the heuristic.  Lets the host autotune each layer shape on the device it runs on. */
     int tile_mr, tile_nr, splits;
     /* activation formats (SRCNN_FMT_*).  SPLIT16: per pixel, each group of 8 channels is stored as
      * [8 x f16 hi][8 x f16 lo] (hi = f16(v), lo = f16(v - hi); same bytes as float32, channel strides
      * are still given in float32-equivalents).  With precision 1 and x_format SPLIT16 both GEMM
      * operands are DMA'd straight into LDS (global_load_lds).  fp32 engine: all formats must be F32. */
     int x_format, y_format, res_format;
+    int tile_waves, tile_stages;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);

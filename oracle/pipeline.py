@@ -57,7 +57,8 @@ def detect_3d(sd, im_left, im_right, im_info, calib, im_shape, eval_thresh=C.EVA
         if st > 0:
             objs.append({'box_left': dl[i, 0:4].copy(), 'box_right': dr[i, 0:4].copy(), 'score': float(dl[i, 4]),
                          'dim': do[i, 0:3].astype(np.float64), 'alpha': alpha, 'xyz': np.array(state[0:3]),
-                         'theta': float(state[3]), 'kpts': kp[i].copy(), 'aligned': False})
+                         'theta': float(state[3]), 'kpts': kp[i].copy(), 'aligned': False,
+                         'xyz_init': np.array(state[0:3])})
     if not objs or not dense:
         return objs
     t = lambda rows: torch.tensor(np.asarray(rows), dtype=torch.float32)

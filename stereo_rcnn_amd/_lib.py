@@ -29,7 +29,8 @@ class ConvDesc(ctypes.Structure):
                 ("relu", c_int), ("mode", c_int),
                 ("precision", c_int), ("w_lo", c_void_p), ("w_inv_scale", c_float),
                 ("tile_mr", c_int), ("tile_nr", c_int), ("splits", c_int),
-                ("x_format", c_int), ("y_format", c_int), ("res_format", c_int)]
+                ("x_format", c_int), ("y_format", c_int), ("res_format", c_int),
+                ("tile_waves", c_int), ("tile_stages", c_int)]
 
 
 _SIGNATURES = {

@@ -55,6 +55,11 @@ struct Carver {
     }
 };
 
+// nms.hip: batched NMS where problems (2b, 2b+1) are scanned in lockstep and stop once the intersection of their
+// keep lists has `stop_after` entries (keep lists are then complete only up to that point).  Used by the proposal layer.
+int nms_pairs_until(int *keep_out, const float *dets, int *num_out, const int *n_valid, int nb, int n, int dim,
+                    float thresh, void *ws, size_t ws_bytes, int stop_after, hipStream_t st);
+
 // profiling hooks (conv engine)
 bool prof_enabled();
 void prof_begin(hipStream_t s);

@@ -98,11 +98,13 @@ __device__ __forceinline__ void act_store8(void *base, int fmt, size_t pixel, in
 }
 
 struct Plan {
-    int mr, nr, splits, kt_per_split;
+    int mr, nr, splits, kt_per_split;   // workgroup tile (64*mr) x (64*nr); K slices
+    int waves = 4, stages = 2;          // wavefronts per workgroup; LDS ring depth (conv_f16s only)
 };
 
 void launch_conv_f16x3(const ConvArgs &a, const Plan &pl, hipStream_t st);   // A operand fp32 in HBM
 void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st);    // A operand split16 in HBM
+bool conv_f16s_plan_ok(const Plan &pl);
 const void *zero_page();
 
 }  // namespace srcnn

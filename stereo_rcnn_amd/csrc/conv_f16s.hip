@@ -12,8 +12,11 @@
 //     keeps ds_read_b128 conflict-free is applied on the SOURCE side: lane (row=l>>2, slot=l&3)
 //     fetches chunk slot ^ ((row>>2)&3) of its row;
 //   * zero padding (image borders, M/N tails) = lanes pointed at a zero page in HBM;
-//   * loads for tile t+1 are issued before the MFMAs of tile t and land in the other LDS stage;
-//     the single barrier per K tile also drains them (hipcc places vmcnt(0) there).
+//   * NS-stage LDS ring: the loads of tile t+NS-1 are issued before the MFMAs of tile t; the one
+//     barrier per K tile is preceded by a hand-written `s_waitcnt vmcnt(n)` that waits only for the
+//     OLDEST tile in flight (vector-memory results return in order), so up to NS-1 tiles of DMA stay
+//     outstanding across barriers -- the L2 -> LDS path (~56 B/clk/CU) runs at throughput instead of
+//     one latency per K tile.
 #include "conv_common.h"
 
 namespace srcnn {
@@ -34,10 +37,20 @@ __device__ __forceinline__ void dma16(const void *gsrc, _Float16 *lds_wave_base)
 #endif
 }
 
+// wait until at most N of this wave's vector-memory operations are outstanding and every LDS read has
+// returned, then workgroup barrier.  Hand-written so that the compiler's fence (vmcnt(0)) is not used.
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+extern __shared__ __attribute__((aligned(1024))) _Float16 smem[];
+
 // MR/NR: per-WAVE tile in 32x32 MFMA tiles; WM x 2 waves per workgroup -> workgroup tile (32*MR*WM) x (64*NR).
-// WM = 2: 4 waves (256 threads).  WM = 4: 8 waves (512 threads) on the same 128x128 tile -> twice the waves
-// per SIMD for the same LDS footprint (more latency hiding; more LDS read traffic per MFMA).
-template <int MR, int NR, bool OUT_SPLIT, int WM>
+// WM = 2: 4 waves (256 threads).  WM = 4: 8 waves (512 threads).  NS: LDS ring stages (NS-1 K tiles in flight).
+template <int MR, int NR, bool OUT_SPLIT, int WM, int NS>
 __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p)
 {
     constexpr int NWAVES = 2 * WM, NTHREADS = 64 * NWAVES;
@@ -46,7 +59,9 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     static_assert(AG >= 1 && BG >= 1 && BM % (16 * NWAVES) == 0 && BN % (16 * NWAVES) == 0, "tile / wave count mismatch");
     constexpr int PANEL_A = BM * SROW, PANEL_B = BN * SROW;   // halves
     constexpr int STAGE = 2 * PANEL_A + 2 * PANEL_B;
-    __shared__ __attribute__((aligned(1024))) _Float16 smem[2 * STAGE];
+    constexpr int LPT = 2 * (AG + BG);                        // DMA instructions per wave per K tile
+    static_assert(NS >= 2 && NS <= 4 && (NS - 2) * LPT < 64, "ring depth");
+    static_assert(NS * STAGE * 2 >= BM * BN * 4, "epilogue tile must fit in the operand ring");
 
     const int t = threadIdx.x;
     const int nblk = p.mtiles * p.ntiles;
@@ -148,15 +163,24 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                 for (int x = 0; x < (NX > 0 ? NX : 1); ++x) accx[x][i][j][e] = 0.f;
             }
 
-    if (kt_begin < kt_end) dma_tile(kt_begin, 0);
-    __syncthreads();
+    // ---- prologue: fill NS-1 stages, wait for the first
+    const int nk = kt_end - kt_begin;
+    {
+        const int pre = min(NS - 1, nk);
+        for (int i = 0; i < pre; ++i) dma_tile(kt_begin + i, i);
+        if (NS >= 4 && pre == 3) wait_vm_barrier<2 * LPT>();
+        else if (NS >= 3 && pre == 2) wait_vm_barrier<LPT>();
+        else wait_vm_barrier<0>();
+    }
+    int cs = 0, ls = NS - 1;                                  // compute stage / load stage of the ring
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int stage = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) dma_tile(kt + 1, stage ^ 1);
-        const _Float16 *sah = smem + stage * STAGE + (wm * 32 * MR + li) * SROW + r_sw;
+        if (kt + NS - 1 < kt_end) dma_tile(kt + NS - 1, ls);
+        ls = (ls + 1 == NS) ? 0 : ls + 1;
+        const _Float16 *sah = smem + cs * STAGE + (wm * 32 * MR + li) * SROW + r_sw;
         const _Float16 *sal = sah + PANEL_A;
-        const _Float16 *sbh = smem + stage * STAGE + 2 * PANEL_A + (wn * 32 * NR + li) * SROW + r_sw;
+        const _Float16 *sbh = smem + cs * STAGE + 2 * PANEL_A + (wn * 32 * NR + li) * SROW + r_sw;
         const _Float16 *sbl = sbh + PANEL_B;
+        cs = (cs + 1 == NS) ? 0 : cs + 1;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int ko = kk ? ((r_sw ^ 16) - r_sw) : 0;
@@ -170,6 +194,14 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
             for (int j = 0; j < NR; ++j) {
                 bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * SROW + ko);
                 bl[j] = *reinterpret_cast<const half8 *>(sbl + j * 32 * SROW + ko);
+            }
+            if (kk == BK / 16 - 1) {
+                // every wave has now read the whole stage: wait for tile kt+1 (only), barrier, and let the
+                // last MFMAs of this tile run behind it.  n_after = tiles issued after tile kt+1.
+                const int n_after = min(kt + NS - 1, kt_end - 1) - (kt + 1);
+                if (NS >= 4 && n_after == 2) wait_vm_barrier<2 * LPT>();
+                else if (NS >= 3 && n_after == 1) wait_vm_barrier<LPT>();
+                else wait_vm_barrier<0>();
             }
 #pragma unroll
             for (int i = 0; i < MR; ++i)
@@ -191,7 +223,6 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                 for (int j = 0; j < NR; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
     if (NX > 0) {
 #pragma unroll
@@ -213,7 +244,8 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     // scatter): the accumulator tile is transposed through the now idle operand LDS so that each lane
     // owns 8 consecutive channels of one pixel -> bias / residual / ReLU / SPLIT16 re-split on 8 values,
     // residual read and result written with 16-byte accesses (2 per group instead of 16 two-byte ones).
-    if (p.mode == 0 && (p.Cout & 7) == 0 && (p.ycs & 7) == 0 && (p.yco & 7) == 0 && (!p.res || (p.rcs & 7) == 0)) {
+    const int cq = p.mode == 1 ? (p.Cout >> 2) : p.Cout;     // channels per output pixel (deconv: Cout = 4 taps x cq)
+    if ((cq & 7) == 0 && (p.ycs & 7) == 0 && (p.yco & 7) == 0 && (!p.res || (p.rcs & 7) == 0)) {
         float *tile = reinterpret_cast<float *>(smem);       // [BM][BN] floats <= the two operand stages
 #pragma unroll
         for (int i = 0; i < MR; ++i)
@@ -241,9 +273,12 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                 *reinterpret_cast<float4 *>(dst + 4) = b;
                 continue;
             }
+            // deconv (mode 1): column = (tap ij, channel co); the 8-channel group never straddles a tap
+            const int ij = p.mode == 1 ? col / cq : 0;
+            const int co = col - ij * cq;
             if (p.bias) {
-                const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + col);
-                const float4 b1 = *reinterpret_cast<const float4 *>(p.bias + col + 4);
+                const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co);
+                const float4 b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4);
                 v.v[0] += b0.x; v.v[1] += b0.y; v.v[2] += b0.z; v.v[3] += b0.w;
                 v.v[4] += b1.x; v.v[5] += b1.y; v.v[6] += b1.z; v.v[7] += b1.w;
             }
@@ -256,7 +291,14 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
             }
-            act_store8(p.y, OUT_SPLIT ? 1 : 0, (size_t)row, p.ycs, (p.yco + col) >> 3, v);
+            size_t opix = (size_t)row;
+            if (p.mode == 1) {                                   // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j)
+                const int ohw = p.OH * p.OW;
+                const int b = row / ohw, rem = row - b * ohw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                opix = ((size_t)b * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
+            }
+            act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + co) >> 3, v);
         }
         return;
     }
@@ -296,22 +338,52 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     }
 }
 
-template <int MR, int NR, int WM>
+template <int MR, int NR, int WM, int NS>
 static void launch(const ConvArgs &a, int splits, hipStream_t st)
 {
-    if (a.y_fmt == 1)
-        hipLaunchKernelGGL((conv_f16s_kernel<MR, NR, true, WM>), dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_f16s_kernel<MR, NR, false, WM>), dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), 0, st, a);
+    constexpr size_t lds = (size_t)NS * 128 * (32 * MR * WM + 64 * NR);   // NS stages of (hi+lo) x (BM+BN) rows x 64 B
+    static bool configured = false;
+    auto *k1 = conv_f16s_kernel<MR, NR, true, WM, NS>;
+    auto *k0 = conv_f16s_kernel<MR, NR, false, WM, NS>;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    if (a.y_fmt == 1) hipLaunchKernelGGL(k1, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);
+    else hipLaunchKernelGGL(k0, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);
+}
+
+// Plan -> instantiation.  Workgroup tile (64*mr) x (64*nr); waves 4 or 8; stages = LDS ring depth.
+bool conv_f16s_plan_ok(const Plan &pl)
+{
+    const int t = pl.mr * 100 + pl.nr * 10 + (pl.waves == 8 ? 8 : 4);
+    switch (t) {
+    case 114: return pl.stages == 2 || pl.stages == 4;
+    case 214: case 124: return pl.stages == 2 || pl.stages == 3;
+    case 224: return pl.stages == 2;
+    case 228: return pl.stages == 2 || pl.stages == 4;
+    case 428: return pl.stages == 3;
+    default: return false;
+    }
 }
 
 void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st)
 {
-    if (pl.mr == 4 && pl.nr == 2) launch<1, 2, 4>(a, pl.splits, st);       // 128x128 tile, 8 waves of 32x64
-    else if (pl.mr == 2 && pl.nr == 2) launch<2, 2, 2>(a, pl.splits, st);
-    else if (pl.mr == 2 && pl.nr == 1) launch<2, 1, 2>(a, pl.splits, st);
-    else if (pl.mr == 1 && pl.nr == 2) launch<1, 2, 2>(a, pl.splits, st);
-    else launch<1, 1, 2>(a, pl.splits, st);
+    const int t = pl.mr * 1000 + pl.nr * 100 + (pl.waves == 8 ? 80 : 40) + pl.stages;
+    switch (t) {
+    case 1142: launch<1, 1, 2, 2>(a, pl.splits, st); break;
+    case 1144: launch<1, 1, 2, 4>(a, pl.splits, st); break;
+    case 2142: launch<2, 1, 2, 2>(a, pl.splits, st); break;
+    case 2143: launch<2, 1, 2, 3>(a, pl.splits, st); break;
+    case 1242: launch<1, 2, 2, 2>(a, pl.splits, st); break;
+    case 1243: launch<1, 2, 2, 3>(a, pl.splits, st); break;
+    case 2242: launch<2, 2, 2, 2>(a, pl.splits, st); break;
+    case 2282: launch<1, 2, 4, 2>(a, pl.splits, st); break;   // 128x128 on 8 waves of 32x64
+    case 2284: launch<1, 2, 4, 4>(a, pl.splits, st); break;
+    case 4283: launch<2, 2, 4, 3>(a, pl.splits, st); break;   // 256x128 on 8 waves of 64x64
+    default: launch<1, 1, 2, 2>(a, pl.splits, st); break;     // unreachable: plan_for() validates with conv_f16s_plan_ok
+    }
 }
 
 }  // namespace srcnn

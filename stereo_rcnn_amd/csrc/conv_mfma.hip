@@ -279,18 +279,23 @@ static Plan make_plan(int M, int N, int nkt, int mode, int precision)
 static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
 {
     Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
-    // tile_mr == 4 (with tile_nr == 2): the 128x128 tile run by 8 waves (f16 SPLIT16 engine only)
-    const bool wide8 = d->tile_mr == 4 && d->tile_nr == 2 && d->precision == 1 && d->x_format == 1;
-    if (wide8 || (d->tile_mr >= 1 && d->tile_mr <= 2 && d->tile_nr >= 1 && d->tile_nr <= 2)) {
-        pl.mr = d->tile_mr;
-        pl.nr = d->tile_nr;
-        int s = d->splits >= 1 ? d->splits : 1;
-        if (a.mode != 0) s = 1;
-        s = min(s, a.nkt);
-        pl.kt_per_split = cdiv(a.nkt, s);
-        pl.splits = cdiv(a.nkt, pl.kt_per_split);
-    }
-    return pl;
+    if (d->tile_mr <= 0 || d->tile_nr <= 0) return pl;
+    Plan req = pl;
+    req.mr = d->tile_mr;
+    req.nr = d->tile_nr;
+    req.waves = d->tile_waves > 0 ? d->tile_waves : 4;
+    req.stages = d->tile_stages > 0 ? d->tile_stages : 2;
+    const bool f16s = d->precision == 1 && d->x_format == 1;
+    // the fp32 and fp32-input f16x3 kernels have the four 4-wave 2-stage tiles; the SPLIT16 kernel has more
+    const bool ok = f16s ? conv_f16s_plan_ok(req)
+                         : (req.mr <= 2 && req.nr <= 2 && req.waves == 4 && req.stages == 2);
+    if (!ok) return pl;            // unknown override: fall back to the heuristic plan (never an error)
+    int s = d->splits >= 1 ? d->splits : 1;
+    if (a.mode != 0) s = 1;
+    s = min(s, a.nkt);
+    req.kt_per_split = cdiv(a.nkt, s);
+    req.splits = cdiv(a.nkt, req.kt_per_split);
+    return req;
 }
 
 static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
@@ -358,7 +363,7 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     if (rc != SRCNN_OK) return rc;
     Plan pl = plan_for(d, a);
     a.kt_per_split = pl.kt_per_split;
-    a.mtiles = cdiv(a.M, pl.mr == 4 ? 128 : 64 * pl.mr);
+    a.mtiles = cdiv(a.M, 64 * pl.mr);
     a.ntiles = cdiv(a.Cout, 64 * pl.nr);
     if (pl.splits > 1) {
         const size_t need = (size_t)pl.splits * a.M * a.Cout * sizeof(float);

@@ -4,7 +4,8 @@
 //   * pair_mask_kernel  == nms_kernel (:41-85): one 64-lane wavefront per 64x64 tile, one
 //     uint64 suppression word per (box, column block); IoU arithmetic op-for-op as devIoU
 //     (:31-39) so the keep list is bit-identical.  Tiles below the diagonal are skipped:
-//     the greedy pass never reads them (:139-142 starts at j = nblock).
+//     the greedy pass never reads them (:139-142 starts at j = nblock).  The words are stored
+//     COLUMN-BLOCK major (maskT[c][box]): what the scan needs for block c is then contiguous.
 //   * greedy_scan_kernel replaces the HOST loop (:117-144): the reference copies the whole
 //     mask to the CPU and reduces it serially; here one workgroup per problem walks the
 //     column blocks on the device (see the kernel's comment).  No D2H copy, no sync, no
@@ -31,9 +32,10 @@ __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b)
 // grid: (col_blocks, col_blocks, nb); block: 64 threads (one wavefront == one mask word)
 __global__ __launch_bounds__(64) void pair_mask_kernel(const float *__restrict__ dets, int n, int dim,
                                                        float thresh, unsigned long long *__restrict__ mask,
-                                                       int col_blocks)
+                                                       int col_blocks, unsigned long long *__restrict__ zero_word)
 {
     const int col_start = blockIdx.x, row_start = blockIdx.y;
+    if ((blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) *zero_word = 0ULL;   // read by the scan's dummy DMAs
     if (row_start > col_start) return;
     const float *d = dets + (size_t)blockIdx.z * n * dim;
     unsigned long long *m = mask + (size_t)blockIdx.z * n * col_blocks;
@@ -54,102 +56,277 @@ __global__ __launch_bounds__(64) void pair_mask_kernel(const float *__restrict__
         const int start = (row_start == col_start) ? t + 1 : 0;
         for (int i = start; i < col_size; ++i)
             if (iou_plus1(me, cols[i]) > thresh) bits |= 1ULL << i;
-        m[(size_t)cur * col_blocks + col_start] = bits;
+        m[(size_t)col_start * n + cur] = bits;          // column-block major
     }
 }
 
-// One workgroup per problem, one wavefront per 64 mask words (column blocks): lane l of wave w owns
-// the `removed` word of column block j = 64*w + l.  For each block b of 64 boxes (in score order):
-//   1. every lane issues the loads of ALL 64 candidate rows' word j up front (64 independent loads
-//      in flight: the walk pays ~one L2 round trip per block instead of one per kept row);
-//   2. meanwhile the block's 64 boxes are resolved against the diagonal tile on the scalar unit:
-//      only KEPT boxes cost an iteration (find-first-set on the availability mask + one readlane);
-//   3. the rows of the kept boxes are OR-ed into the lane's word, the word of block b+1.. is
-//      published through LDS for the next step.
-// Waves of a workgroup stay in lockstep (two barriers per step); every wave resolves the diagonal
-// redundantly so no cross-wave broadcast of the kept mask is needed.
-__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane)
+// The greedy pass.  Block c of 64 boxes (score order) can be resolved once the suppression word of
+// column block c is known for every box kept so far:  removed_c = OR_{kept i < 64c} maskT[c][i].
+// Instead of OR-ing whole mask rows into a `removed` array after every block (4.5 MB of row reads for
+// 6000 boxes, one dependent memory round trip per block), each step GATHERS only column c over the
+// list of kept boxes (<= a few hundred words), and everything block t = c+D needs is requested D = 3
+// steps ahead, before blocks c .. c+D-1 are resolved:
+//   * the gather of column t over the boxes kept in blocks < c   (the kept list at the start of step c),
+//   * all 64 words maskT[t][64(c+w) + lane] of block c+w, carried by wave w (speculative: selected by
+//     that block's keep bits when step t consumes them),
+//   * the diagonal tile of block t.
+// The requests are global_load_lds DMAs into a per-wave LDS ring (lane-linear, so a lane reads back only
+// what its own wave requested: no extra barrier), a fixed number per step (pieces that do not exist
+// read a zero word kept behind the mask), and each step waits with a hand-written `s_waitcnt vmcnt(n)`
+// for the OLDEST generation only: D-1 generations stay in flight across the two workgroup barriers
+// of a step, so a step costs max(L2 round trip / D, resolve) instead of their sum.  Wave 0 resolves
+// the block on the scalar unit: only KEPT boxes cost an iteration (find-first-set on the availability
+// mask + one readlane of the diagonal word).
+// PAIR = 2 (proposal layer): problems (2b, 2b+1) = the left and right boxes of one image walk in lockstep
+// in one workgroup and stop as soon as the INTERSECTION of their keep lists has `stop_after` entries --
+// all that proposal_layer.py:127-143 consumes (intersect1d, then [:post_nms_topN]).
+typedef unsigned long long u64;
+constexpr int SCAN_T = 256;                  // threads per problem (4 wavefronts)
+constexpr int SCAN_G = 4;                    // gathered words per thread per generation (SCAN_G * SCAN_T kept boxes)
+constexpr int SCAN_D = 3;                    // generations in flight (waves 0..D-1 carry the speculative blocks)
+constexpr int SCAN_W = SCAN_G + 2;           // words per lane per generation: gather, spec, diag
+constexpr int SCAN_LPW = 2 * SCAN_W;         // DMA instructions per wave per step (lo + hi dword of each word)
+constexpr int SCAN_RING = SCAN_D * 4 * SCAN_LPW * 64;   // dwords of ring per problem
+
+__device__ __forceinline__ u64 readlane64(u64 v, int lane)
 {
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)(v & 0xFFFFFFFFULL), lane);
     const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
-    return ((unsigned long long)hi << 32) | lo;
+    return ((u64)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(256) void greedy_scan_kernel(const unsigned long long *__restrict__ mask, int n,
-                                                          int col_blocks, const int *__restrict__ n_valid,
-                                                          int *__restrict__ keep_out, int *__restrict__ num_out)
+// OR over the 64 lanes, returned wave-uniform.  DPP row shifts / row broadcasts (register crossbar, no LDS
+// permutes): after row_shr 1,2,4,8 lane 15 of each 16-lane row holds the row's OR, row_bcast:15 / :31 fold the
+// rows together into lane 63.  Lanes shifted in from outside a row read 0 (bound_ctrl), the identity of OR.
+__device__ __forceinline__ unsigned wave_or32(unsigned v)
 {
-    __shared__ unsigned long long removed[256];
-    const int prob = blockIdx.x;
-    const unsigned long long *m = mask + (size_t)prob * n * col_blocks;
+#if defined(__HIP_DEVICE_COMPILE__)
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+#else
+    return v;
+#endif
+}
+
+__device__ __forceinline__ u64 wave_or(u64 v)
+{
+    const unsigned lo = wave_or32((unsigned)(v & 0xFFFFFFFFULL)), hi = wave_or32((unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+// LDS-visibility barrier that leaves vector-memory operations in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// one 4-byte-per-lane DMA: lane l's dword lands at lds_wave_base + 4*l  (device-only builtin)
+__device__ __forceinline__ void dma4(const void *gsrc, unsigned *lds_wave_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 4, 0, 0);
+#else
+    (void)gsrc;
+    (void)lds_wave_base;
+#endif
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
+
+template <int PAIR>
+__global__ __launch_bounds__(SCAN_T *PAIR) void greedy_scan_kernel(const u64 *__restrict__ maskT, const u64 *__restrict__ zero_word,
+                                                                    int n, int col_blocks, const int *__restrict__ n_valid,
+                                                                    int *__restrict__ keep_out, int *__restrict__ num_out,
+                                                                    int stop_after)
+{
+    u64 *red = reinterpret_cast<u64 *>(scan_lds);                     // [PAIR][4] per-wave partial ORs
+    u64 *kbits = red + PAIR * 4;                                       // [PAIR] keep bits of the block just resolved
+    unsigned *ring_all = reinterpret_cast<unsigned *>(kbits + PAIR);   // [PAIR][D][4 waves][LPW][64 lanes]
+    int *kept_all = reinterpret_cast<int *>(ring_all + PAIR * SCAN_RING);   // [PAIR][n] kept boxes so far
+    const int tid = threadIdx.x, grp = tid / SCAN_T, gt = tid % SCAN_T;
+    const int wave = __builtin_amdgcn_readfirstlane(gt >> 6), lane = gt & 63;
+    const int prob = blockIdx.x * PAIR + grp;
+    const u64 *m = maskT + (size_t)prob * col_blocks * n;
     int *keep = keep_out + (size_t)prob * n;
-    const int tid = threadIdx.x, lane = tid & 63;
+    int *kept = kept_all + (size_t)grp * n;
+    unsigned *ring = ring_all + grp * SCAN_RING + wave * (SCAN_LPW * 64);   // this wave's part of slot 0
+    constexpr int SLOT = 4 * SCAN_LPW * 64;                                  // dwords per generation
     const int nv = n_valid ? min(n_valid[prob], n) : n;
     const int nblocks = (nv + 63) / 64;
-    const int j = min(tid, col_blocks - 1);           // my column block (clamped lanes do harmless work)
-    removed[tid] = 0ULL;
-    __syncthreads();
-    int count = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        const int in_block = min(64, nv - b * 64);
-        // 1. all 64 rows' words for my column, unconditionally (rows clamped), 64 loads in flight
-        unsigned long long v[64];
-        const unsigned long long *col = m + (size_t)(b * 64) * col_blocks + j;
-        const int rmax = n - 1 - b * 64;
-#pragma unroll
-        for (int t = 0; t < 64; ++t) v[t] = col[(size_t)min(t, rmax) * col_blocks];
-        // 2. diagonal resolve (wave-uniform; scalar unit)
-        const unsigned long long diag = (lane < in_block) ? m[(size_t)(b * 64 + lane) * col_blocks + b] : 0ULL;
-        unsigned long long cur = removed[b];
-        if (in_block < 64) cur |= ~0ULL << in_block;
-        unsigned cl = __builtin_amdgcn_readfirstlane((unsigned)(cur & 0xFFFFFFFFULL));
-        unsigned ch = __builtin_amdgcn_readfirstlane((unsigned)(cur >> 32));
-        cur = ((unsigned long long)ch << 32) | cl;
-        unsigned long long kept = 0, avail = ~cur;
-        while (avail) {
-            const int t = __ffsll((long long)avail) - 1;
-            kept |= 1ULL << t;
-            cur |= readlane64(diag, t);                 // bits > t only (kernel writes the upper triangle)
-            avail = ~cur & ~((2ULL << t) - 1ULL);
-            if (t == 63) break;
-        }
-        if (tid < 64) {
-            if ((kept >> lane) & 1ULL) keep[count + __popcll(kept & ((1ULL << lane) - 1ULL))] = b * 64 + lane;
-        }
-        count += __popcll(kept);
-        // 3. OR the kept rows into my word
-        unsigned long long acc = 0;
-#pragma unroll
-        for (int t = 0; t < 64; ++t)
-            if ((kept >> t) & 1ULL) acc |= v[t];
-        __syncthreads();                                // everyone has read removed[b]
-        if (tid > b && tid < col_blocks) removed[tid] |= acc;
-        __syncthreads();
+    int nb_all = nblocks;
+    if (PAIR == 2) {
+        const int nvo = n_valid ? min(n_valid[prob ^ 1], n) : n;
+        nb_all = max(nblocks, (nvo + 63) / 64);
     }
-    if (tid == 0) num_out[prob] = count;
+    int count = 0, both = 0;
+    u64 hist[SCAN_D];                                                  // keep bits of blocks c-1, c-2, .. c-D
+#pragma unroll
+    for (int d = 0; d < SCAN_D; ++d) hist[d] = 0ULL;
+
+    // request block t into ring slot `slot`: always SCAN_LPW DMAs per wave; missing pieces read the zero word
+    auto issue = [&](int slot, int t, int count_now) {
+        unsigned *dst = ring + slot * SLOT;
+        const bool live = t < nblocks;
+        const u64 *col = m + (size_t)(live ? t : 0) * n;
+#pragma unroll
+        for (int q = 0; q < SCAN_G; ++q) {
+            const int k = gt + q * SCAN_T;
+            const u64 *src = (live && k < count_now) ? col + kept[k] : zero_word;
+            dma4(src, dst + (2 * q) * 64);
+            dma4(reinterpret_cast<const unsigned *>(src) + 1, dst + (2 * q + 1) * 64);
+        }
+        const int sb = t - SCAN_D + wave;                              // waves >= D carry nothing
+        const u64 *sp = (live && wave < SCAN_D && sb >= 0) ? col + sb * 64 + lane : zero_word;
+        dma4(sp, dst + (2 * SCAN_G) * 64);
+        dma4(reinterpret_cast<const unsigned *>(sp) + 1, dst + (2 * SCAN_G + 1) * 64);
+        const int r = t * 64 + lane;
+        const u64 *dg = (live && r < nv) ? col + r : zero_word;
+        dma4(dg, dst + (2 * SCAN_G + 2) * 64);
+        dma4(reinterpret_cast<const unsigned *>(dg) + 1, dst + (2 * SCAN_G + 3) * 64);
+    };
+    auto word = [&](int slot, int j) -> u64 {
+        const unsigned *src = ring + slot * SLOT + (2 * j) * 64 + lane;
+        return ((u64)src[64] << 32) | (u64)src[0];
+    };
+
+#pragma unroll
+    for (int d = 0; d < SCAN_D; ++d) issue(d, d, 0);
+    int slot = 0;
+    int cnt_ring[SCAN_D];                                              // kept-list length each generation's gather covers
+#pragma unroll
+    for (int d = 0; d < SCAN_D; ++d) cnt_ring[d] = 0;
+
+    for (int c = 0; c < nb_all; ++c) {
+        const bool active = c < nblocks;
+        // ---- the oldest generation (block c) has landed once at most (D-1) generations are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SCAN_D - 1) * SCAN_LPW) : "memory");
+        u64 part = 0ULL;
+#pragma unroll
+        for (int q = 0; q < SCAN_G; ++q) part |= word(slot, q);
+        const int cnt_c = slot == 0 ? cnt_ring[0] : slot == 1 ? cnt_ring[1] : cnt_ring[2];
+        if (cnt_c > SCAN_G * SCAN_T) {                                 // kept list longer than the DMA window
+            const u64 *colc = m + (size_t)min(c, col_blocks - 1) * n;
+            int k = SCAN_G * SCAN_T + gt;
+            for (; k + 3 * SCAN_T < cnt_c; k += 4 * SCAN_T) {          // four independent loads in flight
+                const u64 a0 = colc[kept[k]], a1 = colc[kept[k + SCAN_T]], a2 = colc[kept[k + 2 * SCAN_T]],
+                          a3 = colc[kept[k + 3 * SCAN_T]];
+                part |= (a0 | a1) | (a2 | a3);
+            }
+            for (; k < cnt_c; k += SCAN_T) part |= colc[kept[k]];
+        }
+        // wave w carries block c-D+w, whose keep bits are hist[D-1-w]
+        const u64 hb = wave == 0 ? hist[2] : wave == 1 ? hist[1] : wave == 2 ? hist[0] : 0ULL;
+        if ((hb >> lane) & 1ULL) part |= word(slot, SCAN_G);
+        const u64 cur_diag = word(slot, SCAN_G + 1);
+        part = wave_or(part);
+        if (lane == 0) red[grp * 4 + wave] = part;
+        lds_barrier();                                                 // ring slot read back by everyone
+        // ---- request block c+D into the slot just consumed (kept list = blocks < c; blocks c.. via `spec`)
+        issue(slot, c + SCAN_D, count);
+        if (slot == 0) cnt_ring[0] = count; else if (slot == 1) cnt_ring[1] = count; else cnt_ring[2] = count;
+        if (wave == 0) {
+            u64 kb = 0ULL;
+            if (active) {
+                u64 cur = red[grp * 4] | red[grp * 4 + 1] | red[grp * 4 + 2] | red[grp * 4 + 3];
+                const int in_block = min(64, nv - c * 64);
+                if (in_block < 64) cur |= ~0ULL << in_block;
+                const unsigned cl = __builtin_amdgcn_readfirstlane((unsigned)(cur & 0xFFFFFFFFULL));
+                const unsigned ch = __builtin_amdgcn_readfirstlane((unsigned)(cur >> 32));
+                cur = ((u64)ch << 32) | cl;
+                // Peel in parallel first: a box none of whose still-undecided block mates can suppress it is kept
+                // at once (typically most of a block); two wave-wide ORs per round instead of one scalar iteration
+                // per kept box.  What is left (boxes inside overlap chains) is walked in order on the scalar unit.
+                u64 avail = ~cur;
+#pragma unroll 1
+                for (int round = 0; round < 3 && avail; ++round) {
+                    const u64 col_or = wave_or(((avail >> lane) & 1ULL) ? cur_diag : 0ULL);
+                    const u64 free_now = avail & ~col_or;
+                    if (!free_now) break;
+                    kb |= free_now;
+                    cur |= wave_or(((free_now >> lane) & 1ULL) ? cur_diag : 0ULL);
+                    avail = ~cur & ~kb;
+                }
+                while (avail) {
+                    const int t = __ffsll((long long)avail) - 1;
+                    kb |= 1ULL << t;
+                    cur |= readlane64(cur_diag, t);             // bits > t only (upper triangle)
+                    if (t == 63) break;
+                    avail = ~cur & ~kb & ~((2ULL << t) - 1ULL);
+                }
+                if ((kb >> lane) & 1ULL) {
+                    const int pos = count + __popcll(kb & ((1ULL << lane) - 1ULL));
+                    keep[pos] = c * 64 + lane;
+                    kept[pos] = c * 64 + lane;
+                }
+            }
+            if (lane == 0) kbits[grp] = kb;
+        }
+        lds_barrier();
+        const u64 kb = kbits[grp];
+        hist[2] = hist[1];
+        hist[1] = hist[0];
+        hist[0] = kb;
+        count += __popcll(kb);
+        slot = slot + 1 == SCAN_D ? 0 : slot + 1;
+        if (PAIR == 2) {
+            both += __popcll(kbits[0] & kbits[1]);
+            if (stop_after > 0 && both >= stop_after) break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no DMA may outlive the workgroup's LDS
+    if (gt == 0) num_out[prob] = count;
 }
 
+template <int PAIR>
+static void launch_scan(const u64 *mask, const u64 *zero_word, int nb, int n, int cb, const int *n_valid, int *keep_out,
+                        int *num_out, int stop_after, hipStream_t st)
+{
+    static size_t configured = 0;
+    const size_t lds = (size_t)PAIR * 5 * sizeof(u64) + (size_t)PAIR * SCAN_RING * sizeof(unsigned) +
+                       (size_t)PAIR * n * sizeof(int);
+    auto *k = greedy_scan_kernel<PAIR>;
+    if (lds > 48 * 1024 && lds > configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k, dim3(nb / PAIR), dim3(SCAN_T * PAIR), lds, st, mask, zero_word, n, cb, n_valid, keep_out,
+                       num_out, stop_after);
+}
+
+// paired != 0: problems (2b, 2b+1) are scanned together and stop once their keep lists share `stop_after` boxes
 static int launch_nms(int *keep_out, const float *dets, int *num_out, const int *n_valid, int nb, int n,
-                      int dim, float thresh, void *ws, size_t ws_bytes, hipStream_t st)
+                      int dim, float thresh, void *ws, size_t ws_bytes, hipStream_t st, int paired = 0,
+                      int stop_after = 0)
 {
     SRCNN_REQUIRE(nb >= 0 && n >= 0 && dim >= 4, "bad sizes");
     SRCNN_REQUIRE(n <= 64 * 64 * 4, "n > 16384 boxes per problem not supported");
+    SRCNN_REQUIRE(!paired || nb % 2 == 0, "paired NMS needs an even number of problems");
     if (nb == 0) return SRCNN_OK;
     if (n == 0) {
         SRCNN_HIP_TRY(hipMemsetAsync(num_out, 0, sizeof(int) * nb, st));
         return SRCNN_OK;
     }
     const int cb = cdiv(n, 64);
-    const size_t need = (size_t)nb * n * cb * sizeof(unsigned long long);
+    const size_t words = (size_t)nb * n * cb;                       // + one zero word behind the mask
+    const size_t need = (words + 1) * sizeof(unsigned long long);
     if (ws == nullptr || ws_bytes < need) {
         set_error("nms: workspace too small (%zu < %zu)", ws_bytes, need);
         return SRCNN_ERR_WORKSPACE;
     }
+    SRCNN_REQUIRE((size_t)(paired ? 2 : 1) * (SCAN_RING + (size_t)n) * 4 + 128 <= 160 * 1024, "n too large for the LDS kept list");
     auto *mask = static_cast<unsigned long long *>(ws);
-    hipLaunchKernelGGL(pair_mask_kernel, dim3(cb, cb, nb), dim3(64), 0, st, dets, n, dim, thresh, mask, cb);
-    const int waves = cdiv(cb, 64);                    // <= 4 (n <= 16384)
-    hipLaunchKernelGGL(greedy_scan_kernel, dim3(nb), dim3(64 * waves), 0, st, mask, n, cb, n_valid, keep_out, num_out);
+    hipLaunchKernelGGL(pair_mask_kernel, dim3(cb, cb, nb), dim3(64), 0, st, dets, n, dim, thresh, mask, cb, mask + words);
+    if (paired) launch_scan<2>(mask, mask + words, nb, n, cb, n_valid, keep_out, num_out, stop_after, st);
+    else launch_scan<1>(mask, mask + words, nb, n, cb, n_valid, keep_out, num_out, 0, st);
     return check_launch("nms");
+}
+
+int nms_pairs_until(int *keep_out, const float *dets, int *num_out, const int *n_valid, int nb, int n, int dim,
+                    float thresh, void *ws, size_t ws_bytes, int stop_after, hipStream_t st)
+{
+    return launch_nms(keep_out, dets, num_out, n_valid, nb, n, dim, thresh, ws, ws_bytes, st, 1, stop_after);
 }
 
 // library-owned scratch for the legacy-named entry point
@@ -164,13 +341,13 @@ extern "C" {
 size_t srcnn_nms_workspace_bytes(int n)
 {
     if (n <= 0) return 256;
-    return srcnn::align_up((size_t)n * srcnn::cdiv(n, 64) * 8, 256);
+    return srcnn::align_up((size_t)n * srcnn::cdiv(n, 64) * 8 + 8, 256);
 }
 
 size_t srcnn_nms_batched_workspace_bytes(int nb, int n)
 {
     if (n <= 0 || nb <= 0) return 256;
-    return srcnn::align_up((size_t)nb * n * srcnn::cdiv(n, 64) * 8, 256);
+    return srcnn::align_up((size_t)nb * n * srcnn::cdiv(n, 64) * 8 + 8, 256);
 }
 
 int srcnn_nms(int *keep_out, const float *dets, int *num_out, int n, int dim, float thresh, void *workspace,

@@ -9,11 +9,11 @@
 // device launches with no host synchronisation:
 //   1. tk_* kernels         exact top-K by (score desc, index asc): chip-wide radix select on the
 //                           order-preserving score key, tie-break select on the index, compaction
-//                           and an in-LDS bitonic sort of the K survivors.
+//                           and a chip-wide rank sort of the K survivors.
 //                           == torch.sort(descending, stable)[:K]  (proposal_layer.py:96,111-115)
 //   2. gather_decode_kernel anchors recomputed analytically in float64 (bit-equal to the
 //                           numpy anchors cast to float32), left/right decode + clip.
-//   3-4. batched NMS        (nms.hip) over 2*B problems.
+//   3-4. batched NMS        (nms.hip) over 2*B problems, left/right in lockstep with joint early exit.
 //   5. intersect_pad_kernel sorted-set intersection, first `post` rows, zero padding.
 #include "common.h"
 
@@ -64,7 +64,7 @@ constexpr int TK_BINS = 2048;      // 11-bit radix digits
 //         -> tk_pick (one wave walks the 2048 bins from the top) }     -> key T of the K-th score
 //   2 x { tk_hist on the INDEX digits of the elements with key == T -> tk_pick from the bottom }
 //         (skipped on the device when every tie is taken)              -> largest tie index taken
-//   tk_compact (grid-wide, wave-aggregated append)  ->  tk_sort (in-LDS bitonic sort of <= 8192 keys)
+//   tk_compact (grid-wide, wave-aggregated append)  ->  tk_rank (chip-wide rank sort of the <= 8192 unique keys)
 struct TkState {
     unsigned prefix, remaining, ties, T, iprefix, idx_limit, need_tb, count;
 };
@@ -177,31 +177,36 @@ __global__ __launch_bounds__(256) void tk_compact_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(1024) void tk_sort_kernel(const unsigned long long *__restrict__ cand_in, int cap, int ksel,
+// Rank sort of the selected candidates on the whole chip: keys are unique (the low word holds the anchor index), so
+// the rank of a key = the number of keys greater than it.  A workgroup stages all keys in LDS and ranks 64 of them:
+// 16 threads per key, each counting over an interleaved 1/16 of the keys (conflict-free 16 x 8-byte LDS reads,
+// broadcast across the four keys of a wavefront), then a 4-step shuffle reduction.  Descending key order =
+// descending score, ascending index among ties (the stable order of proposal_layer.py:107).
+__global__ __launch_bounds__(1024) void tk_rank_kernel(const unsigned long long *__restrict__ cand_in, int cap, int ksel,
                                                        int K, int *__restrict__ order_out)
 {
-    __shared__ unsigned long long cand[TK_MAXK];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    int np = 1;
-    while (np < ksel) np <<= 1;
+    __shared__ unsigned long long keys[TK_MAXK];
+    const int b = blockIdx.y, tid = threadIdx.x;
     const unsigned long long *in = cand_in + (size_t)b * cap;
-    for (int i = tid; i < np; i += 1024) cand[i] = i < ksel ? in[i] : 0ULL;
+    for (int i = tid; i < ksel; i += 1024) keys[i] = in[i];
     __syncthreads();
-    for (int k = 2; k <= np; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = cand[i], c = cand[ixj];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (a < c) : (a > c)) { cand[i] = c; cand[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    const int sub = tid & 15, mi = blockIdx.x * 64 + (tid >> 4);
+    const unsigned long long mine = mi < ksel ? keys[mi] : ~0ULL;
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    int j = sub;
+    for (; j + 48 < ksel; j += 64) {
+        r0 += keys[j] > mine;
+        r1 += keys[j + 16] > mine;
+        r2 += keys[j + 32] > mine;
+        r3 += keys[j + 48] > mine;
     }
-    for (int i = tid; i < ksel; i += 1024)
-        order_out[(size_t)b * K + i] = (int)(0xFFFFFFFFu - (unsigned)(cand[i] & 0xFFFFFFFFULL));
+    for (; j < ksel; j += 16) r0 += keys[j] > mine;
+    int rank = r0 + r1 + r2 + r3;
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    rank += __shfl_xor(rank, 4);
+    rank += __shfl_xor(rank, 8);
+    if (sub == 0 && mi < ksel) order_out[(size_t)b * K + rank] = (int)(0xFFFFFFFFu - (unsigned)(mine & 0xFFFFFFFFULL));
 }
 
 // ------------------------------------------------------------------ anchors + decode + clip
@@ -428,14 +433,15 @@ int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num
                                num_anchors);
         }
         hipLaunchKernelGGL(tk_compact_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, cand, TK_MAXK);
-        hipLaunchKernelGGL(tk_sort_kernel, dim3(B), dim3(1024), 0, st, cand, TK_MAXK, ksel, n, order);
+        hipLaunchKernelGGL(tk_rank_kernel, dim3(cdiv(ksel, 64), B), dim3(1024), 0, st, cand, TK_MAXK, ksel, n, order);
     }
     hipLaunchKernelGGL(gather_decode_kernel, dim3(cdiv(B * n, 256)), dim3(256), 0, st, probs, deltas, num_anchors, B,
                        n, n, order, lt, im_info, dets);
     int rc = check_launch("proposal: select/decode");
     if (rc != SRCNN_OK) return rc;
-    rc = srcnn_nms_batched(keep, dets, num, nullptr, 2 * B, n, 5, nms_thresh, ws + L.nms,
-                           workspace_bytes - L.nms, stream);
+    // left/right problems of an image scanned in lockstep; stop once `post_nms` boxes survive in both
+    rc = nms_pairs_until(keep, dets, num, nullptr, 2 * B, n, 5, nms_thresh, ws + L.nms, workspace_bytes - L.nms,
+                         post_nms, st);
     if (rc != SRCNN_OK) return rc;
     hipLaunchKernelGGL(intersect_pad_kernel, dim3(B), dim3(1024), 0, st, keep, num, dets, n, post_nms, rois_left,
                        rois_right, num_valid);

@@ -100,11 +100,19 @@ PRECISION = 'f32'     # default engine: 'f32' (exact fp32 MFMA) or 'f16x3' (3-te
 # once on the device it runs on over the legal (tile, split-K) plans; the winner is cached.
 AUTOTUNE = True
 _TUNED = {}
-_CANDIDATES = [(2, 2), (2, 1), (1, 2), (1, 1)]
+_TUNE_LOG = {}       # key -> [(plan, ms)] of the last tuning run (dev tools print it)
+# (tile_mr, tile_nr, waves, stages): workgroup tile (64*mr) x (64*nr), wavefronts, LDS ring depth
+_CANDIDATES = [(2, 2, 4, 2), (2, 1, 4, 2), (1, 2, 4, 2), (1, 1, 4, 2)]
+# extra variants of the SPLIT16 engine (csrc/conv_f16s.hip): 8-wave tiles and deeper DMA rings
+_CANDIDATES_F16S = [(4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
 
 
 def _shape_key(cw, B, H, W, OH, OW, x_cstride, precision, fmts=(0, 0, 0)):
     return (precision, B, H, W, OH, OW, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, cw.mode, x_cstride) + tuple(fmts)
+
+
+def _set_plan(d, plan):
+    d.tile_mr, d.tile_nr, d.tile_waves, d.tile_stages, d.splits = plan
 
 
 def _tune(d, key, device):
@@ -115,24 +123,26 @@ def _tune(d, key, device):
     cands = []
     tiles = list(_CANDIDATES)
     if d.precision == 1 and d.x_format == 1:
-        tiles.insert(0, (4, 2))          # 128x128 tile on 8 wavefronts (csrc/conv_f16s.hip, WM = 4)
-    for mr, nr in tiles:
+        tiles = _CANDIDATES_F16S + tiles
+    for mr, nr, waves, stages in tiles:
         if nr == 2 and d.Cout <= 64:
             continue
-        if mr == 2 and M <= 64:
+        if mr >= 2 and M <= 64 * (mr // 2):
             continue
-        blocks = -(-M // (128 if mr == 4 else 64 * mr)) * -(-d.Cout // (64 * nr))
+        blocks = -(-M // (64 * mr)) * -(-d.Cout // (64 * nr))
         splits = [1]
         if d.mode == 0:
             for s in (2, 3, 4, 6, 8, 12, 16):
                 if blocks * s <= 4096 and nkt // s >= 4 and blocks < 1024:
                     splits.append(s)
         for s in splits:
-            cands.append((mr, nr, s))
-    best, best_t = (0, 0, 0), None
+            cands.append((mr, nr, waves, stages, s))
+    best, best_t = (0, 0, 0, 0, 0), None
+    log = _TUNE_LOG.setdefault(key, [])
+    del log[:]
     st = _lib.stream()
-    for mr, nr, s in cands:
-        d.tile_mr, d.tile_nr, d.splits = mr, nr, s
+    for plan in cands:
+        _set_plan(d, plan)
         need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
         ws = _lib.workspace(need, device, "conv")
         t_best = None
@@ -145,8 +155,9 @@ def _tune(d, key, device):
             t = e0.elapsed_time(e1)
             if rep > 0 and (t_best is None or t < t_best):
                 t_best = t
+        log.append((plan, t_best))
         if best_t is None or t_best < best_t:
-            best, best_t = (mr, nr, s), t_best
+            best, best_t = plan, t_best
     _TUNED[key] = best
     return best
 
@@ -186,10 +197,10 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         plan = _TUNED.get(key)
         if plan is None:
             if torch.cuda.is_current_stream_capturing():
-                plan = (0, 0, 0)          # never time inside a graph capture; warm-up runs tune first
+                plan = (0, 0, 0, 0, 0)    # never time inside a graph capture; warm-up runs tune first
             else:
                 plan = _tune(d, key, x.device)
-        d.tile_mr, d.tile_nr, d.splits = plan
+        _set_plan(d, plan)
     need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _lib.workspace(need, x.device, "conv")
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")

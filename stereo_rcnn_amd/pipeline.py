@@ -45,7 +45,8 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
             solved.append({'box_left': dets_left[i, 0:4].copy(), 'box_right': dets_right[i, 0:4].copy(),
                            'score': float(dets_left[i, 4]), 'dim': dim.astype(np.float64), 'alpha': alpha,
                            'xyz': np.array(state[0:3], dtype=np.float64), 'theta': float(state[3]),
-                           'kpts': kpts[i].copy(), 'aligned': False})
+                           'kpts': kpts[i].copy(), 'aligned': False,
+                           'xyz_init': np.array(state[0:3], dtype=np.float64)})   # 4-DoF solve, before alignment
     if not solved or not dense_align:
         return solved
     dev = im_left_data.device

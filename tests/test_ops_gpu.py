@@ -186,6 +186,31 @@ def test_conv_engine_vs_torch_cpu(dev, case, precision):
     _conv_case(dev, *case, seed=hash(case) % 1000, precision=precision)
 
 
+@pytest.mark.parametrize("plan", [
+    # (tile_mr, tile_nr, waves, stages, splits): every SPLIT16 kernel instantiation, with and without split-K
+    (1, 1, 4, 2, 1), (1, 1, 4, 4, 1), (1, 1, 4, 4, 3), (2, 1, 4, 2, 1), (2, 1, 4, 3, 2), (1, 2, 4, 2, 1), (1, 2, 4, 3, 1),
+    (2, 2, 4, 2, 2), (2, 2, 8, 2, 1), (2, 2, 8, 4, 1), (2, 2, 8, 4, 9), (4, 2, 8, 3, 1), (4, 2, 8, 3, 4),
+])
+@pytest.mark.parametrize("case", [
+    (2, 23, 37, 96, 200, 3, 1, 1, True, True, True),      # ragged M (1702) and N (200) tails, image-border taps
+    (1, 9, 11, 64, 264, 1, 1, 0, False, False, False),    # K = 2 tiles: shorter than the deepest DMA ring
+    (1, 12, 40, 32, 64, 1, 1, 0, True, False, True),      # K = 1 tile
+])
+def test_conv_f16s_every_plan(dev, plan, case):
+    """Forces each launch plan of the DMA-ring kernel (csrc/conv_f16s.hip) instead of the autotuned one."""
+    from stereo_rcnn_amd import engine
+    saved_tuned, saved_flag = dict(engine._TUNED), engine.AUTOTUNE
+
+    class Forced(dict):
+        def get(self, key, default=None):
+            return plan
+    engine._TUNED = Forced()
+    try:
+        _conv_case(dev, *case, seed=11, precision='f16s')
+    finally:
+        engine._TUNED, engine.AUTOTUNE = saved_tuned, saved_flag
+
+
 @pytest.mark.parametrize("precision", ['f32', 'f16x3'])
 def test_conv_stem_vs_torch_cpu(dev, precision):
     from stereo_rcnn_amd import engine

@@ -52,4 +52,10 @@ for name, B, H, W, cin, cout, k, s, p in SHAPES:
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * B * OH * OW * cout * cin * k * k
     plan = [v for kk, v in engine._TUNED.items() if kk[0] == PREC][-1] if engine._TUNED else None
-    print('%-34s M=%7d N=%5d K=%6d  %8.3f ms  %7.1f TFLOP/s  plan(mr,nr,splits)=%s' % (name, B * OH * OW, cout, cin * k * k, ms, fl / ms / 1e9, plan), flush=True)
+    print('%-34s M=%7d N=%5d K=%6d  %8.3f ms  %7.1f TFLOP/s  plan(mr,nr,waves,stages,splits)=%s' % (name, B * OH * OW, cout, cin * k * k, ms, fl / ms / 1e9, plan), flush=True)
+    if os.environ.get('SWEEP'):
+        log = sorted(list(engine._TUNE_LOG.values())[-1], key=lambda e: e[1])
+        best_per_tile = {}
+        for pl, t in log:
+            best_per_tile.setdefault(pl[:4], (pl[4], t))
+        print('      ' + '  '.join('%s/s%d:%.0fTF' % (''.join(map(str, tl)), sp, fl / t / 1e9) for tl, (sp, t) in best_per_tile.items()), flush=True)
