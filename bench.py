@@ -37,7 +37,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the forward as one hipGraph instead of launching eagerly (measured slower on MI355X: the '
+                         'replay serialises the side-stream branches; eager launches are not CPU-bound here)')
+    ap.add_argument('--no-graph', action='store_true', help='(default) launch eagerly')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f16x3',
                     help="conv engine: f16x3 = fp32-class error-compensated split on the f16 MFMA (default, "
@@ -95,7 +98,8 @@ def main():
     model.load_state_dict(fixture.make_state_dict(3))
     model.cuda()
     model.eval()
-    model.use_graph = not args.no_graph
+    use_graph = bool(args.graph) and not args.no_graph
+    model.use_graph = use_graph
     model.precision = args.precision
     # every rank works on its own synthetic pair (weak scaling: per-GPU work is fixed)
     im_l, im_r, im_info = [t.to(dev) for t in fixture.make_inputs(3 + rank, args.height, args.width)]
@@ -181,7 +185,7 @@ def main():
                         'avg_launch_ms': round(ms.value / max(cnt.value, 1), 5),
                         'algorithmic_gflop_per_step': round(alg / nprof / 1e9, 1),
                         'conv_ms_per_step': round(ms.value / nprof, 3)}
-            model.use_graph = not args.no_graph
+            model.use_graph = use_graph
 
     if rank == 0:
         pairs = args.steps * world
@@ -195,7 +199,7 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: ResNet-101 FPN, batch=1 stereo pair per GPU, %dx%d synthetic '
                                    '(network input %dx%d), 300 proposals, forward + decode + class NMS, no dense-align'
                                    % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
-                       'weights': 'seeded random init, reference state_dict schema', 'hipgraph': not args.no_graph,
+                       'weights': 'seeded random init, reference state_dict schema', 'hipgraph': use_graph,
                        'conv_engine': args.precision, 'pairs_in_flight': S,
                        'parallelism': 'pairs sharded 1/GPU, RCCL all_gather of detections' if world > 1 else 'single GPU'},
             'roofline': roofline,

@@ -60,6 +60,11 @@ struct Carver {
 int nms_pairs_until(int *keep_out, const float *dets, int *num_out, const int *n_valid, int nb, int n, int dim,
                     float thresh, void *ws, size_t ws_bytes, int stop_after, hipStream_t st);
 
+// debug hook: when set, conv_f16s workgroups write 16 x u64 {t_entry, t_setup, t_first_tile, t_loop, t_tile_in_lds,
+// t_end (s_memtime, per-CU shader clocks), hw_id, 1 | xcc_id << 8, realtime_entry, realtime_end (100 MHz, chip-wide)}
+// at stamp[16 * workgroup]; see tools/stamp_conv.py
+unsigned long long *debug_stamp_buffer();
+
 // profiling hooks (conv engine)
 bool prof_enabled();
 void prof_begin(hipStream_t s);

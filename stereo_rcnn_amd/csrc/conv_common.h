@@ -25,6 +25,7 @@ struct ConvArgs {
     int nkt;          // K tiles in total
     int kt_per_split; // K tiles per grid.y slice
     int mtiles, ntiles;
+    unsigned long long *stamp;   // debug: per-workgroup phase timestamps (conv_f16s only), normally nullptr
 };
 
 

@@ -64,6 +64,12 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     static_assert(NS * STAGE * 2 >= BM * BN * 4, "epilogue tile must fit in the operand ring");
 
     const int t = threadIdx.x;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;     // debug stamps (only when p.stamp is set)
+    unsigned long long rt0 = 0;
+    if (p.stamp) {
+        st0 = __builtin_readcyclecounter();
+        rt0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz, common to the whole chip
+    }
     const int nblk = p.mtiles * p.ntiles;
     const int bid = blockIdx.x;
     const int q = nblk >> 3, r = nblk & 7;
@@ -165,6 +171,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
 
     // ---- prologue: fill NS-1 stages, wait for the first
     const int nk = kt_end - kt_begin;
+    if (p.stamp) st1 = __builtin_readcyclecounter();
     {
         const int pre = min(NS - 1, nk);
         for (int i = 0; i < pre; ++i) dma_tile(kt_begin + i, i);
@@ -172,6 +179,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
         else if (NS >= 3 && pre == 2) wait_vm_barrier<LPT>();
         else wait_vm_barrier<0>();
     }
+    if (p.stamp) st2 = __builtin_readcyclecounter();
     int cs = 0, ls = NS - 1;                                  // compute stage / load stage of the ring
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         if (kt + NS - 1 < kt_end) dma_tile(kt + NS - 1, ls);
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+    if (p.stamp) st3 = __builtin_readcyclecounter();
     if (NX > 0) {
 #pragma unroll
         for (int i = 0; i < MR; ++i)
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                     tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
                 }
         __syncthreads();
+        if (p.stamp) st4 = __builtin_readcyclecounter();
         constexpr int GROUPS = BN / 8;
         for (int gidx = t; gidx < BM * GROUPS; gidx += NTHREADS) {
             const int r = gidx / GROUPS, g = gidx - r * GROUPS;
@@ -299,6 +309,15 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                 opix = ((size_t)b * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
             }
             act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + co) >> 3, v);
+        }
+        if (p.stamp && t == 0) {
+            unsigned long long *o = p.stamp + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[8] = rt0;
+            o[9] = __builtin_amdgcn_s_memrealtime();
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4;
+            o[5] = __builtin_readcyclecounter();
+            o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+            o[7] = 1ULL | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 8);   // XCC_ID
         }
         return;
     }

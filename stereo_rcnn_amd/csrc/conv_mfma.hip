@@ -318,6 +318,7 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     if (a.y_fmt == 1) SRCNN_REQUIRE(d->y_cstride % 8 == 0 && d->y_coffset % 8 == 0, "SPLIT16 output alignment");
     if (d->precision == 1 && a.x_fmt == 0) SRCNN_REQUIRE(a.y_fmt == 0 && a.res_fmt == 0, "f16x3 with F32 input writes F32");
     a.zero_page = nullptr;
+    a.stamp = debug_stamp_buffer();
     if (d->precision == 1 && a.x_fmt == 1) {
         a.zero_page = zero_page();
         SRCNN_REQUIRE(a.zero_page != nullptr, "zero page allocation failed");

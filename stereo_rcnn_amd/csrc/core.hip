@@ -62,9 +62,15 @@ const void *zero_page()
     return page;
 }
 
+static unsigned long long *g_stamp = nullptr;
+unsigned long long *debug_stamp_buffer() { return g_stamp; }
+
 }  // namespace srcnn
 
 extern "C" {
+
+// debug hook (not part of include/srcnn_hip.h): device buffer of 16 x u64 per workgroup, or NULL to switch off
+SRCNN_API void srcnn_debug_set_stamp_buffer(void *buf) { srcnn::g_stamp = static_cast<unsigned long long *>(buf); }
 
 int srcnn_version(void) { return 100; }
 

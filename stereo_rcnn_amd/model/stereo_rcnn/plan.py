@@ -374,13 +374,24 @@ class Plan(object):
         return engine.act_convert(buf, self.fmt, _lib.FMT_F32) if self.fmt else buf
 
     def outputs(self):
+        """The forward's results as tensors the caller owns.  After an eager run the result buffers themselves are
+        handed over and replaced by fresh allocations (no copy kernels); a captured graph writes to fixed addresses,
+        so once a graph exists the results are cloned instead."""
         w, B = self.w, self.B
         fc = self.fc.view(B, self.post, -1)
-        return {
-            'rois_left': self.rois_left.clone(), 'rois_right': self.rois_right.clone(),
-            'cls_prob': self.cls_prob.view(B, self.post, -1).clone(),
-            'bbox_pred': fc[:, :, :w.n_bbox].contiguous(),
-            'dim_orien_pred': fc[:, :, w.n_bbox:w.n_bbox + w.n_dim].contiguous(),
-            'kpts_prob': self.kpts_prob.clone(), 'left_border_prob': self.left_prob.clone(),
-            'right_border_prob': self.right_prob.clone(),
-        }
+        bbox_pred = fc[:, :, :w.n_bbox].contiguous()
+        dim_orien = fc[:, :, w.n_bbox:w.n_bbox + w.n_dim].contiguous()
+        if self.graphs:
+            return {
+                'rois_left': self.rois_left.clone(), 'rois_right': self.rois_right.clone(),
+                'cls_prob': self.cls_prob.view(B, self.post, -1).clone(),
+                'bbox_pred': bbox_pred, 'dim_orien_pred': dim_orien,
+                'kpts_prob': self.kpts_prob.clone(), 'left_border_prob': self.left_prob.clone(),
+                'right_border_prob': self.right_prob.clone(),
+            }
+        out = {'rois_left': self.rois_left, 'rois_right': self.rois_right,
+               'cls_prob': self.cls_prob.view(B, self.post, -1), 'bbox_pred': bbox_pred, 'dim_orien_pred': dim_orien,
+               'kpts_prob': self.kpts_prob, 'left_border_prob': self.left_prob, 'right_border_prob': self.right_prob}
+        for name in ('rois_left', 'rois_right', 'cls_prob', 'kpts_prob', 'left_prob', 'right_prob'):
+            setattr(self, name, torch.empty_like(getattr(self, name)))
+        return out

@@ -53,7 +53,7 @@ def test_detect_3d_matches_oracle_pipeline(dev):
     if ddis_same:
         assert np.median(ddis_same) < 2e-3
     if ddis_other:
-        assert max(ddis_other) < 12.5 + 1.0                             # coarse search bracket: 50 x 0.5 m around the solve
+        assert np.median(ddis_other) < 1.0          # each side searches +-12.5 m around ITS solve: only typical agreement is checkable
 
 
 def test_write_kitti_results(dev, tmp_path):
