@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 PEAKS = {'f32': 157.3, 'f16x3': 2500.0}
 ENGINE_DESC = {
     'f32': 'conv_mfma_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32, exact fp32)',
-    'f16x3': 'conv_f16x3_kernel (implicit-GEMM conv, 3x v_mfma_f32_32x32x16_f16 error-compensated split, fp32 accumulate)',
+    'f16x3': 'conv_f16s_kernel (implicit-GEMM conv, both operands DMA-ed to LDS, 3x v_mfma_f32_32x32x16_f16 '
+             'error-compensated split, fp32 accumulate)',
 }
 
 

@@ -1,0 +1,35 @@
+"""Sums rocprofv3 --pmc counters per kernel family over the steady-state bench steps (dev tool).
+
+    python tools/pmc_sum.py <dir with pass*/ or <COUNTER>/ sub-directories>  [skip_first_steps]
+Counts steps by stem_pack_kernel launches (2 per step); the first `skip` steps (autotuning, warm-up) are dropped.
+"""
+import collections, csv, glob, os, sys
+
+root = sys.argv[1]
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+res = collections.defaultdict(lambda: collections.defaultdict(float))
+steps_seen = {}
+for f in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True)):
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    step, seen = -1, set()
+    for r in rows:
+        name = r['Kernel_Name']
+        if 'stem_pack' in name and r['Dispatch_Id'] not in seen:
+            # two stem_pack launches per step: count pairs
+            seen.add(r['Dispatch_Id'])
+            if len(seen) % 2 == 1:
+                step += 1
+        if step < skip:
+            continue
+        short = name.replace('void ', '').replace('srcnn::', '')
+        short = short[:short.index('(')] if '(' in short else short
+        fam = 'conv engine' if short.startswith('conv_') else ('splitk_reduce' if 'splitk' in short else 'other')
+        res[r['Counter_Name']][fam] += float(r['Counter_Value'])
+        res[r['Counter_Name']]['all kernels'] += float(r['Counter_Value'])
+    steps_seen[f] = step + 1 - skip
+    for c in set(r['Counter_Name'] for r in rows):
+        res[c]['_steps'] = max(res[c]['_steps'], step + 1 - skip)
+for c in sorted(res):
+    n = max(res[c]['_steps'], 1)
+    print('%-28s (%d steps): ' % (c, n) + '  '.join('%s=%.6g' % (k, v / n) for k, v in sorted(res[c].items()) if k != '_steps'))
