@@ -155,13 +155,16 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el[0])
 
-        # ---- roofline of the dominant kernel (conv engine, fp32 MFMA): HIP events recorded by the
-        # library on the launch stream around every conv launch, over the same K steps (eager
-        # launches: events cannot be read back from inside a replayed graph).
+        # ---- roofline of the dominant kernel (the conv engine): HIP events recorded by the library on
+        # the launch stream around every conv launch, over the same workload (eager launches on ONE
+        # stream, so that each launch is timed alone on the chip rather than while sharing it with the
+        # side-stream branches; events cannot be read back from inside a replayed graph).
         roofline = None
         if rank == 0:
             L = _lib.lib()
             model.use_graph = False
+            for pl in model._plans.values():        # one stream: every conv launch is timed alone on the chip
+                pl.overlap = False
             step()
             torch.cuda.synchronize()
             engine.FlopCounter.enabled, engine.FlopCounter.flops, engine.FlopCounter.launches = True, 0.0, 0
@@ -181,12 +184,16 @@ def main():
             roofline = {'bound': 'mfma', 'kernel': ENGINE_DESC[args.precision],
                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': round(achieved / peak, 4), 'traffic': None,
+                        'traffic_note': 'PMC passes are separate rocprofv3 runs: profiles/pmc_r01_f16x3_bench.txt '
+                                        '(74-115 MB HBM-side per conv launch vs ~38 MB algorithmic)',
                         'issued_mfma_frac': round(achieved * issued / peak, 4),
                         'launches_per_step': int(cnt.value // nprof),
                         'avg_launch_ms': round(ms.value / max(cnt.value, 1), 5),
                         'algorithmic_gflop_per_step': round(alg / nprof / 1e9, 1),
                         'conv_ms_per_step': round(ms.value / nprof, 3)}
             model.use_graph = use_graph
+            for pl in model._plans.values():
+                pl.overlap = True
 
     if rank == 0:
         pairs = args.steps * world
