@@ -5,10 +5,12 @@ batch=1, 300 proposals, no dense-align  (BASELINE.json configs[1]).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one pass of the hot path over one synthetic stereo pair per GPU:
+One step = one pass of the hot path over one synthetic stereo pair per GPU (batch = 1 per forward; by default two
+forwards are in flight per GPU on separate HIP streams, `--streams 1` = strictly sequential, also reported):
   _StereoRCNN.forward (trunk+FPN on both eyes, stereo RPN, proposals, ROIAlign, heads)
   + detection decode + per-class NMS  (the reference's det_time region, demo.py:137-220, plus :231-257)
-  + (N > 1) an RCCL all_gather of the fixed-size detection record.
+  + (under torch.distributed.run) the detection record of every step packed on the device and gathered over RCCL/xGMI,
+    one all_gather per `--gather-every` steps on a side stream (all of them inside the timed region).
 Inputs are preprocessed and resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -46,8 +48,12 @@ def parse():
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f16x3',
                     help="conv engine: f16x3 = fp32-class error-compensated split on the f16 MFMA (default, "
                          "passes the same parity tests), f32 = exact fp32 MFMA")
-    ap.add_argument('--streams', type=int, default=1,
-                    help='stereo pairs in flight per GPU: each on its own HIP stream and buffer set, batch=1 each')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='stereo pairs in flight per GPU: each forward is batch=1 on its own HIP stream and buffer set '
+                         '(default 2: the second pair fills the launch-synchronous phases of the small layers); '
+                         '--streams 1 = strictly one pair at a time (also reported as one_pair_at_a_time)')
+    ap.add_argument('--gather-every', type=int, default=8,
+                    help='(multi-GPU) steps whose detection records share one RCCL all_gather')
     ap.add_argument('--height', type=int, default=375)
     ap.add_argument('--width', type=int, default=1242)
     return ap.parse_args()
@@ -109,17 +115,49 @@ def main():
     S = max(1, args.streams)
     streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [None]
 
-    def step(slot=0):
+    # detections of G consecutive steps are packed into one buffer and gathered by ONE RCCL all_gather
+    # (two buffers alternate so that a gather in flight on the side stream never races the next writes)
+    G = max(1, args.gather_every)
+    n_rec = 300 + 1
+    rec_bufs = [torch.zeros((G, n_rec, sdist.REC_COLS), device=dev) for _ in range(2)] if use_dist else None
+    gather_done = [None, None]
+    st = {'k': 0}
+
+    def compute_streams():
+        cur = torch.cuda.current_stream()
+        return [cur] + [x for x in streams if x is not None and x != cur]
+
+    def flush(b):
+        for cs in compute_streams():
+            gather_stream.wait_stream(cs)
+        with torch.cuda.stream(gather_stream):          # xGMI gather overlaps the following pairs' forwards
+            sdist.gather_detections(rec_bufs[b])
+            ev = torch.cuda.Event()
+            ev.record(gather_stream)
+            gather_done[b] = ev
+
+    def step(slot=0, gather=True):
+        """gather=False: no collective (the rank-0-only roofline pass must not enter an all_gather alone)"""
         out = model(im_l, im_r, im_info, slot=slot)
         det = hpost.decode_detections(out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], im_info)
         keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
-        if use_dist:
-            rec = sdist.pack_records_device(det, keep_idx, num, 1)
-            gather_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(gather_stream):      # xGMI gather overlaps the next pair's trunk
-                rec.record_stream(gather_stream)
-                sdist.gather_detections(rec)
+        if use_dist and gather:
+            k = st['k']
+            b, row = (k // G) % 2, k % G
+            if row == 0 and gather_done[b] is not None:
+                for cs in compute_streams():
+                    cs.wait_event(gather_done[b])
+            sdist.pack_records_device(det, keep_idx, num, 1, out=rec_bufs[b][row])
+            st['k'] = k + 1
+            if row == G - 1:
+                flush(b)
         return keep_idx, num
+
+    def finish_gathers():
+        """gather the partially filled buffer of the last steps"""
+        if use_dist and st['k'] % G:
+            flush((st['k'] // G) % 2)
+            st['k'] += G - st['k'] % G
 
     with torch.no_grad():
         def run_steps(n):
@@ -139,12 +177,14 @@ def main():
                     step(slot)
                 torch.cuda.synchronize()
         run_steps(max(args.warmup, 1))
+        finish_gathers()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(args.steps)
+        finish_gathers()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -154,6 +194,28 @@ def main():
         if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el[0])
+
+        # the same K steps strictly one pair at a time (reported next to the headline when S > 1)
+        single = None
+        if S > 1:
+            step(0)
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step(0)
+            finish_gathers()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            e1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(e1, op=dist.ReduceOp.MAX)
+            single = {'value': round(args.steps * world / float(e1[0]), 3), 'unit': 'stereo pairs/s',
+                      'ms_per_step': round(float(e1[0]) / args.steps * 1e3, 3)}
 
         # ---- roofline of the dominant kernel (the conv engine): HIP events recorded by the library on
         # the launch stream around every conv launch, over the same workload (eager launches on ONE
@@ -165,13 +227,13 @@ def main():
             model.use_graph = False
             for pl in model._plans.values():        # one stream: every conv launch is timed alone on the chip
                 pl.overlap = False
-            step()
+            step(gather=False)
             torch.cuda.synchronize()
             engine.FlopCounter.enabled, engine.FlopCounter.flops, engine.FlopCounter.launches = True, 0.0, 0
             L.srcnn_prof_enable(1)
             nprof = min(args.steps, 5)
             for _ in range(nprof):
-                step()
+                step(gather=False)
             torch.cuda.synchronize()
             ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
             L.srcnn_prof_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
@@ -208,8 +270,8 @@ def main():
                                    '(network input %dx%d), 300 proposals, forward + decode + class NMS, no dense-align'
                                    % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
                        'weights': 'seeded random init, reference state_dict schema', 'hipgraph': use_graph,
-                       'conv_engine': args.precision, 'pairs_in_flight': S,
-                       'parallelism': 'pairs sharded 1/GPU, RCCL all_gather of detections' if world > 1 else 'single GPU'},
+                       'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single,
+                       'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},
             'roofline': roofline,
         }
         if not args.no_cpu_baseline:

@@ -35,15 +35,17 @@ def pack_records(cls_det, max_det=300):
     return rec
 
 
-def pack_records_device(det, keep_idx, num, j=1):
+def pack_records_device(det, keep_idx, num, j=1, out=None):
     """Same record, built on the device by one native launch from the -1 padded keep list, no host sync
-    (det: postprocess.decode_detections; keep_idx/num: postprocess.class_nms_device).  CPU tensors (the gloo
-    tests) take an equivalent torch path."""
+    (det: postprocess.decode_detections; keep_idx/num: postprocess.class_nms_device).  `out`: optional
+    (n + 1, REC_COLS) float32 destination, e.g. one row block of a buffer that is gathered every few steps.
+    CPU tensors (the gloo tests) take an equivalent torch path."""
     n = int(keep_idx.shape[0])
     dev = keep_idx.device
     if keep_idx.is_cuda:
         from . import _lib
-        rec = torch.empty((n + 1, REC_COLS), dtype=torch.float32, device=dev)
+        rec = torch.empty((n + 1, REC_COLS), dtype=torch.float32, device=dev) if out is None else out
+        assert rec.is_contiguous() and tuple(rec.shape) == (n + 1, REC_COLS) and rec.dtype == torch.float32
         n_cls = int(det['scores'].shape[1])
         _lib.check(_lib.lib().srcnn_pack_detections(det['scores'].data_ptr(), det['boxes_left'].data_ptr(),
                                                     det['boxes_right'].data_ptr(), det['dim_orien'].data_ptr(),
@@ -62,7 +64,11 @@ def pack_records_device(det, keep_idx, num, j=1):
     body[:, 19] = idx.float()
     head = torch.zeros((1, REC_COLS), dtype=torch.float32, device=dev)
     head[0, 0] = num[0].float()
-    return torch.cat((head, body * valid), 0)
+    rec = torch.cat((head, body * valid), 0)
+    if out is not None:
+        out.copy_(rec)
+        return out
+    return rec
 
 
 def unpack_records(rec):
@@ -73,8 +79,9 @@ def unpack_records(rec):
 
 
 def gather_detections(rec, async_op=False):
-    """all_gather of one fixed-size record per rank -> (world, max_det + 1, REC_COLS) on every rank.
-    Works with the gloo backend on CPU tensors (tests) and nccl/RCCL on device tensors."""
+    """all_gather of one fixed-size record (or a stack of records, any leading shape) per rank ->
+    (world,) + rec.shape on every rank.  Works with the gloo backend on CPU tensors (tests) and nccl/RCCL on
+    device tensors."""
     if not dist.is_initialized():
         return rec.unsqueeze(0), None
     world = dist.get_world_size()
