@@ -56,6 +56,26 @@ def _worker(rank, world, port, q):
     for r in range(world):
         k = int(out[r, 0, 0])
         got += out[r, 1:1 + k, 0].long().tolist()
+    # bench.py's form: the records of G steps packed in place (out=) and gathered by ONE all_gather
+    G, n = 3, 300
+    buf = torch.zeros(G, n + 1, sdist.REC_COLS)
+    for row in range(G):
+        det = {'scores': torch.zeros(n, 2), 'boxes_left': torch.zeros(n, 8), 'boxes_right': torch.zeros(n, 8),
+               'dim_orien': torch.zeros(n, 10), 'kpts': torch.zeros(n, 5)}
+        det['scores'][:, 1] = 100 * rank + 10 * row + torch.arange(n) / 1000.0
+        keep = torch.full((n,), -1, dtype=torch.int32)
+        keep[:row + 1] = torch.arange(row + 1, dtype=torch.int32)
+        ret = sdist.pack_records_device(det, keep, torch.tensor([row + 1], dtype=torch.int32), 1, out=buf[row])
+        assert ret.data_ptr() == buf[row].data_ptr()
+    stacked, work = sdist.gather_detections(buf)
+    if work is not None:
+        work.wait()
+    assert tuple(stacked.shape) == (world, G, n + 1, sdist.REC_COLS)
+    for r in range(world):
+        for row in range(G):
+            assert int(stacked[r, row, 0, 0]) == row + 1
+            assert abs(float(stacked[r, row, 1, 0]) - (100 * r + 10 * row)) < 1e-6
+            assert float(stacked[r, row, row + 2:, :].abs().sum()) == 0.0
     q.put((rank, sorted(got)))
     dist.barrier()
     dist.destroy_process_group()
