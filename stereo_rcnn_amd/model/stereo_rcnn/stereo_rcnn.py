@@ -36,7 +36,9 @@ class _StereoRCNN(nn.Module):
         self.RCNN_roi_align = RoIAlignAvg(cfg.POOLING_SIZE, cfg.POOLING_SIZE, 1.0 / 16.0)
         self.RCNN_roi_kpts_align = RoIAlignAvg(cfg.POOLING_SIZE * 2, cfg.POOLING_SIZE * 2, 1.0 / 16.0)
         self.use_graph = False            # replay the forward as one hipGraph (see plan.py)
-        self.precision = 'f32'            # conv engine: 'f32' (exact) or 'f16x3' (error-compensated f16 MFMA)
+        # conv engine: 'f16x3' (default: error-compensated 3-term split on the f16 MFMA, fp32-class results, same parity
+        # tolerances) or 'f32' (exact fp32 MFMA, ~2.4x slower)
+        self.precision = 'f16x3'
         self._weights = None
         self._plans = {}
 

@@ -36,6 +36,7 @@ def _build_model(dev, seed=3):
     m.load_state_dict(sd)
     m.cuda()
     m.eval()
+    m.precision = 'f32'       # the exact engine unless a test selects the default f16x3 engine explicitly
     return m, sd
 
 
@@ -338,3 +339,21 @@ def test_resnet50_trunk_small(dev):
         torch.cuda.synchronize()
         frac, errs = _check_end_to_end(out, ref['rois_left'][0], ref['rois_right'][0], ref, 0.95)
         assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (precision, errs)
+
+
+@pytest.mark.parametrize("hw,short", [((123, 411), 200), ((97, 333), 160)])
+def test_odd_image_sizes_end_to_end(dev, hw, short):
+    """Sizes that are not multiples of the strides: ceil-mode pooling, FPN upsample to the finer map's odd size,
+    ragged M / N tails of every conv tile, P6 subsampling (KITTI frames vary between 370x1224 and 376x1242)."""
+    from oracle import net as onet
+    from stereo_rcnn_amd import fixture
+    m, sd = _build_model(dev)
+    l, r, info = fixture.make_inputs(11, hw[0], hw[1], target_short=short)
+    ref = onet.forward(sd, l, r, info)
+    for precision in ('f16x3', 'f32'):
+        m.precision = precision
+        with torch.no_grad():
+            out = m(l.to(dev), r.to(dev), info.to(dev))
+        torch.cuda.synchronize()
+        frac, errs = _check_end_to_end(out, ref['rois_left'][0], ref['rois_right'][0], ref, 0.95)
+        assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (precision, hw, errs)
