@@ -3,6 +3,16 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package, and only as the checker.  The product path (stereo_rcnn_amd/)
 never imports it and fails loudly when its HIP library is missing.
-Parity status: UNPINNED by the reference (no importable/buildable reference and
-no upstream tests or golden vectors - see DESIGN.md).
+Parity status: PINNED against outputs of the reference itself, produced in the build container (the reference ships
+no tests or golden vectors of its own - SURVEY.md 8(c)):
+  * its Python (network, stereo RPN, proposal layer, anchors, box transforms, ROI level routing, heads, box_estimator
+    cost/gradient closures and solutions, infer_boundary, KITTI writer, dense_align / Box3d) is imported from
+    /root/reference/lib under the shims of tests/golden/reference_shims.py and run on seeded inputs; the outputs are
+    committed as tests/golden/reference_*.npz (generator: tests/golden/make_reference_golden.py) and the oracle
+    reproduces them bit for bit (tests/test_reference_golden.py);
+  * its two CUDA kernels (NMS, ROIAlign) are compiled UNCHANGED for gfx950 (oracle/build.py:build_ref ->
+    oracle/_ref/libref_ops*.so) and executed on the MI355X against the C restatement and the product kernels
+    (tests/test_ref_kernels_gpu.py): bit-equal.
+Not pinned: the demo.py decode loop (script code, restated in postprocess.py and checked by hand-computed cases) and
+OpenCV's resize in the preprocessing (cv2 is absent offline).
 """

@@ -12,7 +12,9 @@ quirk of the reference: the keypoint residual is doubled (:264) but its hand-wri
 (:311-316) lacks the matching factor 2, i.e. the reference's gradient weights that term by 1/2.
 `kpt_grad_weight=0.5` keeps the quirk (default); the stationary point scipy converges to is the one
 the quirk defines.
-Parity status: unpinned by the reference (no tests upstream); scipy version here is 1.15.
+Parity status: PINNED -- cost and (quirky) gradient equal the reference's own f_kpt/j_kpt and f_rect/j_rect closures
+(captured from inside its solve functions) to 1e-12 at 192 points, statuses and start points equal; end points are
+compared statistically because scipy's Newton-CG is chaotic on this problem (tests/test_reference_golden.py).  scipy 1.15.
 """
 import math
 

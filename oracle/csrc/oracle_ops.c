@@ -14,10 +14,11 @@
  *   - ROIAlign lattice  lib/model/roi_align/src/roi_align_kernel.cu:27-68
  *   - 2x2/s1 avg-pool   lib/model/roi_align/modules/roi_align.py:26-29
  *
- * Parity status: PARITY UNPINNED by the reference (it ships no tests, golden
- * vectors or buildable CPU path for these ops; the .cu sources need nvcc+THC).
- * Pinned instead against an independent pure-Python loop restatement
- * (oracle/ops_py.py) and committed golden vectors (tests/golden/).
+ * Parity status: PINNED.  The reference's own .cu files compile unchanged with hipcc for gfx950 (oracle/build.py:build_ref,
+ * oracle/ref_cuda_on_hip.h) and run on the MI355X: their keep lists and ROIAlign outputs are bit-identical to this file
+ * (tests/test_ref_kernels_gpu.py).  That check found and fixed a promotion error of the first restatement (the two lower
+ * taps of the bilinear blend start as float x float products, see below).  Also pinned against an independent
+ * pure-Python loop restatement (oracle/ops.py) and committed golden vectors (tests/golden/).
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/build.py)
  */
@@ -127,10 +128,17 @@ int oracle_roi_align_forward(int ah, int aw, float spatial_scale,
                         int upright = upleft + 1;
                         int downleft = upleft + width;
                         int downright = downleft + 1;
+                        /* roi_align_kernel.cu:64-67, usual arithmetic conversions left to right: terms 1 and 2 meet the
+                         * double `(1. - h_ratio)` first and are double products; `feat * h_ratio` is float x float (one
+                         * float rounding) before `(1. - w_ratio)` promotes it; term 4 is a float product throughout.
+                         * (Pinned by running the reference's own kernel: tests/test_ref_kernels_gpu.py.) */
+                        float dl_h = feat[downleft] * h_ratio;
+                        float dr_h = feat[downright] * h_ratio;
+                        float dr_hw = dr_h * w_ratio;
                         double v = (double)feat[upleft] * (1. - (double)h_ratio) * (1. - (double)w_ratio)
                                  + (double)feat[upright] * (1. - (double)h_ratio) * (double)w_ratio
-                                 + (double)feat[downleft] * (double)h_ratio * (1. - (double)w_ratio)
-                                 + (double)feat[downright] * (double)h_ratio * (double)w_ratio;
+                                 + (double)dl_h * (1. - (double)w_ratio)
+                                 + (double)dr_hw;
                         out[o] = (float)v;
                     }
                 }

@@ -13,9 +13,9 @@ PyTorch-0.3 semantics that must be spelled out under torch 2.x: bilinear
 `F.upsample` == align_corners=True (stereo_rcnn.py:108); torch.round is
 half-away-from-zero (stereo_rcnn.py:117).
 
-Parity status: UNPINNED by the reference (py2/torch-0.3/CUDA-only source cannot be
-imported or built here; no tests or golden vectors exist upstream - SURVEY 8(c)).
-The oracle's own golden dumps (tests/golden/) are the contract.
+Parity status: PINNED -- `forward` reproduces, bit for bit on every coordinate-matched proposal, the outputs of the
+reference's own `_StereoRCNN.forward` run in the build container with the same seeded weights and inputs
+(tests/golden/reference_net_*.npz, tests/test_reference_golden.py; shims: tests/golden/reference_shims.py).
 """
 import math
 

@@ -5,7 +5,8 @@ Two independent restatements are kept on purpose:
   * the numpy/pure-Python one below (`*_py`) -- slow, used only to pin the C one
     on small cases (tests/test_oracle_ops.py).
 Reference lines followed: see the header of oracle_ops.c.
-Parity status: unpinned by the reference itself (no tests / golden vectors there).
+Parity status: PINNED -- the reference's own CUDA kernels, built unchanged for gfx950 (oracle/_ref), give bit-identical
+keep lists and ROIAlign outputs on the MI355X (tests/test_ref_kernels_gpu.py).
 """
 import ctypes
 import math
@@ -157,9 +158,13 @@ def roi_align_forward_py(feat, rois, ah, aw, scale):
                     hr = float(f32(hh - f32(hs)))
                     wr = float(f32(ww - f32(ws)))
                     ul = img_start + (ch * height + hs) * width + ws
+                    # usual arithmetic conversions, left to right (roi_align_kernel.cu:64-67): double products for the two
+                    # upper taps, float x float first for the lower ones
+                    dl_h = f32(flat[ul + width] * f32(hr))
+                    dr_hw = f32(f32(flat[ul + width + 1] * f32(hr)) * f32(wr))
                     v = (float(flat[ul]) * (1. - hr) * (1. - wr)
                          + float(flat[ul + 1]) * (1. - hr) * wr
-                         + float(flat[ul + width]) * hr * (1. - wr)
-                         + float(flat[ul + width + 1]) * hr * wr)
+                         + float(dl_h) * (1. - wr)
+                         + float(dr_hw))
                     out[i, ch, ph, pw] = f32(v)
     return out

@@ -4,7 +4,8 @@ Reference lines followed (relative to /root/reference):
   de-interleave + denormalise + decode + clip + /scale   demo.py:144-218 (= test_net.py:138-212)
   keypoint / border decode                              lib/model/rpn/bbox_transform.py:133-155
   per-class threshold, sort, NMS, gather                demo.py:231-257
-Parity status: unpinned by the reference (no tests upstream).
+Parity status: the decode / filter loop is script code in demo.py (not importable), so this file is pinned only by
+hand-computed cases (tests/test_oracle_net.py); its kpts/border decode formulas are bbox_transform.py:133-155.
 """
 import numpy as np
 import torch

@@ -7,7 +7,9 @@ Reference lines followed (relative to /root/reference/lib/model/rpn):
   proposal layer proposal_layer.py:60-145
 Sort: the reference's torch.sort tie order is unspecified (proposal_layer.py:96);
 the oracle and the HIP path both use a STABLE descending sort (ties -> lower index).
-Parity status: unpinned by the reference (no tests upstream).
+Parity status: PINNED -- anchors equal generate_anchors_all_pyramids (sha256 over all 298 476 rows), decode/clip equal
+bbox_transform_inv / clip_boxes bit for bit, and the layer as a whole is exercised by the network goldens
+(tests/test_reference_golden.py).
 """
 import numpy as np
 import torch

@@ -47,11 +47,16 @@ __device__ __forceinline__ float lattice_point(float h, float w, int height, int
     int wstart = (int)fminf(floorf(w), (float)(width - 2));                  // :49
     float h_ratio = h - (float)hstart;
     float w_ratio = w - (float)wstart;
-    double hr = (double)h_ratio, wr = (double)w_ratio;
-    double v = (double)at(hstart, wstart) * (1. - hr) * (1. - wr)            // :64-67
-             + (double)at(hstart, wstart + 1) * (1. - hr) * wr
-             + (double)at(hstart + 1, wstart) * hr * (1. - wr)
-             + (double)at(hstart + 1, wstart + 1) * hr * wr;
+    // :64-67 with C++'s usual arithmetic conversions, left to right: `1.` is a double, so the first two terms are double
+    // products; `down * h_ratio` is float x float (rounded to float) before it meets a double, and the last term is a
+    // float product throughout.  (Checked against the reference's own kernel built for gfx950: tests/test_ref_kernels_gpu.py.)
+    const double hr1 = 1. - (double)h_ratio, wr1 = 1. - (double)w_ratio;
+    const float dl_h = at(hstart + 1, wstart) * h_ratio;
+    const float dr_hw = at(hstart + 1, wstart + 1) * h_ratio * w_ratio;
+    double v = (double)at(hstart, wstart) * hr1 * wr1
+             + (double)at(hstart, wstart + 1) * hr1 * (double)w_ratio
+             + (double)dl_h * wr1
+             + (double)dr_hw;
     return (float)v;
 }
 

@@ -1,0 +1,229 @@
+"""Golden vectors produced by the REFERENCE'S OWN PYTHON, executed in this container.
+
+    python tests/golden/make_reference_golden.py            # needs /root/reference (read-only); writes tests/golden/reference_*.npz
+
+The reference (py2 / torch-0.3 era) is imported from /root/reference/lib under the shims of reference_shims.py
+(listed there with what each one does and does not change).  These files are what pins the CPU oracle
+(tests/test_reference_golden.py) and, through it or directly, the HIP path (tests/test_*_gpu.py): nothing at test
+time reads /root/reference.  Inputs are regenerated from seeds by stereo_rcnn_amd/fixture.py; only outputs are stored.
+"""
+import hashlib
+import math
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+warnings.filterwarnings('ignore')
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+torch.set_num_threads(min(os.cpu_count() or 1, 16))
+from oracle import ops as oracle_ops          # noqa: E402
+import reference_shims                        # noqa: E402
+
+reference_shims.install(oracle_ops)
+from stereo_rcnn_amd import fixture           # noqa: E402
+
+NAMES = ['rois_left', 'rois_right', 'cls_prob', 'bbox_pred', 'dim_orien_pred', 'kpts_prob', 'left_border_prob',
+         'right_border_prob']
+
+
+def reference_model(seed, layers=101):
+    from model.stereo_rcnn.resnet import resnet
+    net = resnet(('__background__', 'Car'), layers, pretrained=False)
+    net.create_architecture()
+    net.load_state_dict(fixture.make_state_dict(seed))
+    net.eval()
+    return net
+
+
+def net_golden(net, seed, h, w, short, tag):
+    l, r, info = fixture.make_inputs(seed, h, w, target_short=short)
+    z, nb = torch.zeros(1, 1, 5), torch.zeros(1)
+    with torch.no_grad():
+        out = net(l, r, info, z, z, z, z, z, nb)      # the reference's 9-argument eval call (demo.py:137-140)
+    d = {n: out[i].detach().numpy().astype(np.float32) for i, n in enumerate(NAMES)}
+    d['input_shape'] = np.asarray(l.shape)
+    d['spec'] = np.asarray([seed, h, w, short])
+    np.savez_compressed(os.path.join(HERE, 'reference_net_%s.npz' % tag), **d)
+    print('reference_net_%s.npz' % tag, {k: v.shape for k, v in d.items()})
+
+
+def anchors_golden():
+    from generate_anchors import generate_anchors_all_pyramids
+    from model.utils.config import cfg
+    out = {}
+    for tag, (h, w) in (('full', (600, 1987)), ('small', (192, 640))):
+        shapes = []
+        hh, ww = h, w
+        # feature map sizes exactly as the network produces them: conv 7x7/2 pad 3, maxpool 3/2 ceil, then /2 three times
+        hh, ww = (hh + 2 * 3 - 7) // 2 + 1, (ww + 2 * 3 - 7) // 2 + 1
+        hh, ww = math.ceil((hh - 3) / 2) + 1, math.ceil((ww - 3) / 2) + 1
+        shapes.append((hh, ww))
+        for _ in range(3):
+            hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+            shapes.append((hh, ww))
+        shapes.append(((hh - 1) // 2 + 1, (ww - 1) // 2 + 1))          # P6: max_pool2d(p5, 1, stride=2)
+        a = generate_anchors_all_pyramids(cfg.FPN_ANCHOR_SCALES, cfg.ANCHOR_RATIOS, np.asarray(shapes),
+                                          cfg.FPN_FEAT_STRIDES, cfg.FPN_ANCHOR_STRIDE).astype(np.float32)
+        out['anchors_%s_shapes' % tag] = np.asarray(shapes)
+        out['anchors_%s_count' % tag] = np.asarray([a.shape[0]])
+        out['anchors_%s_sha256' % tag] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+        out['anchors_%s_sample' % tag] = a[::499].copy()
+    return out
+
+
+def bbox_transform_golden():
+    from bbox_transform import bbox_transform_inv, clip_boxes
+    g = torch.Generator().manual_seed(5)
+    boxes = torch.rand(1, 200, 4, generator=g) * 300
+    boxes[:, :, 2:] += boxes[:, :, :2] + 5
+    deltas = torch.randn(1, 200, 4, generator=g) * 0.3
+    im_info = torch.tensor([[192.0, 640.0, 1.6]])
+    dec = bbox_transform_inv(boxes, deltas, 1)
+    clipped = clip_boxes(dec.clone(), im_info, 1)
+    return {'bt_boxes': boxes.numpy(), 'bt_deltas': deltas.numpy(), 'bt_im_info': im_info.numpy(),
+            'bt_decoded': dec.numpy(), 'bt_clipped': clipped.numpy()}
+
+
+# ---------------------------------------------------------------------------- host-side geometry (A13, A14, A17)
+def synthetic_cases(n=24, seed=7):
+    """Observations of random 3-D boxes projected with the KITTI demo calibration (same generator as the tests):
+    (alpha, dim(w,h,l), box_left, box_right, kpts(5)) per case, float64."""
+    from oracle import box_estimator as obe
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        z = rng.uniform(6, 45)
+        x = rng.uniform(-0.45, 0.45) * z
+        th = rng.uniform(-math.pi, math.pi)
+        dim = (rng.uniform(1.5, 1.8), rng.uniform(1.4, 1.7), rng.uniform(3.5, 4.6))
+        bl, br, corners = obe.project_observations(calib, (x, 1.65, z, th), dim)
+        f, cx = calib.p2[0, 0], calib.p2[0, 2]
+        kt = int(rng.integers(0, 4))
+        sx, sz = obe._KPT_VERTS[kt]
+        X, Z = corners[(sx, sz)]
+        kp = f * X / Z + cx + rng.normal(0, 0.5)
+        if not (bl[0] + 1 < kp < bl[2] - 1) or bl[2] - bl[0] < 12 or bl[3] - bl[1] < 12:
+            continue
+        alpha = th - math.pi / 2 + math.atan2(-x, z) + rng.normal(0, 0.05)
+        noise = rng.normal(0, 0.4, 8)
+        bl = [bl[i] + noise[i] for i in range(4)]
+        br = [br[0] + noise[4], bl[1], br[2] + noise[5], bl[3]]
+        cases.append((alpha, dim, bl, br, [kp, kt, 0.9, bl[0], bl[2]]))
+    return cases
+
+
+def solver_golden():
+    """The reference's OWN cost / gradient closures (captured by intercepting scipy.optimize.minimize inside its module),
+    evaluated at the start point and at perturbed points, and its solutions."""
+    import box_estimator as rbe                 # the reference module (lib/model/utils on sys.path)
+    import kitti_utils as rku
+    import scipy.optimize
+    calib = rku.read_obj_calibration('/root/reference/demo/calib.txt')
+    captured = {}
+
+    def recording_minimize(fun, x0, *a, **k):
+        captured['fun'], captured['jac'], captured['x0'] = fun, k.get('jac'), np.array(x0, dtype=np.float64)
+        return scipy.optimize.minimize(fun, x0, *a, **k)
+    rbe.minimize = recording_minimize
+
+    class _ScipyCompat(object):                # `scipy.array` (a numpy alias) was removed from scipy; same function
+        array = staticmethod(np.array)
+        optimize = scipy.optimize
+    rbe.scipy = _ScipyCompat()
+    im_shape = (375, 1242, 3)
+    rng = np.random.default_rng(11)
+    rows4, rows3, cases_out = [], [], []
+    for alpha, dim, bl, br, kpts in synthetic_cases():
+        dimv = np.array(dim)
+        status, state = rbe.solve_x_y_z_theta_from_kpt(im_shape, calib, alpha, dimv, np.array(bl), np.array(br), np.array(kpts))
+        x0 = captured['x0']
+        pts = [x0] + [x0 + rng.normal(0, [0.3, 0.1, 0.8, 0.1]) for _ in range(3)]
+        ev = [[float(captured['fun'](p))] + list(np.asarray(captured['jac'](p), dtype=np.float64)) for p in pts]
+        rows4.append(np.concatenate([[status], np.asarray(state, dtype=np.float64).ravel()[:4] if status or np.ndim(state) else np.zeros(4),
+                                     np.concatenate(pts), np.asarray(ev).ravel()]))
+        disp = (bl[0] + bl[2]) / 2 - (br[0] + br[2]) / 2
+        st3, z = rbe.solve_x_y_theta_from_kpt(im_shape, calib, alpha, dimv, np.array(bl), disp, np.array(kpts))
+        x0 = captured['x0']
+        pts = [x0] + [x0 + rng.normal(0, [0.3, 0.1, 0.1]) for _ in range(3)]
+        ev = [[float(captured['fun'](p))] + list(np.asarray(captured['jac'](p), dtype=np.float64)) for p in pts]
+        rows3.append(np.concatenate([np.asarray(st3, dtype=np.float64), [z], np.concatenate(pts), np.asarray(ev).ravel()]))
+        cases_out.append(np.concatenate([[alpha], dim, bl, br, kpts]))
+    out = {'solver_cases': np.asarray(cases_out), 'solver_4dof': np.asarray(rows4), 'solver_3dof': np.asarray(rows3),
+           'calib_p2': calib.p2, 'calib_p3': calib.p3, 'calib_t_cam2_cam0': calib.t_cam2_cam0}
+    # discrete helpers: viewpoint classification / vertex tables / keypoint -> alpha
+    al = np.linspace(-7.0, 7.0, 561)
+    out['viewpoint_alpha'] = al
+    out['viewpoint_class'] = np.asarray([rbe.BB2Viewpoint(a) for a in al])
+    out['viewpoint_vertex'] = np.asarray([np.ravel(rbe.viewpoint2vertex(v, 1.6, 4.0)) for v in range(-1, 8)], dtype=np.float64)
+    out['kpt_vertex'] = np.asarray([np.ravel(rbe.kpt2vertex(t, 1.6, 4.0)) for t in range(4)], dtype=np.float64)
+    box = np.array([100.0, 50.0, 220.0, 130.0])
+    out['kpt2alpha'] = np.asarray([[rbe.kpt2alpha(p, t, box) for p in np.linspace(60, 260, 21)] for t in range(4)])
+    # infer_boundary on overlapping boxes; the KITTI result line
+    g = np.random.default_rng(3)
+    b = np.zeros((12, 4), np.float32)
+    b[:, 0] = g.uniform(0, 900, 12); b[:, 2] = b[:, 0] + g.uniform(30, 300, 12)
+    b[:, 1] = g.uniform(100, 200, 12); b[:, 3] = b[:, 1] + g.uniform(30, 170, 12)
+    b[:, 2] = np.minimum(b[:, 2], 1241)
+    out['ib_boxes'] = b
+    out['ib_left_right'] = rku.infer_boundary((375, 1242, 3), b)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        rku.write_detection_results(td, '000007', calib, np.array([10.5, 20.25, 200.0, 180.125]), np.array([1.5, 1.6, 22.75]),
+                                    np.array([1.62, 1.53, 3.9]), 0.37, 0.93)
+        out['kitti_line'] = np.frombuffer(open(td + '/data/000007.txt', 'rb').read(), np.uint8)
+    return out
+
+
+# ---------------------------------------------------------------------------- dense alignment (A15, A16)
+def dense_align_golden():
+    from model.dense_align.dense_align import align_parallel
+    import kitti_utils as rku
+    from oracle import dense_align as oda           # only its box-projection helper, to place boxes around the poses
+    calib = rku.read_obj_calibration('/root/reference/demo/calib.txt')
+    out = {}
+    for seed, n in ((2, 6), (3, 12)):
+        rng = np.random.default_rng(seed)
+        poses = []
+        for _ in range(n):
+            z = rng.uniform(7, 45)
+            x = rng.uniform(-0.6, 0.6) * z * 0.8
+            poses.append([x, rng.uniform(1.4, 1.8), z, 1.6 * rng.uniform(0.9, 1.1), 1.5 * rng.uniform(0.9, 1.1),
+                          4.0 * rng.uniform(0.9, 1.1), rng.uniform(-np.pi, np.pi)])
+        poses = torch.tensor(poses, dtype=torch.float32)
+        boxes = torch.tensor([oda.project_box(oda.KITTI_DEMO_CALIB, p) for p in poses], dtype=torch.float32)
+        boxes[:, 0::2].clamp_(0, 1241)
+        boxes[:, 1::2].clamp_(0, 374)
+        kp = torch.zeros(n, 5)
+        kp[:, 3] = boxes[:, 0] + torch.from_numpy(rng.uniform(0, 3, n).astype(np.float32))
+        kp[:, 4] = boxes[:, 2] - torch.from_numpy(rng.uniform(0, 3, n).astype(np.float32))
+        l, r, info = fixture.make_inputs(seed, 375, 1242)
+        with torch.no_grad():
+            status, dis = align_parallel(calib, float(info[0, 2]), l, r, boxes.clone(), kp.clone(), poses.clone())
+        t = 'da%d_' % seed
+        out.update({t + 'poses': poses.numpy(), t + 'boxes': boxes.numpy(), t + 'kpts': kp.numpy(),
+                    t + 'status': status.numpy().astype(np.float32), t + 'best_dis': dis.numpy().astype(np.float32)})
+    return out
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['net', 'misc']
+    if 'net' in which:
+        net = reference_model(3)
+        net_golden(net, 3, 120, 400, 192, 'small_r101_seed3')
+        net_golden(net, 3, 375, 1242, 600, 'full_r101_seed3')
+    if 'misc' in which:
+        d = {}
+        d.update(anchors_golden())
+        d.update(bbox_transform_golden())
+        d.update(solver_golden())
+        d.update(dense_align_golden())
+        np.savez_compressed(os.path.join(HERE, 'reference_misc.npz'), **d)
+        print('reference_misc.npz', sorted(d))

@@ -98,3 +98,25 @@ def test_planted_disparity_is_recovered(dev):
     # satisfies fb/(z*-2) ~ d0  ->  reported disparity fb/z* + 0.5
     z_star = fb / d0 + 2.0
     assert abs(float(dis[0]) - (fb / z_star + 0.5)) < 0.6, float(dis[0])
+
+
+@pytest.mark.parametrize("seed", [2, 3])
+def test_align_parallel_vs_reference_code_golden(dev, seed):
+    """HIP dense alignment against the REFERENCE'S OWN align_parallel (tests/golden/reference_misc.npz, written by
+    tests/golden/make_reference_golden.py): same status, aligned disparity equal up to one fine depth step on a flipped
+    near-tie of the discrete argmin."""
+    import os
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib       # calibration constants only (== the reference's demo/calib.txt)
+    from stereo_rcnn_amd import fixture
+    from stereo_rcnn_amd.model.dense_align.dense_align import align_parallel
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_misc.npz'))
+    t = 'da%d_' % seed
+    l, r, info = fixture.make_inputs(seed, 375, 1242)
+    st, dis = align_parallel(calib, float(info[0, 2]), l.to(dev), r.to(dev), torch.from_numpy(g[t + 'boxes']).to(dev),
+                             torch.from_numpy(g[t + 'kpts']).to(dev), torch.from_numpy(g[t + 'poses']).to(dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), g[t + 'status'])
+    d = np.abs(dis.cpu().numpy() - g[t + 'best_dis'])
+    z = g[t + 'poses'][:, 2]
+    step_px = 721.5377 * 0.5327 * 0.05 / np.maximum(z - 13.0, 1.5) ** 2 * 1.5 + 2e-3     # one fine step at the nearest bracket depth
+    assert float((d < 1e-3).mean()) >= 0.8 and bool((d <= step_px).all()), (d, step_px)

@@ -357,3 +357,27 @@ def test_odd_image_sizes_end_to_end(dev, hw, short):
         torch.cuda.synchronize()
         frac, errs = _check_end_to_end(out, ref['rois_left'][0], ref['rois_right'][0], ref, 0.95)
         assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (precision, hw, errs)
+
+
+@pytest.mark.parametrize("tag", ['small_r101_seed3', 'full_r101_seed3'])
+@pytest.mark.parametrize("precision", ['f16x3', 'f32'])
+def test_hip_forward_vs_reference_code_golden(dev, tag, precision):
+    """The HIP forward against outputs of the REFERENCE'S OWN PYTHON (tests/golden/reference_net_*.npz, written by
+    tests/golden/make_reference_golden.py in the build container): regressions within the 1e-4 north-star tolerance."""
+    from stereo_rcnn_amd import fixture
+    g = np.load(os.path.join(GOLD, 'reference_net_%s.npz' % tag))
+    seed, h, w, short = [int(v) for v in g['spec']]
+    m, _ = _build_model(dev)
+    m.precision = precision
+    l, r, info = fixture.make_inputs(seed, h, w, target_short=short)
+    assert list(l.shape) == list(g['input_shape'])
+    with torch.no_grad():
+        out = m(l.to(dev), r.to(dev), info.to(dev))
+    torch.cuda.synchronize()
+    ref_out = {k: torch.from_numpy(g[k]) for k in ('cls_prob', 'bbox_pred', 'dim_orien_pred', 'kpts_prob',
+                                                   'left_border_prob', 'right_border_prob')}
+    frac, errs = _check_end_to_end(out, torch.from_numpy(g['rois_left'])[0], torch.from_numpy(g['rois_right'])[0], ref_out, 0.90)
+    print('%s %s vs reference code: matched proposals %.3f, errs %s' % (tag, precision, frac, errs))
+    assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, errs
+    for k, v in errs.items():
+        assert v < 2e-3, (k, v)
