@@ -13,6 +13,7 @@ no tests or golden vectors of its own - SURVEY.md 8(c)):
   * its two CUDA kernels (NMS, ROIAlign) are compiled UNCHANGED for gfx950 (oracle/build.py:build_ref ->
     oracle/_ref/libref_ops*.so) and executed on the MI355X against the C restatement and the product kernels
     (tests/test_ref_kernels_gpu.py): bit-equal.
-Not pinned: the demo.py decode loop (script code, restated in postprocess.py and checked by hand-computed cases) and
-OpenCV's resize in the preprocessing (cv2 is absent offline).
+  * demo.py's decode and per-class NMS blocks (script code) are sliced out of the file and exec'd on the reference
+    network's outputs; postprocess.py gives the same numbers exactly.
+Not pinned: OpenCV's resize in the preprocessing (cv2 is absent offline).
 """

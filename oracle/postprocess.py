@@ -4,8 +4,9 @@ Reference lines followed (relative to /root/reference):
   de-interleave + denormalise + decode + clip + /scale   demo.py:144-218 (= test_net.py:138-212)
   keypoint / border decode                              lib/model/rpn/bbox_transform.py:133-155
   per-class threshold, sort, NMS, gather                demo.py:231-257
-Parity status: the decode / filter loop is script code in demo.py (not importable), so this file is pinned only by
-hand-computed cases (tests/test_oracle_net.py); its kpts/border decode formulas are bbox_transform.py:133-155.
+Parity status: PINNED -- demo.py is a script, so its decode block (:143-224) and per-class filter/sort/NMS block (:231-251)
+are sliced out by content markers and exec'd on the reference network's outputs (tests/golden/make_reference_golden.py:
+decode_golden); this file reproduces those numbers exactly (tests/test_reference_golden.py).
 """
 import numpy as np
 import torch

@@ -213,6 +213,44 @@ def dense_align_golden():
     return out
 
 
+# ---------------------------------------------------------------------------- detection decode + per-class NMS (A11, A12)
+def _demo_slice(start_marker, end_marker):
+    """Source lines of /root/reference/demo.py from the line containing start_marker to the one containing end_marker
+    (inclusive), de-indented -- executed in memory, never written anywhere."""
+    import textwrap
+    lines = open('/root/reference/demo.py').read().split('\n')
+    a = next(i for i, ln in enumerate(lines) if start_marker in ln)
+    b = next(i for i, ln in enumerate(lines) if end_marker in ln and i > a)
+    return textwrap.dedent('\n'.join(lines[a:b + 1]))
+
+
+def decode_golden():
+    """demo.py is a script, so its decode block (:143-224) and the per-class filter / sort / NMS block (:231-251) are
+    sliced out of the file by content markers and exec'd on the reference network's own outputs."""
+    from bbox_transform import bbox_transform_inv, kpts_transform_inv, border_transform_inv, clip_boxes
+    from model.utils.config import cfg
+    from model.nms.nms_wrapper import nms
+    g = np.load(os.path.join(HERE, 'reference_net_small_r101_seed3.npz'))
+    seed, h, w, short = [int(v) for v in g['spec']]
+    _, _, info = fixture.make_inputs(seed, h, w, target_short=short)
+    ns = {'torch': torch, 'np': np, 'cfg': cfg, 'kitti_classes': np.asarray(['__background__', 'Car']), 'xrange': range,
+          'bbox_transform_inv': bbox_transform_inv, 'kpts_transform_inv': kpts_transform_inv,
+          'border_transform_inv': border_transform_inv, 'clip_boxes': clip_boxes, 'nms': nms, 'eval_thresh': 0.05,
+          'im_info': info, 'cls_prob': torch.from_numpy(g['cls_prob']), 'rois_left': torch.from_numpy(g['rois_left']),
+          'rois_right': torch.from_numpy(g['rois_right']), 'bbox_pred': torch.from_numpy(g['bbox_pred']),
+          'bbox_pred_dim': torch.from_numpy(g['dim_orien_pred']), 'kpts_prob': torch.from_numpy(g['kpts_prob']),
+          'left_prob': torch.from_numpy(g['left_border_prob']), 'right_prob': torch.from_numpy(g['right_border_prob'])}
+    exec(compile(_demo_slice('scores = cls_prob.data', 'dim_orien = dim_orien.squeeze()'), 'demo.py[decode]', 'exec'), ns)
+    out = {'dec_scores': ns['scores'].numpy(), 'dec_boxes_left': ns['pred_boxes_left'].numpy(),
+           'dec_boxes_right': ns['pred_boxes_right'].numpy(), 'dec_kpts': ns['pred_kpts'].numpy(),
+           'dec_dim_orien': ns['dim_orien'].numpy()}
+    exec(compile(_demo_slice('for j in xrange(1, len(kitti_classes)):', 'cls_kpts = cls_kpts[keep]'), 'demo.py[class loop]', 'exec'), ns)
+    out.update({'cls_dets_left': ns['cls_dets_left'].numpy(), 'cls_dets_right': ns['cls_dets_right'].numpy(),
+                'cls_dim_orien': ns['cls_dim_orien'].numpy(), 'cls_kpts': ns['cls_kpts'].numpy(),
+                'cls_keep': ns['keep'].numpy().astype(np.int64)})
+    return out
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['net', 'misc']
     if 'net' in which:
@@ -225,5 +263,6 @@ if __name__ == '__main__':
         d.update(bbox_transform_golden())
         d.update(solver_golden())
         d.update(dense_align_golden())
+        d.update(decode_golden())
         np.savez_compressed(os.path.join(HERE, 'reference_misc.npz'), **d)
         print('reference_misc.npz', sorted(d))

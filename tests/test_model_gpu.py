@@ -381,3 +381,27 @@ def test_hip_forward_vs_reference_code_golden(dev, tag, precision):
     assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, errs
     for k, v in errs.items():
         assert v < 2e-3, (k, v)
+
+
+def test_hip_decode_and_class_nms_vs_reference_demo_script(dev):
+    """Product decode + per-class NMS kernels on the reference network's own outputs vs what the reference's demo.py code
+    computes from them (tests/golden/reference_misc.npz: dec_* / cls_*)."""
+    from stereo_rcnn_amd import fixture
+    from stereo_rcnn_amd import postprocess as hpost
+    g = np.load(os.path.join(GOLD, 'reference_net_small_r101_seed3.npz'))
+    m = np.load(os.path.join(GOLD, 'reference_misc.npz'))
+    seed, h, w, short = [int(v) for v in g['spec']]
+    _, _, info = fixture.make_inputs(seed, h, w, target_short=short)
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    det = hpost.decode_detections(t('rois_left'), t('rois_right'), t('cls_prob'), t('bbox_pred'), t('dim_orien_pred'),
+                                  t('kpts_prob'), t('left_border_prob'), t('right_border_prob'), info.to(dev))
+    for a, b, tol in (('scores', 'dec_scores', 0.0), ('boxes_left', 'dec_boxes_left', 2e-3), ('boxes_right', 'dec_boxes_right', 2e-3),
+                      ('kpts', 'dec_kpts', 2e-3), ('dim_orien', 'dec_dim_orien', 1e-6)):
+        err = float(np.abs(det[a].cpu().numpy() - m[b].reshape(tuple(det[a].shape))).max())
+        assert err <= tol, (a, err)             # expf may differ from torch's CPU exp by an ulp -> ~1e-4 px on a 600-px box
+    cls = hpost.class_detections(det, 1)
+    assert cls['dets_left'].shape[0] == m['cls_dets_left'].shape[0]
+    assert float((cls['dets_left'].cpu() - torch.from_numpy(m['cls_dets_left'])).abs().max()) < 2e-3
+    assert float((cls['dets_right'].cpu() - torch.from_numpy(m['cls_dets_right'])).abs().max()) < 2e-3
+    assert float((cls['dim_orien'].cpu() - torch.from_numpy(m['cls_dim_orien'])).abs().max()) < 1e-6
+    assert float((cls['kpts'].cpu() - torch.from_numpy(m['cls_kpts'])).abs().max()) < 2e-3

@@ -193,3 +193,23 @@ def test_dense_alignment_equals_reference_code(misc, seed):
                                  torch.from_numpy(misc[t + 'kpts']), torch.from_numpy(misc[t + 'poses']))
     assert np.array_equal(st.numpy(), misc[t + 'status'])
     assert float(np.abs(dis.numpy() - misc[t + 'best_dis']).max()) < 1e-5
+
+
+def test_decode_and_class_nms_equal_reference_demo_script(misc):
+    """demo.py:143-224 (decode) and :231-251 (per-class filter, sort, NMS, gather) were sliced out of the reference script
+    and exec'd on the reference network's outputs; oracle/postprocess.py gives the same numbers exactly."""
+    from oracle import postprocess as opost
+    from stereo_rcnn_amd import fixture
+    g = np.load(os.path.join(GOLD, 'reference_net_small_r101_seed3.npz'))
+    seed, h, w, short = [int(v) for v in g['spec']]
+    _, _, info = fixture.make_inputs(seed, h, w, target_short=short)
+    out = {k: torch.from_numpy(g[k]) for k in g.files if k not in ('spec', 'input_shape')}
+    det = opost.decode_detections(out, info)
+    for a, b in (('scores', 'dec_scores'), ('boxes_left', 'dec_boxes_left'), ('boxes_right', 'dec_boxes_right'),
+                 ('kpts', 'dec_kpts'), ('dim_orien', 'dec_dim_orien')):
+        assert np.array_equal(det[a].numpy(), misc[b].reshape(det[a].shape)), a
+    cls = opost.class_detections(det)
+    for a, b in (('dets_left', 'cls_dets_left'), ('dets_right', 'cls_dets_right'), ('dim_orien', 'cls_dim_orien'),
+                 ('kpts', 'cls_kpts')):
+        assert np.array_equal(cls[a].numpy(), misc[b]), a
+    assert cls['dets_left'].shape[0] == 53
