@@ -138,25 +138,41 @@ def solver_golden():
         array = staticmethod(np.array)
         optimize = scipy.optimize
     rbe.scipy = _ScipyCompat()
-    im_shape = (375, 1242, 3)
     rng = np.random.default_rng(11)
-    rows4, rows3, cases_out = [], [], []
-    for alpha, dim, bl, br, kpts in synthetic_cases():
-        dimv = np.array(dim)
-        status, state = rbe.solve_x_y_z_theta_from_kpt(im_shape, calib, alpha, dimv, np.array(bl), np.array(br), np.array(kpts))
-        x0 = captured['x0']
-        pts = [x0] + [x0 + rng.normal(0, [0.3, 0.1, 0.8, 0.1]) for _ in range(3)]
-        ev = [[float(captured['fun'](p))] + list(np.asarray(captured['jac'](p), dtype=np.float64)) for p in pts]
-        rows4.append(np.concatenate([[status], np.asarray(state, dtype=np.float64).ravel()[:4] if status or np.ndim(state) else np.zeros(4),
-                                     np.concatenate(pts), np.asarray(ev).ravel()]))
-        disp = (bl[0] + bl[2]) / 2 - (br[0] + br[2]) / 2
-        st3, z = rbe.solve_x_y_theta_from_kpt(im_shape, calib, alpha, dimv, np.array(bl), disp, np.array(kpts))
-        x0 = captured['x0']
-        pts = [x0] + [x0 + rng.normal(0, [0.3, 0.1, 0.1]) for _ in range(3)]
-        ev = [[float(captured['fun'](p))] + list(np.asarray(captured['jac'](p), dtype=np.float64)) for p in pts]
-        rows3.append(np.concatenate([np.asarray(st3, dtype=np.float64), [z], np.concatenate(pts), np.asarray(ev).ravel()]))
-        cases_out.append(np.concatenate([[alpha], dim, bl, br, kpts]))
-    out = {'solver_cases': np.asarray(cases_out), 'solver_4dof': np.asarray(rows4), 'solver_3dof': np.asarray(rows3),
+
+    def closure_rows(im_shape, cases):
+        rows4, rows3, cases_out = [], [], []
+        for alpha, dim, bl, br, kpts in cases:
+            dimv = np.array(dim)
+            captured.clear()
+            status, state = rbe.solve_x_y_z_theta_from_kpt(im_shape, calib, alpha, dimv, np.array(bl), np.array(br), np.array(kpts))
+            if 'x0' not in captured:            # early-out (:186-187): nothing to evaluate
+                continue
+            x0 = captured['x0']
+            pts = [x0] + [x0 + rng.normal(0, [0.3, 0.1, 0.8, 0.1]) for _ in range(3)]
+            ev = [[float(captured['fun'](p))] + list(np.asarray(captured['jac'](p), dtype=np.float64)) for p in pts]
+            rows4.append(np.concatenate([[status], np.asarray(state, dtype=np.float64).ravel()[:4], np.concatenate(pts), np.asarray(ev).ravel()]))
+            disp = (bl[0] + bl[2]) / 2 - (br[0] + br[2]) / 2
+            st3, z = rbe.solve_x_y_theta_from_kpt(im_shape, calib, alpha, dimv, np.array(bl), disp, np.array(kpts))
+            x0 = captured['x0']
+            pts = [x0] + [x0 + rng.normal(0, [0.3, 0.1, 0.1]) for _ in range(3)]
+            ev = [[float(captured['fun'](p))] + list(np.asarray(captured['jac'](p), dtype=np.float64)) for p in pts]
+            rows3.append(np.concatenate([np.asarray(st3, dtype=np.float64), [z], np.concatenate(pts), np.asarray(ev).ravel()]))
+            cases_out.append(np.concatenate([[alpha], dim, bl, br, kpts]))
+        return np.asarray(cases_out), np.asarray(rows4), np.asarray(rows3)
+
+    cases_out, rows4, rows3 = closure_rows((375, 1242, 3), synthetic_cases())
+    # the per-class detections of the small network run on a 120x400 frame: boxes hugging every image border, i.e. the
+    # truncation branches (alpha residual, right-box residuals, dropped top/bottom/left/right terms)
+    d = decode_golden()
+    det_cases = []
+    for i in range(d['cls_dets_left'].shape[0]):
+        do = d['cls_dim_orien'][i].astype(np.float64)
+        det_cases.append((math.atan2(do[3], do[4]), do[0:3], d['cls_dets_left'][i, 0:4].astype(np.float64),
+                          d['cls_dets_right'][i, 0:4].astype(np.float64), d['cls_kpts'][i].astype(np.float64)))
+    tc, t4, t3 = closure_rows((120, 400, 3), det_cases)
+    out = {'solver_cases': cases_out, 'solver_4dof': rows4, 'solver_3dof': rows3,
+           'solver_trunc_cases': tc, 'solver_trunc_4dof': t4, 'solver_trunc_3dof': t3,
            'calib_p2': calib.p2, 'calib_p3': calib.p3, 'calib_t_cam2_cam0': calib.t_cam2_cam0}
     # discrete helpers: viewpoint classification / vertex tables / keypoint -> alpha
     al = np.linspace(-7.0, 7.0, 561)
@@ -251,6 +267,78 @@ def decode_golden():
     return out
 
 
+# ---------------------------------------------------------------------------- the post-network flow of demo.py (:259-326)
+def pipeline_golden():
+    """Border replacement, 4-DoF solve, dense alignment and 3-DoF rectification exactly as demo.py strings them together:
+    the three blocks are sliced out of the script and exec'd on the per-class detections of decode_golden()."""
+    import types
+    import box_estimator as rbe
+    import kitti_utils as rku
+    from model.dense_align import dense_align as rda
+    import math as m
+    d = decode_golden()
+    g = np.load(os.path.join(HERE, 'reference_net_small_r101_seed3.npz'))
+    seed, h, w, short = [int(v) for v in g['spec']]
+    l, r, info = fixture.make_inputs(seed, h, w, target_short=short)
+
+    class _Scalar03(object):              # torch 0.3: indexing a tensor down to one element gave a Python number
+        def __init__(self, t):
+            self.t = t
+
+        @property
+        def data(self):
+            return self
+
+        def __getitem__(self, idx):
+            v = self.t[idx]
+            return float(v) if (not torch.is_tensor(v) or v.dim() == 0) else v
+
+    class _Img(object):
+        shape = (h, w, 3)
+    solved = []
+    vis = types.SimpleNamespace(vis_box_in_bev=lambda im, xyz, dim, theta, width=0: solved.append(
+        np.concatenate([np.asarray(xyz, dtype=np.float64), [float(theta)]])) or im,
+        vis_single_box_in_img=lambda im, calib, xyz, dim, theta: im)
+    ns = {'torch': torch, 'np': np, 'm': m, 'time': __import__('time'), 'kitti_utils': rku, 'box_estimator': rbe,
+          'dense_align': rda, 'vis_utils': vis, 'vis_detections': lambda im, *a, **k: im, 'kitti_classes': ['__background__', 'Car'],
+          'j': 1, 'eval_thresh': 0.05, 'vis_thresh': -1.0, 'calib': rku.read_obj_calibration('/root/reference/demo/calib.txt'),
+          'im2show_left': _Img(), 'im2show_right': _Img(), 'im_box': None, 'im_info': _Scalar03(info),
+          'im_left_data': l, 'im_right_data': r,
+          'cls_dets_left': torch.from_numpy(d['cls_dets_left']), 'cls_dets_right': torch.from_numpy(d['cls_dets_right']),
+          'cls_dim_orien': torch.from_numpy(d['cls_dim_orien']), 'cls_kpts': torch.from_numpy(d['cls_kpts']).clone()}
+
+    class _ScipyCompat(object):
+        array = staticmethod(np.array)
+    rbe.scipy = _ScipyCompat()
+    import scipy.optimize
+    rbe.minimize = scipy.optimize.minimize
+    # torch 0.3 indexing rule for this block: a tensor indexed down to ONE element is a Python number, so that e.g. the
+    # keypoint terms of the solver run in double as they did for the reference's authors (under torch 2.x they would be
+    # float32 0-dim tensor arithmetic, and scipy's Newton-CG amplifies that 1e-7 difference to metres on ill-posed boxes)
+    _getitem = torch.Tensor.__getitem__
+
+    def getitem03(self, idx):
+        v = _getitem(self, idx)
+        return v.item() if v.dim() == 0 else v
+    torch.Tensor.__getitem__ = getitem03
+    try:
+        return _pipeline_blocks(ns, solved)
+    finally:
+        torch.Tensor.__getitem__ = _getitem
+
+
+def _pipeline_blocks(ns, solved):
+    exec(compile(_demo_slice('infered_kpts = kitti_utils.infer_boundary(', 'cls_kpts[detect_idx,3:5] = infered_kpts[detect_idx]'),
+                 'demo.py[borders]', 'exec'), ns)
+    out = {'pipe_kpts_after_borders': ns['cls_kpts'].numpy().copy()}
+    exec(compile(_demo_slice('# read intrinsic', 'poses_all = torch.cat((poses_all,poses.unsqueeze(0)),0)'), 'demo.py[solve]', 'exec'), ns)
+    out.update({'pipe_boxes_all': ns['boxes_all'].numpy(), 'pipe_kpts_all': ns['kpts_all'].numpy(), 'pipe_poses_all': ns['poses_all'].numpy()})
+    exec(compile(_demo_slice('if boxes_all.dim() > 0:', 'im2show_left = vis_utils.vis_single_box_in_img('), 'demo.py[align+rectify]', 'exec'), ns)
+    out.update({'pipe_succ': ns['succ'].numpy().astype(np.float32), 'pipe_dis_final': ns['dis_final'].numpy().astype(np.float32),
+                'pipe_rectified': np.asarray(solved, dtype=np.float64).reshape(-1, 4)})
+    return out
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['net', 'misc']
     if 'net' in which:
@@ -264,5 +352,6 @@ if __name__ == '__main__':
         d.update(solver_golden())
         d.update(dense_align_golden())
         d.update(decode_golden())
+        d.update(pipeline_golden())
         np.savez_compressed(os.path.join(HERE, 'reference_misc.npz'), **d)
         print('reference_misc.npz', sorted(d))

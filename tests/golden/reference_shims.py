@@ -16,7 +16,8 @@ What is shimmed, and why it does not change what the reference computes:
     alignment, KITTI helpers) is the reference's code.
   * `.cuda()` is made the identity and `torch.cuda.FloatTensor` etc. alias the CPU types (the code runs on CPU tensors); `torch.cuda.is_available()` is forced True
     only while `model.nms.nms_wrapper` is imported so that it binds `nms_gpu`.
-  * torch-0.3 semantics that changed: `F.upsample(mode='bilinear')` was align_corners=True (restored here);
+  * torch-0.3 semantics that changed: `F.upsample(mode='bilinear')` and `F.grid_sample` were align_corners=True (restored
+    here; dense_align.py:195-197 normalises its grid with (size-1)/2, i.e. for exactly that convention);
     `Variable(volatile=True)` is a no-op wrapper (generation runs under no_grad).
     Scalar indexing returned Python numbers in 0.3 and 0-dim tensors now, so a few scalar expressions run in
     float32 instead of double here; where that matters the comparison tolerances in the tests say so.
@@ -107,6 +108,10 @@ def install(oracle_ops):
     torch.nn.Module.cuda = lambda self, *a, **k: self
     F.upsample = lambda x, size=None, scale_factor=None, mode='nearest', align_corners=None: F.interpolate(
         x, size=size, scale_factor=scale_factor, mode=mode, align_corners=(True if mode == 'bilinear' else None))
+
+    _grid_sample = F.grid_sample          # torch 0.3 (and up to 1.2): grid_sample sampled with align_corners=True semantics
+    F.grid_sample = lambda inp, grid, mode='bilinear', padding_mode='zeros', align_corners=None: _grid_sample(
+        inp, grid, mode=mode, padding_mode=padding_mode, align_corners=True)
 
     # torch 0.3's TH catArray treated a tensor with fewer dimensions as having size 1 in the missing trailing ones
     # (box_3d.py:97 concatenates an (H, W) tensor to an (H, W, 2) one along dim 2): same rule here

@@ -213,3 +213,50 @@ def test_decode_and_class_nms_equal_reference_demo_script(misc):
                  ('kpts', 'cls_kpts')):
         assert np.array_equal(cls[a].numpy(), misc[b]), a
     assert cls['dets_left'].shape[0] == 53
+
+
+def test_post_network_flow_stage_by_stage_vs_reference_demo_script(misc):
+    """demo.py:259-326 (border replacement -> 4-DoF solve -> dense alignment -> 3-DoF rectification) was exec'd block by block
+    on the reference's own detections.  Each stage of the oracle is fed the REFERENCE's intermediate results, so that the
+    chaotic end point of the 4-DoF Newton-CG does not leak into the deterministic stages."""
+    import math
+    from oracle import box_estimator as obe, dense_align as oda, pipeline as opipe
+    from stereo_rcnn_amd import fixture
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    calib, im_shape = oda.KITTI_DEMO_CALIB, (120, 400, 3)
+    dl, dr, do = misc['cls_dets_left'], misc['cls_dets_right'], misc['cls_dim_orien']
+    # stage 1: borders replaced when narrower than half the inferred ones (demo.py:259-265) -- exact
+    kp = misc['cls_kpts'].copy()
+    inf = opipe.infer_boundary(im_shape, dl)
+    for i in range(dl.shape[0]):
+        if kp[i, 4] - kp[i, 3] < 0.5 * (inf[i, 1] - inf[i, 0]):
+            kp[i, 3:5] = inf[i]
+    assert np.array_equal(kp, misc['pipe_kpts_after_borders'])
+    # stage 2: which detections come out of the 4-DoF solve with status 1 (z <= 100): chaotic on these ill-posed boxes
+    # (a 120x400 frame with the KITTI focal length), so only the bulk has to agree
+    ref_solved = {tuple(np.round(r[:4], 3)) for r in misc['pipe_boxes_all']}
+    same = 0
+    for i in range(dl.shape[0]):
+        st, _ = obe.solve_x_y_z_theta_from_kpt(im_shape, calib, math.atan2(do[i, 3], do[i, 4]), do[i, 0:3], dl[i, 0:4], dr[i, 0:4], kp[i])
+        same += (st > 0) == (tuple(np.round(dl[i, :4], 3)) in ref_solved)
+    assert same >= 0.85 * dl.shape[0], same
+    # stage 3: dense alignment of the REFERENCE's solved poses -- deterministic, exact
+    l, r, info = fixture.make_inputs(3, 120, 400, target_short=192)
+    succ, dis = oda.align_parallel(calib, float(info[0, 2]), l, r, torch.from_numpy(misc['pipe_boxes_all'][:, 0:4]),
+                                   torch.from_numpy(misc['pipe_kpts_all']), torch.from_numpy(misc['pipe_poses_all'][:, 0:7]))
+    assert np.array_equal(succ.numpy(), misc['pipe_succ'])
+    assert float(np.abs(dis.numpy() - misc['pipe_dis_final'])[misc['pipe_succ'] > 0].max()) < 1e-4
+    # stage 4: 3-DoF rectification with the REFERENCE's aligned disparities (z is closed-form; x, y, theta from Newton-CG)
+    k, dz, dxy = 0, [], []
+    for i in range(misc['pipe_boxes_all'].shape[0]):
+        if misc['pipe_succ'][i] <= 0:
+            continue
+        p = misc['pipe_poses_all'][i]
+        state, z = obe.solve_x_y_theta_from_kpt(im_shape, calib, float(p[7]), p[3:6], misc['pipe_boxes_all'][i, 0:4],
+                                                float(misc['pipe_dis_final'][i]), misc['pipe_kpts_all'][i])
+        want = misc['pipe_rectified'][k]
+        k += 1
+        dz.append(abs(z - want[2]) / max(1.0, abs(want[2])))
+        dxy.append(max(abs(state[0] - want[0]), abs(state[1] - want[1])))
+    assert k == misc['pipe_rectified'].shape[0]
+    assert max(dz) < 1e-6 and np.median(dxy) < 1e-2, (max(dz), np.median(dxy), max(dxy))
