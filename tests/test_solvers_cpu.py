@@ -133,3 +133,21 @@ def test_calibration_reader_and_result_writer(tmp_path):
     assert abs(float(line[14]) - (0.3 - 1.57)) < 1e-5 and abs(float(line[15]) - 0.91) < 1e-6
     assert abs(float(line[3]) - (0.3 - math.pi / 2 + math.atan2(-1.0, 20.0))) < 1e-5
     kitti_utils.write_detection_results(None, 'x', c, [0] * 4, [0, 0, 1], [1, 1, 1], 0, 0)    # result_dir None: no-op
+
+
+def test_solver_pool_matches_serial():
+    """pipeline.SolverPool fans the per-object scipy solves out to worker processes; same function, same inputs ->
+    bitwise the same answers as the serial path."""
+    import os
+    import numpy as np
+    from stereo_rcnn_amd import pipeline
+    m = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_misc.npz'))
+    tasks = [(4, (375, 1242, 3), m['calib_p2'], m['calib_p3'], (r[0], r[1:4], r[4:8], r[8:12], r[12:17]))
+             for r in m['solver_cases'][:8]]
+    tasks += [(3, (375, 1242, 3), m['calib_p2'], m['calib_p3'], (r[0], r[1:4], r[4:8], 25.0, r[12:17]))
+              for r in m['solver_cases'][:8]]
+    serial = [pipeline._solve_task(t) for t in tasks]
+    with pipeline.SolverPool(2) as pool:
+        par = pool.map(tasks)
+    for a, b in zip(serial, par):
+        assert np.array_equal(np.asarray(a[0]), np.asarray(b[0])) and np.array_equal(np.asarray(a[1]), np.asarray(b[1]))

@@ -32,6 +32,15 @@ if __name__ == '__main__':
         torch.cuda.synchronize(); t0 = time.time()
         objs = pipeline.detect_3d(m, l, r, info, calib, (375, 1242, 3))
         torch.cuda.synchronize(); dt = time.time() - t0
-        print('pass %d: %d objects solved, %d aligned, %.1f ms' % (it, len(objs), sum(o['aligned'] for o in objs), dt * 1e3))
+        print('pass %d (serial solvers): %d objects solved, %d aligned, %.1f ms' % (it, len(objs), sum(o['aligned'] for o in objs), dt * 1e3))
+    workers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    with pipeline.SolverPool(workers) as pool:
+        for it in range(4):
+            torch.cuda.synchronize(); t0 = time.time()
+            objs2 = pipeline.detect_3d(m, l, r, info, calib, (375, 1242, 3), pool=pool)
+            torch.cuda.synchronize(); dt = time.time() - t0
+            print('pass %d (%d solver processes): %d objects solved, %d aligned, %.1f ms' % (it, workers, len(objs2), sum(o['aligned'] for o in objs2), dt * 1e3))
+    same = len(objs) == len(objs2) and all(np.array_equal(a['xyz'], b['xyz']) for a, b in zip(objs, objs2))
+    print('pool results identical to serial:', same)
     for o in objs[:5]:
         print('score %.3f box %s xyz %s theta %.2f' % (o['score'], np.round(o['box_left'], 1), np.round(o['xyz'], 2), o['theta']))
