@@ -1,0 +1,96 @@
+"""KITTI split evaluation driver - the reference's test_net.py:62-345 (config 4 of BASELINE.json), MI355X layout:
+one process per GPU, image ids sharded `i mod world` (the reference loops over them on one GPU with batch size 1),
+every frame: PNG decode on the host -> preprocessing, forward, decode, NMS, 3-D solve, dense alignment, rectification
+(`pipeline.detect_3d`) -> one KITTI result file per frame (`kitti_utils.write_detection_results`, test_net.py:329-330).
+Result files are per frame, so ranks never write to the same file; there is no collective besides the final barrier.
+
+    python -m stereo_rcnn_amd.test_net --kitti-root <.../object/training> --split val.txt --checkpoint model.pth --result-dir out
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m stereo_rcnn_amd.test_net ...
+
+`--kitti-root` holds image_2/, image_3/ and calib/ (the layout lib/datasets/kitti.py:60-75 reads).  The external KITTI
+evaluator (C++ `evaluate_object_3d_offline`) consumes <result-dir>/data/*.txt as with the reference.
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import engine, pipeline
+from .distributed import shard_indices
+from .model.stereo_rcnn.resnet import resnet
+from .model.utils import kitti_utils
+from .model.utils.config import cfg
+
+
+def read_split(path):
+    with open(path) as fh:
+        return [ln.strip() for ln in fh if ln.strip()]
+
+
+def read_png_rgb(path):
+    """uint8 (H, W, 3) RGB.  (The reference reads BGR with cv2 and flips; the device preprocessing takes RGB.)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert('RGB'), dtype=np.uint8)
+
+
+def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None):
+    """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds)."""
+    t0, n_obj = time.time(), 0
+    os.makedirs(os.path.join(result_dir, 'data'), exist_ok=True)
+    for k, frame in enumerate(ids):
+        left = read_image(os.path.join(kitti_root, 'image_2', frame + '.png'))
+        right = read_image(os.path.join(kitti_root, 'image_3', frame + '.png'))
+        calib = kitti_utils.read_obj_calibration(os.path.join(kitti_root, 'calib', frame + '.txt'))
+        l, scale = engine.preprocess(torch.from_numpy(left).to(device), cfg.TEST.SCALES[0])
+        r, _ = engine.preprocess(torch.from_numpy(right).to(device), cfg.TEST.SCALES[0])
+        info = torch.tensor([[l.shape[2], l.shape[3], scale]], dtype=torch.float32, device=device)
+        objs = pipeline.detect_3d(model, l, r, info, calib, left.shape, pool=pool)
+        open(os.path.join(result_dir, 'data', frame + '.txt'), 'w').close()      # a frame without detections still gets a file
+        pipeline.write_kitti_results(result_dir, frame, calib, [o for o in objs if o['aligned']])   # test_net.py:322-330
+        n_obj += sum(o['aligned'] for o in objs)
+        if log and (k + 1) % 50 == 0:
+            log('%d/%d frames, %.1f frames/s' % (k + 1, len(ids), (k + 1) / (time.time() - t0)))
+    torch.cuda.synchronize(device)
+    return len(ids), n_obj, time.time() - t0
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--kitti-root', required=True)
+    ap.add_argument('--split', required=True, help='text file with one frame id per line (e.g. data/kitti/splits/val.txt)')
+    ap.add_argument('--checkpoint', required=True, help="torch checkpoint with a 'model' state_dict (reference schema) or a bare state_dict")
+    ap.add_argument('--result-dir', required=True)
+    ap.add_argument('--solver-workers', type=int, default=8)
+    ap.add_argument('--precision', choices=['f16x3', 'f32'], default='f16x3')
+    args = ap.parse_args(argv)
+    rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
+    use_dist = 'RANK' in os.environ and world > 1
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    model = resnet(('__background__', 'Car'), 101, pretrained=False)
+    model.create_architecture()
+    sd = torch.load(args.checkpoint, map_location='cpu')
+    model.load_state_dict(sd['model'] if 'model' in sd else sd)
+    model.cuda()
+    model.eval()
+    model.precision = args.precision
+    ids = read_split(args.split)
+    mine = [ids[i] for i in shard_indices(len(ids), rank, world)]
+    with pipeline.SolverPool(args.solver_workers) as pool:
+        frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, pool,
+                                     log=(lambda s: print('[rank %d] %s' % (rank, s), flush=True)))
+    print('[rank %d] %d frames, %d objects, %.1f s (%.1f frames/s)' % (rank, frames, objs, dt, frames / max(dt, 1e-9)), flush=True)
+    if use_dist:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

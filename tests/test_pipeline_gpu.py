@@ -2,6 +2,8 @@
 The 4-DoF scipy solve is chaotic in depth (see model/utils/box_estimator.py), so the comparison is per matched
 object and statistical: same detections, same solver status, aligned disparities equal up to one fine depth
 step, rectified 3-D boxes close for most objects."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -67,3 +69,42 @@ def test_write_kitti_results(dev, tmp_path):
              'theta': 0.2, 'score': 0.8}]
     pipeline.write_kitti_results(str(tmp_path), '000001', c, objs)
     assert (tmp_path / 'data' / '000001.txt').read_text().startswith('Car -1 -1 ')
+
+
+def test_kitti_split_driver_writes_result_files(dev, tmp_path):
+    """test_net.py's loop on a synthetic KITTI tree (image_2 / image_3 PNGs, calib files, split list): every frame of
+    this rank's shard gets a result file whose lines parse as KITTI detections."""
+    from PIL import Image
+    from oracle.dense_align import KITTI_DEMO_CALIB as c            # calibration constants only
+    from stereo_rcnn_amd import fixture, pipeline, test_net
+    from stereo_rcnn_amd.distributed import shard_indices
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    root = tmp_path / 'training'
+    for d in ('image_2', 'image_3', 'calib'):
+        (root / d).mkdir(parents=True)
+    ids = ['%06d' % i for i in range(3)]
+    row = lambda name, mat: name + ': ' + ' '.join('%.12e' % v for v in np.ravel(mat))
+    p0 = c.p2.copy(); p0[0, 3] = 0.0; p0[1, 3] = 0.0; p0[2, 3] = 0.0
+    for k, frame in enumerate(ids):
+        l, r = fixture.synthetic_pair(20 + k, 120, 400)
+        Image.fromarray(l).save(str(root / 'image_2' / (frame + '.png')))
+        Image.fromarray(r).save(str(root / 'image_3' / (frame + '.png')))
+        (root / 'calib' / (frame + '.txt')).write_text('\n'.join([
+            row('P0', p0), row('P1', p0), row('P2', c.p2), row('P3', c.p3), row('R0_rect', np.eye(3)),
+            row('Tr_velo_to_cam', np.eye(3, 4)), row('Tr_imu_to_velo', np.eye(3, 4))]) + '\n')
+    (tmp_path / 'val.txt').write_text('\n'.join(ids) + '\n')
+    assert test_net.read_split(str(tmp_path / 'val.txt')) == ids
+    m = resnet(('__background__', 'Car'), 101)
+    m.create_architecture()
+    m.load_state_dict(fixture.make_state_dict(3))
+    m.cuda().eval()
+    mine = [ids[i] for i in shard_indices(len(ids), 0, 2)]          # rank 0 of 2 -> frames 0 and 2
+    frames, n_obj, _ = test_net.run_split(m, str(root), mine, str(tmp_path / 'result'), dev)
+    assert frames == 2 and mine == ['000000', '000002']
+    written = sorted(os.listdir(str(tmp_path / 'result' / 'data')))
+    assert written == ['000000.txt', '000002.txt']
+    lines = sum(((tmp_path / 'result' / 'data' / f).read_text().splitlines() for f in written), [])
+    assert len(lines) == n_obj
+    for ln in lines:
+        parts = ln.split()
+        assert parts[0] == 'Car' and len(parts) == 16 and all(np.isfinite(float(v)) for v in parts[1:])
