@@ -108,3 +108,25 @@ def test_kitti_split_driver_writes_result_files(dev, tmp_path):
     for ln in lines:
         parts = ln.split()
         assert parts[0] == 'Car' and len(parts) == 16 and all(np.isfinite(float(v)) for v in parts[1:])
+
+
+def test_demo_entry_point(dev, tmp_path, capsys):
+    """python -m stereo_rcnn_amd.demo on PNG files + a calib file + a checkpoint in the reference's format."""
+    from PIL import Image
+    from oracle.dense_align import KITTI_DEMO_CALIB as c            # calibration constants only
+    from stereo_rcnn_amd import demo, fixture
+    l, r = fixture.synthetic_pair(31, 120, 400)
+    Image.fromarray(l).save(str(tmp_path / 'left.png'))
+    Image.fromarray(r).save(str(tmp_path / 'right.png'))
+    row = lambda name, mat: name + ': ' + ' '.join('%.12e' % v for v in np.ravel(mat))
+    p0 = c.p2.copy(); p0[:, 3] = 0.0
+    (tmp_path / 'calib.txt').write_text('\n'.join([row('P0', p0), row('P1', p0), row('P2', c.p2), row('P3', c.p3),
+                                                    row('R0_rect', np.eye(3)), row('Tr_velo_to_cam', np.eye(3, 4))]) + '\n')
+    torch.save({'model': fixture.make_state_dict(3)}, str(tmp_path / 'ckpt.pth'))       # demo.py:81-82 loads checkpoint['model']
+    demo.main(['--left', str(tmp_path / 'left.png'), '--right', str(tmp_path / 'right.png'), '--calib', str(tmp_path / 'calib.txt'),
+               '--checkpoint', str(tmp_path / 'ckpt.pth')])
+    out = capsys.readouterr().out
+    assert 'objects (' in out
+    for ln in out.splitlines():
+        if ln.startswith('Car '):
+            assert len(ln.split()) == 16
