@@ -73,6 +73,11 @@ class SolverPool(object):
             return []
         return self._pool.map(_solve_task, tasks, chunksize=-(-len(tasks) // self._pool._processes))   # one message per worker
 
+    def submit(self, tasks):
+        """Asynchronous form of map(): returns an object whose .get() yields the results."""
+        n = max(len(tasks), 1)
+        return self._pool.map_async(_solve_task, tasks, chunksize=-(-n // self._pool._processes))
+
     def close(self):
         self._pool.close()
         self._pool.join()
@@ -139,6 +144,129 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
         o['aligned'] = True
         o['disparity'] = float(dis_final[i])
     return solved
+
+
+class _Pair(object):
+    """One stereo pair on its way through the streaming pipeline."""
+    __slots__ = ('frame', 'stream', 'stage', 'rec_host', 'event', 'cand', 'alphas', 'pending', 'solved', 'dets', 'succ_host',
+                 'dis_host', 'todo', 'objs')
+
+
+def detect_3d_stream(model, frames, pool, eval_thresh=0.05, class_index=1, dense_align=True, slots=2):
+    """Generator form of detect_3d for a sequence of pairs: yields one object list per frame, in order, and keeps the GPU,
+    the host thread and the solver pool busy at the same time.  frames: iterable of (im_left_data, im_right_data, im_info,
+    calib, im_shape) with device tensors.  Per pair the stages are
+        forward + decode + class NMS + record packing (GPU, async)  ->  borders + 4-DoF tasks (host -> pool, async)
+        ->  dense alignment (GPU, async)  ->  3-DoF tasks (pool, async)  ->  results;
+    every loop iteration launches the next pair's forward and moves each pair in flight ONE stage on, so a wait is always
+    on work that was started an iteration earlier.  Same per-pair results as detect_3d (same kernels, same solver calls)."""
+    import collections
+    from . import distributed as sdist
+    streams = [torch.cuda.Stream() for _ in range(max(1, slots))]
+    inflight = collections.deque()
+
+    def launch(k, frame):
+        p = _Pair()
+        p.frame, p.stream, p.stage, p.objs = frame, streams[k % len(streams)], 1, None
+        l, r, info = frame[0], frame[1], frame[2]
+        p.stream.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(p.stream):
+            out = model(l, r, info, slot=k % len(streams))
+            det = postprocess.decode_detections(*out[:8], info)
+            keep_idx, num = postprocess.class_nms_device(det, class_index, eval_thresh, cfg.TEST.NMS)
+            rec = sdist.pack_records_device(det, keep_idx, num, class_index)
+            p.rec_host = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
+            p.rec_host.copy_(rec, non_blocking=True)
+            p.event = torch.cuda.Event()
+            p.event.record(p.stream)
+        return p
+
+    def advance(p):
+        calib, im_shape = p.frame[3], p.frame[4]
+        if p.stage == 1:                                       # detections are on the host -> borders, 4-DoF tasks
+            p.event.synchronize()
+            rec = p.rec_host.numpy()
+            k = int(rec[0, 0])
+            body = rec[1:k + 1]
+            dl = np.concatenate((body[:, 1:5], body[:, 0:1]), 1)
+            dr = np.concatenate((body[:, 5:9], body[:, 0:1]), 1)
+            do, kpts = body[:, 9:14].copy(), body[:, 14:19].copy()
+            p.dets = (dl, dr, do, kpts)
+            if k == 0:
+                p.objs, p.stage = [], 9
+                return
+            inferred = kitti_utils.infer_boundary(im_shape, dl)
+            for i in range(k):
+                if kpts[i, 4] - kpts[i, 3] < 0.5 * (inferred[i, 1] - inferred[i, 0]):
+                    kpts[i, 3:5] = inferred[i]
+            p.cand = [i for i in range(k) if dl[i, -1] > eval_thresh]
+            p.alphas = [m.atan2(do[i, 3], do[i, 4]) for i in p.cand]
+            p.pending = pool.submit([(4, tuple(im_shape), calib.p2, calib.p3, (a, do[i, 0:3], dl[i, 0:4], dr[i, 0:4], kpts[i]))
+                                     for i, a in zip(p.cand, p.alphas)])
+            p.stage = 2
+        elif p.stage == 2:                                     # 4-DoF results -> dense alignment on the GPU
+            dl, dr, do, kpts = p.dets
+            p.solved = []
+            for i, alpha, (status, state) in zip(p.cand, p.alphas, p.pending.get()):
+                if status > 0:
+                    p.solved.append({'box_left': dl[i, 0:4].copy(), 'box_right': dr[i, 0:4].copy(), 'score': float(dl[i, 4]),
+                                     'dim': do[i, 0:3].astype(np.float64), 'alpha': alpha,
+                                     'xyz': np.array(state[0:3], dtype=np.float64), 'theta': float(state[3]),
+                                     'kpts': kpts[i].copy(), 'aligned': False, 'xyz_init': np.array(state[0:3], dtype=np.float64)})
+            if not p.solved or not dense_align:
+                p.objs, p.stage = p.solved, 9
+                return
+            l, r, info = p.frame[0], p.frame[1], p.frame[2]
+            dev = l.device
+            f32 = lambda rows: torch.tensor(np.asarray(rows), dtype=torch.float32).to(dev, non_blocking=True)
+            with torch.no_grad(), torch.cuda.stream(p.stream):
+                succ, dis = align_parallel(calib, p.frame[5] if len(p.frame) > 5 else float(info.view(-1, 3)[0, 2]), l, r,
+                                           f32([o['box_left'] for o in p.solved]), f32([o['kpts'] for o in p.solved]),
+                                           f32([[o['xyz'][0], o['xyz'][1], o['xyz'][2], o['dim'][0], o['dim'][1], o['dim'][2],
+                                                 o['theta']] for o in p.solved]))
+                p.succ_host = torch.empty(succ.shape, dtype=succ.dtype, pin_memory=True)
+                p.dis_host = torch.empty(dis.shape, dtype=dis.dtype, pin_memory=True)
+                p.succ_host.copy_(succ, non_blocking=True)
+                p.dis_host.copy_(dis, non_blocking=True)
+                p.event = torch.cuda.Event()
+                p.event.record(p.stream)
+            p.stage = 3
+        elif p.stage == 3:                                     # aligned disparities -> 3-DoF tasks
+            p.event.synchronize()
+            succ, dis = p.succ_host.numpy(), p.dis_host.numpy()
+            p.todo = [i for i in range(len(p.solved)) if succ[i] > 0]
+            p.pending = pool.submit([(3, tuple(im_shape), calib.p2, calib.p3,
+                                      (p.solved[i]['alpha'], p.solved[i]['dim'], p.solved[i]['box_left'], float(dis[i]),
+                                       p.solved[i]['kpts'])) for i in p.todo])
+            p.stage = 4
+        elif p.stage == 4:                                     # rectified poses
+            dis = p.dis_host.numpy()
+            for i, (state, z) in zip(p.todo, p.pending.get()):
+                o = p.solved[i]
+                o['xyz'] = np.array([state[0], state[1], z], dtype=np.float64)
+                o['theta'] = float(state[2])
+                o['aligned'] = True
+                o['disparity'] = float(dis[i])
+            p.objs, p.stage = p.solved, 9
+
+    def drain_ready():
+        while inflight and inflight[0].stage == 9:
+            yield inflight.popleft().objs
+
+    for k, frame in enumerate(frames):
+        new = launch(k, frame)
+        for q in list(inflight):
+            if q.stage != 9:
+                advance(q)
+        inflight.append(new)
+        for objs in drain_ready():
+            yield objs
+    while inflight:
+        for q in list(inflight):
+            if q.stage != 9:
+                advance(q)
+        for objs in drain_ready():
+            yield objs
 
 
 def write_kitti_results(result_dir, file_number, calib, objects):

@@ -130,3 +130,28 @@ def test_demo_entry_point(dev, tmp_path, capsys):
     for ln in out.splitlines():
         if ln.startswith('Car '):
             assert len(ln.split()) == 16
+
+
+def test_streaming_pipeline_equals_serial(dev):
+    """detect_3d_stream overlaps the GPU stages and the pooled scipy stages of consecutive pairs; per pair it must return
+    exactly what detect_3d returns (same kernels on the same inputs, same deterministic solver calls)."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib       # calibration constants only
+    from stereo_rcnn_amd import fixture, pipeline
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    m = resnet(('__background__', 'Car'), 101)
+    m.create_architecture()
+    m.load_state_dict(fixture.make_state_dict(3))
+    m.cuda().eval()
+    frames = []
+    for seed in (3, 4, 5):
+        l, r, info = fixture.make_inputs(seed, 200, 660, target_short=320)
+        frames.append((l.to(dev), r.to(dev), info.to(dev), calib, (200, 660, 3), float(info[0, 2])))
+    serial = [pipeline.detect_3d(m, *f[:5]) for f in frames]
+    with pipeline.SolverPool(2) as pool:
+        streamed = list(pipeline.detect_3d_stream(m, frames + frames, pool))
+    assert len(streamed) == 6
+    for want, got in zip(serial + serial, streamed):
+        assert len(want) == len(got)
+        for a, b in zip(want, got):
+            assert np.array_equal(a['box_left'], b['box_left']) and a['aligned'] == b['aligned']
+            assert np.array_equal(a['xyz'], b['xyz']) and a['theta'] == b['theta']

@@ -40,7 +40,16 @@ if __name__ == '__main__':
             objs2 = pipeline.detect_3d(m, l, r, info, calib, (375, 1242, 3), pool=pool)
             torch.cuda.synchronize(); dt = time.time() - t0
             print('pass %d (%d solver processes): %d objects solved, %d aligned, %.1f ms' % (it, workers, len(objs2), sum(o['aligned'] for o in objs2), dt * 1e3))
-    same = len(objs) == len(objs2) and all(np.array_equal(a['xyz'], b['xyz']) for a, b in zip(objs, objs2))
-    print('pool results identical to serial:', same)
+        same = len(objs) == len(objs2) and all(np.array_equal(a['xyz'], b['xyz']) for a, b in zip(objs, objs2))
+        print('pool results identical to serial:', same)
+        # streaming form: forward of pair k+1, solver stages of pairs k, k-1 .. overlap
+        frames = [(l, r, info, calib, (375, 1242, 3), float(info[0, 2]))] * 24
+        list(pipeline.detect_3d_stream(m, frames[:4], pool))
+        torch.cuda.synchronize(); t0 = time.time()
+        res = list(pipeline.detect_3d_stream(m, frames, pool))
+        torch.cuda.synchronize(); dt = time.time() - t0
+        ok = all(len(o) == len(objs) and all(np.array_equal(a['xyz'], b['xyz']) for a, b in zip(objs, o)) for o in res)
+        print('streaming pipeline: %d pairs in %.1f ms = %.1f ms/pair = %.1f pairs/s (%d objects each), identical to serial: %s'
+              % (len(res), dt * 1e3, dt * 1e3 / len(res), len(res) / dt, len(objs), ok))
     for o in objs[:5]:
         print('score %.3f box %s xyz %s theta %.2f' % (o['score'], np.round(o['box_left'], 1), np.round(o['xyz'], 2), o['theta']))
