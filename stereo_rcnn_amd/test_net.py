@@ -36,18 +36,52 @@ def read_png_rgb(path):
         return np.asarray(im.convert('RGB'), dtype=np.uint8)
 
 
-def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None):
-    """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds)."""
+def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4):
+    """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds).
+    With a SolverPool the frames go through pipeline.detect_3d_stream (GPU and solver stages of consecutive frames
+    overlap) and PNG decoding runs `prefetch` frames ahead on host threads; without one, frame by frame."""
+    import collections
+    import concurrent.futures as cf
     t0, n_obj = time.time(), 0
     os.makedirs(os.path.join(result_dir, 'data'), exist_ok=True)
-    for k, frame in enumerate(ids):
-        left = read_image(os.path.join(kitti_root, 'image_2', frame + '.png'))
-        right = read_image(os.path.join(kitti_root, 'image_3', frame + '.png'))
-        calib = kitti_utils.read_obj_calibration(os.path.join(kitti_root, 'calib', frame + '.txt'))
+
+    def load(frame):
+        return (read_image(os.path.join(kitti_root, 'image_2', frame + '.png')),
+                read_image(os.path.join(kitti_root, 'image_3', frame + '.png')),
+                kitti_utils.read_obj_calibration(os.path.join(kitti_root, 'calib', frame + '.txt')))
+
+    calibs = collections.deque()
+
+    def frames():
+        with cf.ThreadPoolExecutor(max_workers=max(1, prefetch)) as ex:
+            pending = collections.deque()
+            it = iter(ids)
+            for frame in it:
+                pending.append(ex.submit(load, frame))
+                if len(pending) <= prefetch:
+                    continue
+                yield to_device(pending.popleft().result())
+            while pending:
+                yield to_device(pending.popleft().result())
+
+    def to_device(loaded):
+        left, right, calib = loaded
         l, scale = engine.preprocess(torch.from_numpy(left).to(device), cfg.TEST.SCALES[0])
         r, _ = engine.preprocess(torch.from_numpy(right).to(device), cfg.TEST.SCALES[0])
-        info = torch.tensor([[l.shape[2], l.shape[3], scale]], dtype=torch.float32, device=device)
-        objs = pipeline.detect_3d(model, l, r, info, calib, left.shape, pool=pool)
+        info = torch.tensor([[l.shape[2], l.shape[3], scale]], dtype=torch.float32).to(device)
+        calibs.append(calib)
+        return (l, r, info, calib, left.shape, float(scale))
+
+    def results():
+        if pool is not None:
+            for objs in pipeline.detect_3d_stream(model, frames(), pool):
+                yield objs
+        else:
+            for f in frames():
+                yield pipeline.detect_3d(model, *f[:5])
+
+    for k, (frame, objs) in enumerate(zip(ids, results())):
+        calib = calibs.popleft()
         open(os.path.join(result_dir, 'data', frame + '.txt'), 'w').close()      # a frame without detections still gets a file
         pipeline.write_kitti_results(result_dir, frame, calib, [o for o in objs if o['aligned']])   # test_net.py:322-330
         n_obj += sum(o['aligned'] for o in objs)

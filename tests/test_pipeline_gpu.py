@@ -108,6 +108,12 @@ def test_kitti_split_driver_writes_result_files(dev, tmp_path):
     for ln in lines:
         parts = ln.split()
         assert parts[0] == 'Car' and len(parts) == 16 and all(np.isfinite(float(v)) for v in parts[1:])
+    # the streaming form (solver pool + overlapped stages + prefetching decode) writes the same files
+    with pipeline.SolverPool(2) as pool:
+        frames2, n_obj2, _ = test_net.run_split(m, str(root), ids, str(tmp_path / 'result2'), dev, pool)
+    assert frames2 == 3
+    for f in written:
+        assert (tmp_path / 'result2' / 'data' / f).read_text() == (tmp_path / 'result' / 'data' / f).read_text()
 
 
 def test_demo_entry_point(dev, tmp_path, capsys):
