@@ -52,7 +52,8 @@ SRCNN_API const char *srcnn_last_error(void);
  * dets (n, dim>=4) float32 [x1,y1,x2,y2,(score)], ALREADY score-sorted.
  * keep_out (n) int32, num_out (1) int32 -- both on the device, as in the
  * reference (nms_gpu.py:8-9).  The greedy reduction also runs on the device:
- * nothing is copied to the host.
+ * nothing is copied to the host.  n <= 16384 boxes per problem.  Keep lists are bit-identical to the reference's own
+ * kernel (built for gfx950 and run on the MI355X by tests/test_ref_kernels_gpu.py).
  */
 SRCNN_API size_t srcnn_nms_workspace_bytes(int n);
 SRCNN_API int srcnn_nms(int *keep_out, const float *dets, int *num_out, int n, int dim, float thresh,
