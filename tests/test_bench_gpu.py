@@ -1,0 +1,44 @@
+"""GPU: bench.py honours the driver's contract (one JSON line with the agreed keys) in both launch forms."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline'}
+
+
+def _check(line, steps, warmup):
+    d = json.loads(line)
+    assert KEYS <= set(d), KEYS - set(d)
+    assert d['steps'] == steps and d['warmup'] == warmup and d['n_gpus'] == 1
+    assert d['unit'] == 'stereo pairs/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic'
+    assert d['value'] > 20 and abs(d['value'] - 1e3 / d['ms_per_step']) < 0.05 * d['value']
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    return d
+
+
+def test_bench_single_process_line(dev):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1'], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _check(out.stdout.strip().splitlines()[-1], 4, 1)
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'stereo pairs/s'
+
+
+def test_bench_under_torch_distributed_run(dev):
+    """the driver's N > 1 launch form, at world size 1 on this box: RCCL init, batched detection gathers, barriers"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                          '127.0.0.1', '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5',
+                          '--warmup', '1', '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _check([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')][-1], 5, 1)
+    assert 'all_gather' in d['config']['parallelism']
