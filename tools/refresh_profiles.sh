@@ -9,7 +9,7 @@ cd $R
 python -m oracle.build > /dev/null 2>&1
 python bench.py > $O/bench_${TAG}_f16x3.json 2> $O/bench_err.log
 python bench.py --precision f32 --no-cpu-baseline > $O/bench_${TAG}_f32.json 2>> $O/bench_err.log
-python bench.py --streams 2 --no-cpu-baseline > $O/bench_${TAG}_f16x3_2inflight.json 2>> $O/bench_err.log
+python bench.py --streams 1 --no-cpu-baseline > $O/bench_${TAG}_f16x3_1inflight.json 2>> $O/bench_err.log
 python tools/time_forward.py f16x3 > $O/stage_times_${TAG}_f16x3.txt 2>&1
 SWEEP=1 python tools/conv_bench.py f16s > $O/conv_microbench_${TAG}_f16x3_split16.txt 2>&1
 python tools/conv_bench.py f32 > $O/conv_microbench_${TAG}_f32.txt 2>&1
