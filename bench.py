@@ -247,7 +247,7 @@ def main():
                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': round(achieved / peak, 4), 'traffic': None,
                         'traffic_note': 'PMC passes are separate rocprofv3 runs: profiles/pmc_r01_f16x3_bench.txt '
-                                        '(74-115 MB HBM-side per conv launch vs ~38 MB algorithmic)',
+                                        '(76-119 MB HBM-side per conv launch vs ~38 MB algorithmic)',
                         'issued_mfma_frac': round(achieved * issued / peak, 4),
                         'launches_per_step': int(cnt.value // nprof),
                         'avg_launch_ms': round(ms.value / max(cnt.value, 1), 5),
