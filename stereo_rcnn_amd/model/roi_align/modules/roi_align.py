@@ -1,33 +1,44 @@
-"""`RoIAlign` / `RoIAlignAvg` modules - reference lib/model/roi_align/modules/roi_align.py:6-29."""
+"""ROIAlign modules with the reference's constructor / call surface (lib/model/roi_align/modules/roi_align.py):
+`RoIAlign(ah, aw, scale)`, `RoIAlignAvg`, `RoIAlignMax`, each called as `module(features, rois, scale)`.
+
+One implementation, three pooling policies: the native lattice op samples an (ah + extra) x (aw + extra) grid of single
+bilinear taps per roi; 'avg' / 'max' reduce every 2x2 neighbourhood of that grid (stride 1) back to ah x aw.  These are
+the op-level drop-ins (NCHW in, NCHW out); `_StereoRCNN.forward` itself uses the fused NHWC pyramid kernel
+(`srcnn_pyramid_roi_align`), which performs the lattice + average in one pass."""
 import torch.nn as nn
-from torch.nn.functional import avg_pool2d
+import torch.nn.functional as F
 
 from ..functions.roi_align import RoIAlignFunction
 
 
-class RoIAlign(nn.Module):
+class _LatticeAlign(nn.Module):
+    extra = 0            # lattice points added per side before pooling
+    reduce = None        # callable on the (n, C, ah + extra, aw + extra) lattice, or None
+
     def __init__(self, aligned_height, aligned_width, spatial_scale):
-        super(RoIAlign, self).__init__()
-        self.aligned_width = int(aligned_width)
-        self.aligned_height = int(aligned_height)
+        super().__init__()
+        # same attribute names as the reference modules; `spatial_scale` is stored but, as there, the scale actually used
+        # is the one passed at call time (the pyramid level decides it)
+        self.aligned_height, self.aligned_width = int(aligned_height), int(aligned_width)
         self.spatial_scale = float(spatial_scale)
 
     def forward(self, features, rois, scale):
-        return RoIAlignFunction(self.aligned_height, self.aligned_width, scale)(features, rois)
+        op = RoIAlignFunction(self.aligned_height + self.extra, self.aligned_width + self.extra, scale)
+        lattice = op(features, rois)
+        return lattice if self.reduce is None else type(self).reduce(lattice)
 
 
-class RoIAlignAvg(nn.Module):
-    """(A+1)x(A+1) point lattice + 2x2/stride-1 average (roi_align.py:26-29).
+class RoIAlign(_LatticeAlign):
+    """The bare lattice."""
 
-    This module is the op-level drop-in (NCHW in / NCHW out).  The forward pass of
-    `_StereoRCNN` uses the fused NHWC pyramid kernel (srcnn_pyramid_roi_align) instead."""
 
-    def __init__(self, aligned_height, aligned_width, spatial_scale):
-        super(RoIAlignAvg, self).__init__()
-        self.aligned_width = int(aligned_width)
-        self.aligned_height = int(aligned_height)
-        self.spatial_scale = float(spatial_scale)
+class RoIAlignAvg(_LatticeAlign):
+    """(A+1) x (A+1) lattice, mean of each 2x2 neighbourhood: what the Stereo R-CNN heads use."""
+    extra = 1
+    reduce = staticmethod(lambda t: F.avg_pool2d(t, kernel_size=2, stride=1))
 
-    def forward(self, features, rois, scale):
-        x = RoIAlignFunction(self.aligned_height + 1, self.aligned_width + 1, scale)(features, rois)
-        return avg_pool2d(x, kernel_size=2, stride=1)
+
+class RoIAlignMax(_LatticeAlign):
+    """(A+1) x (A+1) lattice, max of each 2x2 neighbourhood."""
+    extra = 1
+    reduce = staticmethod(lambda t: F.max_pool2d(t, kernel_size=2, stride=1))
