@@ -54,6 +54,20 @@ def net_golden(net, seed, h, w, short, tag):
     print('reference_net_%s.npz' % tag, {k: v.shape for k, v in d.items()})
 
 
+def net_golden_batch2(net):
+    """BASELINE configs[2] form of the forward: two different pairs in one batch (rois carry the batch index)."""
+    a = fixture.make_inputs(3, 120, 400, target_short=192)
+    b = fixture.make_inputs(4, 120, 400, target_short=192)
+    l, r, info = torch.cat((a[0], b[0]), 0), torch.cat((a[1], b[1]), 0), torch.cat((a[2], b[2]), 0)
+    z, nb = torch.zeros(2, 1, 5), torch.zeros(2)
+    with torch.no_grad():
+        out = net(l, r, info, z, z, z, z, z, nb)
+    d = {n: out[i].detach().numpy().astype(np.float32) for i, n in enumerate(NAMES)}
+    d['input_shape'] = np.asarray(l.shape)
+    np.savez_compressed(os.path.join(HERE, 'reference_net_small_b2_seeds3_4.npz'), **d)
+    print('reference_net_small_b2_seeds3_4.npz', {k: v.shape for k, v in d.items()})
+
+
 def anchors_golden():
     from generate_anchors import generate_anchors_all_pyramids
     from model.utils.config import cfg
@@ -345,6 +359,7 @@ if __name__ == '__main__':
         net = reference_model(3)
         net_golden(net, 3, 120, 400, 192, 'small_r101_seed3')
         net_golden(net, 3, 375, 1242, 600, 'full_r101_seed3')
+        net_golden_batch2(net)
     if 'misc' in which:
         d = {}
         d.update(anchors_golden())

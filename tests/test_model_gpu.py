@@ -405,3 +405,25 @@ def test_hip_decode_and_class_nms_vs_reference_demo_script(dev):
     assert float((cls['dets_right'].cpu() - torch.from_numpy(m['cls_dets_right'])).abs().max()) < 2e-3
     assert float((cls['dim_orien'].cpu() - torch.from_numpy(m['cls_dim_orien'])).abs().max()) < 1e-6
     assert float((cls['kpts'].cpu() - torch.from_numpy(m['cls_kpts'])).abs().max()) < 2e-3
+
+
+def test_hip_forward_batch_of_two_vs_reference_code_golden(dev):
+    """B = 2 (two different pairs) through the HIP forward vs the reference's own code on the same batch."""
+    from stereo_rcnn_amd import fixture
+    g = np.load(os.path.join(GOLD, 'reference_net_small_b2_seeds3_4.npz'))
+    m, _ = _build_model(dev)
+    m.precision = 'f16x3'
+    a = fixture.make_inputs(3, 120, 400, target_short=192)
+    b = fixture.make_inputs(4, 120, 400, target_short=192)
+    l, r, info = torch.cat((a[0], b[0]), 0), torch.cat((a[1], b[1]), 0), torch.cat((a[2], b[2]), 0)
+    with torch.no_grad():
+        out = m(l.to(dev), r.to(dev), info.to(dev))
+    torch.cuda.synchronize()
+    for img in range(2):
+        ro = {k: torch.from_numpy(g[k][img:img + 1] if g[k].ndim == 3 else g[k][img * 300:(img + 1) * 300])
+              for k in ('rois_left', 'rois_right', 'cls_prob', 'bbox_pred', 'dim_orien_pred', 'kpts_prob', 'left_border_prob',
+                        'right_border_prob')}
+        o_img = [out[0][img:img + 1], out[1][img:img + 1], out[2][img:img + 1], out[3][img:img + 1], out[4][img:img + 1],
+                 out[5][img * 300:(img + 1) * 300], out[6][img * 300:(img + 1) * 300], out[7][img * 300:(img + 1) * 300]]
+        frac, errs = _check_end_to_end(o_img, ro['rois_left'][0], ro['rois_right'][0], ro, 0.95)
+        assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (img, errs)

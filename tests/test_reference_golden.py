@@ -260,3 +260,23 @@ def test_post_network_flow_stage_by_stage_vs_reference_demo_script(misc):
         dxy.append(max(abs(state[0] - want[0]), abs(state[1] - want[1])))
     assert k == misc['pipe_rectified'].shape[0]
     assert max(dz) < 1e-6 and np.median(dxy) < 1e-2, (max(dz), np.median(dxy), max(dxy))
+
+
+def test_oracle_forward_batch_of_two_equals_reference_code():
+    """Two different pairs in one batch (BASELINE configs[2]): per image, the oracle equals the reference code."""
+    from oracle import net as onet
+    from stereo_rcnn_amd import fixture
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    g = np.load(os.path.join(GOLD, 'reference_net_small_b2_seeds3_4.npz'))
+    a = fixture.make_inputs(3, 120, 400, target_short=192)
+    b = fixture.make_inputs(4, 120, 400, target_short=192)
+    l, r, info = torch.cat((a[0], b[0]), 0), torch.cat((a[1], b[1]), 0), torch.cat((a[2], b[2]), 0)
+    out = onet.forward(fixture.make_state_dict(3), l, r, info)
+    for img in range(2):
+        ok, idx = _match(torch.from_numpy(g['rois_left'][img]), out['rois_left'][img])
+        assert int(ok.sum()) >= 297 and float(out['rois_left'][img][:, 0].min()) == img
+        for n in NAMES:
+            ref_t, got_t = torch.from_numpy(g[n]), out[n]
+            ref_t = ref_t[img] if ref_t.dim() == 3 else ref_t[img * 300:(img + 1) * 300]
+            got_t = got_t[img] if got_t.dim() == 3 else got_t[img * 300:(img + 1) * 300]
+            assert torch.equal(got_t[idx[ok]], ref_t[ok]), (img, n)
