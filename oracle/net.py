@@ -17,9 +17,6 @@ Parity status: PINNED -- `forward` reproduces, bit for bit on every coordinate-m
 reference's own `_StereoRCNN.forward` run in the build container with the same seeded weights and inputs
 (tests/golden/reference_net_*.npz, tests/test_reference_golden.py; shims: tests/golden/reference_shims.py).
 """
-import math
-
-import numpy as np
 import torch
 import torch.nn.functional as F
 
