@@ -116,7 +116,7 @@ def _set_plan(d, plan):
 
 
 def _tune(d, key, device):
-    """Times each candidate plan with HIP events on the current stream (3 runs, best of)."""
+    """Times each candidate plan with HIP events on the current stream (5 runs, the first discarded, best of the rest)."""
     L = _lib.lib()
     M = d.B * d.OH * d.OW
     nkt = d.KH * d.KW * d.Cin // 32
@@ -146,7 +146,7 @@ def _tune(d, key, device):
         need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
         ws = _lib.workspace(need, device, "conv")
         t_best = None
-        for rep in range(3):
+        for rep in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), st), "srcnn_conv2d(tune)")
