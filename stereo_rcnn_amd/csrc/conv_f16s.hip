@@ -18,6 +18,7 @@
 //     outstanding across barriers -- the L2 -> LDS path (~56 B/clk/CU) runs at throughput instead of
 //     one latency per K tile.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace srcnn {
 
@@ -107,47 +108,71 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
             a_base[g] = zero;
         }
     }
-    const char *bh_base[BG], *bl_base[BG];
-    bool b_ok[BG];
-#pragma unroll
-    for (int g = 0; g < BG; ++g) {
-        const int n = n0 + wave * 16 * BG + g * 16 + drow;
-        b_ok[g] = n < p.Cout;
-        const size_t off = ((size_t)(b_ok[g] ? n : 0) * p.K + dchunk * 8) * 2;
-        bh_base[g] = reinterpret_cast<const char *>(p.w) + off;
-        bl_base[g] = reinterpret_cast<const char *>(p.w_lo) + off;
-    }
-
+    // ---- per-lane DMA source cursors.  A: pointer to the current (tap, channel tile) run of the lane's row, or the
+    //      zero page with step 0 when the tap falls outside the image / the row is past M.  Re-derived only when the
+    //      tap changes (every Cin/32 K tiles); otherwise one 64-bit add per K tile.  B: (row n, k) cursor, step 64 B.
+    const char *a_cur[AG];
+    int a_step[AG];
+    const char *bh_cur[BG], *bl_cur[BG];
+    int b_step[BG];
     int ld_kh, ld_kw, ld_c0;
     {
         const int tap = kt_begin / p.ctiles;
-        ld_c0 = (kt_begin - tap * p.ctiles) * BK;
-        ld_kh = tap / p.KW;
-        ld_kw = tap - ld_kh * p.KW;
+        const int kh = tap / p.KW;
+        ld_c0 = __builtin_amdgcn_readfirstlane((kt_begin - tap * p.ctiles) * BK);   // keep the tap state scalar
+        ld_kh = __builtin_amdgcn_readfirstlane(kh);
+        ld_kw = __builtin_amdgcn_readfirstlane(tap - kh * p.KW);
     }
-    auto dma_tile = [&](int kt, int stage) {
-        const int kh = ld_kh, kw = ld_kw, c0 = ld_c0;
+    auto retap = [&]() {
+        const size_t tap_off = ((size_t)(ld_kh * p.W + ld_kw) * p.xcs + ld_c0) * 4;   // wave-uniform byte offset
+#pragma unroll
+        for (int g = 0; g < AG; ++g) {
+            const int ih = a_ih0[g] + ld_kh, iw = a_iw0[g] + ld_kw;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            a_cur[g] = ok ? a_base[g] + tap_off : zero;
+            a_step[g] = ok ? BK * 4 : 0;
+        }
+    };
+    retap();
+#pragma unroll
+    for (int g = 0; g < BG; ++g) {
+        const int n = n0 + wave * 16 * BG + g * 16 + drow;
+        const bool ok = n < p.Cout;
+        const size_t off = ((size_t)(ok ? n : 0) * p.K + (size_t)kt_begin * BK + dchunk * 8) * 2;
+        bh_cur[g] = ok ? reinterpret_cast<const char *>(p.w) + off : zero;
+        bl_cur[g] = ok ? reinterpret_cast<const char *>(p.w_lo) + off : zero;
+        b_step[g] = ok ? BK * 2 : 0;
+    }
+    // one DMA instruction of the current K tile into ring stage at `stage_base` (halves); pc is a compile-time index
+    // after unrolling: pieces 0..2*AG-1 = A (hi, lo per 16-row group), then B.
+    auto dma_piece = [&](int pc, _Float16 *stage_base) {
+        _Float16 *sa_hi = stage_base + (wave * 16 * AG) * SROW;
+        _Float16 *sb_hi = stage_base + 2 * PANEL_A + (wave * 16 * BG) * SROW;
+        if (pc < 2 * AG) {
+            const int g = pc >> 1;
+            if (pc & 1) dma16(a_cur[g] + 16, sa_hi + PANEL_A + g * 16 * SROW);
+            else dma16(a_cur[g], sa_hi + g * 16 * SROW);
+        } else {
+            const int g = (pc - 2 * AG) >> 1;
+            if (pc & 1) dma16(bl_cur[g], sb_hi + PANEL_B + g * 16 * SROW);
+            else dma16(bh_cur[g], sb_hi + g * 16 * SROW);
+        }
+    };
+    // move the cursors to the next K tile
+    auto advance = [&]() {
         ld_c0 += BK;
         if (ld_c0 == p.Cin) {
             ld_c0 = 0;
             if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
-        }
-        _Float16 *sa_hi = smem + stage * STAGE + (wave * 16 * AG) * SROW;
-        _Float16 *sb_hi = smem + stage * STAGE + 2 * PANEL_A + (wave * 16 * BG) * SROW;
-        const size_t tap_off = ((size_t)(kh * p.W + kw) * p.xcs + c0) * 4;   // wave-uniform byte offset
+            retap();
+        } else {
 #pragma unroll
-        for (int g = 0; g < AG; ++g) {
-            const int ih = a_ih0[g] + kh, iw = a_iw0[g] + kw;
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const char *src = ok ? a_base[g] + tap_off : zero;
-            dma16(src, sa_hi + g * 16 * SROW);
-            dma16(ok ? src + 16 : zero, sa_hi + PANEL_A + g * 16 * SROW);
+            for (int g = 0; g < AG; ++g) a_cur[g] += a_step[g];
         }
-        const size_t kb = (size_t)kt * BK * 2;
 #pragma unroll
         for (int g = 0; g < BG; ++g) {
-            dma16(b_ok[g] ? bh_base[g] + kb : zero, sb_hi + g * 16 * SROW);
-            dma16(b_ok[g] ? bl_base[g] + kb : zero, sb_hi + PANEL_B + g * 16 * SROW);
+            bh_cur[g] += b_step[g];
+            bl_cur[g] += b_step[g];
         }
     };
 
@@ -169,69 +194,116 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                 for (int x = 0; x < (NX > 0 ? NX : 1); ++x) accx[x][i][j][e] = 0.f;
             }
 
-    // ---- prologue: fill NS-1 stages, wait for the first
+    // MFMA operand fragments of one 16-wide K slice
+    struct Frag {
+        half8 ah[MR], al[MR], bh[NR], bl[NR];
+    };
+    const int a_row = (wm * 32 * MR + li) * SROW + r_sw, b_row = 2 * PANEL_A + (wn * 32 * NR + li) * SROW + r_sw;
+    const int k_flip = (r_sw ^ 16) - r_sw;                     // second 16-wide slice of the swizzled row
+    auto read_frag = [&](Frag &f, const _Float16 *stage_base, int kk) {
+        const _Float16 *sah = stage_base + a_row + (kk ? k_flip : 0);
+        const _Float16 *sbh = stage_base + b_row + (kk ? k_flip : 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            f.ah[i] = *reinterpret_cast<const half8 *>(sah + i * 32 * SROW);
+            f.al[i] = *reinterpret_cast<const half8 *>(sah + PANEL_A + i * 32 * SROW);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            f.bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * SROW);
+            f.bl[j] = *reinterpret_cast<const half8 *>(sbh + PANEL_B + j * 32 * SROW);
+        }
+    };
+    // the 3*MR*NR MFMAs of one slice; `between(m)` runs after the m-th (DMA pieces are slotted in there so that
+    // their issue cost hides under the matrix pipe instead of forming a block in which no wave of the SIMD computes)
+    constexpr int NM = 3 * MR * NR;
+    auto mfma_slice = [&](const Frag &f, auto &&between) {
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                floatx16 &d = NX > 0 ? accx[0][i][j] : acc[i][j];
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], d, 0, 0, 0);
+                between(m++);
+            }
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                floatx16 &d = NX > 1 ? accx[NX > 1 ? 1 : 0][i][j] : (NX > 0 ? accx[0][i][j] : acc[i][j]);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], d, 0, 0, 0);
+                between(m++);
+            }
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                between(m++);
+            }
+    };
+
+    // ---- prologue: fill NS-1 stages, wait for the first, fetch its first slice
     const int nk = kt_end - kt_begin;
     if (p.stamp) st1 = __builtin_readcyclecounter();
     {
         const int pre = min(NS - 1, nk);
-        for (int i = 0; i < pre; ++i) dma_tile(kt_begin + i, i);
+        for (int i = 0; i < pre; ++i) {
+#pragma unroll
+            for (int pc = 0; pc < LPT; ++pc) dma_piece(pc, smem + i * STAGE);
+            advance();
+        }
         if (NS >= 4 && pre == 3) wait_vm_barrier<2 * LPT>();
         else if (NS >= 3 && pre == 2) wait_vm_barrier<LPT>();
         else wait_vm_barrier<0>();
     }
     if (p.stamp) st2 = __builtin_readcyclecounter();
+    Frag f0, f1;
+    read_frag(f0, smem, 0);
     int cs = 0, ls = NS - 1;                                  // compute stage / load stage of the ring
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (kt + NS - 1 < kt_end) dma_tile(kt + NS - 1, ls);
+    // One K tile.  Entry: slice 0 of tile kt is in f0.  Phase A: fetch slice 1, run slice 0's MFMAs with the DMA of
+    // tile kt+NS-1 slotted between them.  Phase B: wait until tile kt+1 (only) has landed, barrier (every wave has
+    // finished reading this stage, everybody's part of tile kt+1 is visible), fetch slice 0 of tile kt+1 and run
+    // slice 1's MFMAs over that fetch.  LDS latency and DMA issue never stall the matrix pipe of a wave in steady state.
+    auto k_tile = [&](auto with_dma, int n_after, bool has_next) {
+        constexpr bool DMA = decltype(with_dma)::value;
+        const _Float16 *cbase = smem + cs * STAGE;
+        _Float16 *lbase = smem + ls * STAGE;
+        mfma_slice(f0, [&](int m) {
+            if (m == 0) {
+                // slice 1 is fetched behind the first MFMA: the wait in front of that MFMA then covers only slice 0,
+                // which has had a whole slice of MFMAs to arrive
+                __builtin_amdgcn_sched_barrier(0);
+                read_frag(f1, cbase, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (DMA) {
+#pragma unroll
+                for (int pc = 0; pc < LPT; ++pc)
+                    if (1 + pc * (NM - 1) / LPT == m) {
+                        __builtin_amdgcn_sched_barrier(0);    // pin the piece to its slot
+                        dma_piece(pc, lbase);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+        });
+        if (DMA) advance();
+        // slice 1 has landed in registers -- said with the builtin so that the compiler's own wait-count tracking knows
+        // it (it cannot see into the asm below) and puts no lgkmcnt wait between the next fetch and slice 1's MFMAs
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0), vmcnt / expcnt untouched
+        if (DMA) wait_vm_barrier<(NS - 2) * LPT>();
+        else if (NS >= 4 && n_after == 1) wait_vm_barrier<LPT>();
+        else wait_vm_barrier<0>();
         ls = (ls + 1 == NS) ? 0 : ls + 1;
-        const _Float16 *sah = smem + cs * STAGE + (wm * 32 * MR + li) * SROW + r_sw;
-        const _Float16 *sal = sah + PANEL_A;
-        const _Float16 *sbh = smem + cs * STAGE + 2 * PANEL_A + (wn * 32 * NR + li) * SROW + r_sw;
-        const _Float16 *sbl = sbh + PANEL_B;
         cs = (cs + 1 == NS) ? 0 : cs + 1;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            const int ko = kk ? ((r_sw ^ 16) - r_sw) : 0;
-            half8 ah[MR], al[MR], bh[NR], bl[NR];
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                ah[i] = *reinterpret_cast<const half8 *>(sah + i * 32 * SROW + ko);
-                al[i] = *reinterpret_cast<const half8 *>(sal + i * 32 * SROW + ko);
-            }
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * SROW + ko);
-                bl[j] = *reinterpret_cast<const half8 *>(sbl + j * 32 * SROW + ko);
-            }
-            if (kk == BK / 16 - 1) {
-                // every wave has now read the whole stage: wait for tile kt+1 (only), barrier, and let the
-                // last MFMAs of this tile run behind it.  n_after = tiles issued after tile kt+1.
-                const int n_after = min(kt + NS - 1, kt_end - 1) - (kt + 1);
-                if (NS >= 4 && n_after == 2) wait_vm_barrier<2 * LPT>();
-                else if (NS >= 3 && n_after == 1) wait_vm_barrier<LPT>();
-                else wait_vm_barrier<0>();
-            }
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    floatx16 &d = NX > 0 ? accx[0][i][j] : acc[i][j];
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], d, 0, 0, 0);
-                }
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    floatx16 &d = NX > 1 ? accx[NX > 1 ? 1 : 0][i][j] : (NX > 0 ? accx[0][i][j] : acc[i][j]);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], d, 0, 0, 0);
-                }
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int j = 0; j < NR; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
+        if (has_next) read_frag(f0, smem + cs * STAGE, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_slice(f1, [](int) {});
+    };
+    int kt = kt_begin;
+    for (; kt + NS - 1 < kt_end; ++kt) k_tile(std::true_type{}, NS - 2, true);
+    for (; kt < kt_end; ++kt) k_tile(std::false_type{}, kt_end - 2 - kt, kt + 1 < kt_end);
     if (p.stamp) st3 = __builtin_readcyclecounter();
     if (NX > 0) {
 #pragma unroll
