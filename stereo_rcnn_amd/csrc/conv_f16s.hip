@@ -200,19 +200,34 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     };
     const int a_row = (wm * 32 * MR + li) * SROW + r_sw, b_row = 2 * PANEL_A + (wn * 32 * NR + li) * SROW + r_sw;
     const int k_flip = (r_sw ^ 16) - r_sw;                     // second 16-wide slice of the swizzled row
-    auto read_frag = [&](Frag &f, const _Float16 *stage_base, int kk) {
+    constexpr int NRD = 2 * (MR + NR);                        // ds_read_b128 per slice
+    auto read_piece = [&](Frag &f, const _Float16 *stage_base, int kk, int r) {
         const _Float16 *sah = stage_base + a_row + (kk ? k_flip : 0);
         const _Float16 *sbh = stage_base + b_row + (kk ? k_flip : 0);
-#pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            f.ah[i] = *reinterpret_cast<const half8 *>(sah + i * 32 * SROW);
-            f.al[i] = *reinterpret_cast<const half8 *>(sah + PANEL_A + i * 32 * SROW);
+        if (r < 2 * MR) {
+            const int i = r >> 1;
+            if (r & 1) f.al[i] = *reinterpret_cast<const half8 *>(sah + PANEL_A + i * 32 * SROW);
+            else f.ah[i] = *reinterpret_cast<const half8 *>(sah + i * 32 * SROW);
+        } else {
+            const int j = (r - 2 * MR) >> 1;
+            if (r & 1) f.bl[j] = *reinterpret_cast<const half8 *>(sbh + PANEL_B + j * 32 * SROW);
+            else f.bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * SROW);
         }
+    };
+    auto read_frag = [&](Frag &f, const _Float16 *stage_base, int kk) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            f.bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * SROW);
-            f.bl[j] = *reinterpret_cast<const half8 *>(sbh + PANEL_B + j * 32 * SROW);
-        }
+        for (int r = 0; r < NRD; ++r) read_piece(f, stage_base, kk, r);
+    };
+    // fetch of a slice spread behind the first MFMAs of the other slice, two reads per MFMA: the matrix pipe is fed
+    // before the LDS queue (all waves fetch at the same moment, right after the barrier) has drained
+    auto read_slot = [&](Frag &f, const _Float16 *stage_base, int kk, int m) {
+#pragma unroll
+        for (int r = 0; r < NRD; ++r)
+            if (r / 2 == m) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_piece(f, stage_base, kk, r);
+                __builtin_amdgcn_sched_barrier(0);
+            }
     };
     // the 3*MR*NR MFMAs of one slice; `between(m)` runs after the m-th (DMA pieces are slotted in there so that
     // their issue cost hides under the matrix pipe instead of forming a block in which no wave of the SIMD computes)
@@ -271,13 +286,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
         const _Float16 *cbase = smem + cs * STAGE;
         _Float16 *lbase = smem + ls * STAGE;
         mfma_slice(f0, [&](int m) {
-            if (m == 0) {
-                // slice 1 is fetched behind the first MFMA: the wait in front of that MFMA then covers only slice 0,
-                // which has had a whole slice of MFMAs to arrive
-                __builtin_amdgcn_sched_barrier(0);
-                read_frag(f1, cbase, 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            read_slot(f1, cbase, 1, m);                      // slice 1: not needed before phase B
             if (DMA) {
 #pragma unroll
                 for (int pc = 0; pc < LPT; ++pc)
@@ -297,9 +306,11 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
         else wait_vm_barrier<0>();
         ls = (ls + 1 == NS) ? 0 : ls + 1;
         cs = (cs + 1 == NS) ? 0 : cs + 1;
-        if (has_next) read_frag(f0, smem + cs * STAGE, 0);
+        const _Float16 *nbase = smem + cs * STAGE;
         __builtin_amdgcn_sched_barrier(0);
-        mfma_slice(f1, [](int) {});
+        mfma_slice(f1, [&](int m) {
+            if (has_next) read_slot(f0, nbase, 0, m);        // slice 0 of the next tile: needed at the next phase A
+        });
     };
     int kt = kt_begin;
     for (; kt + NS - 1 < kt_end; ++kt) k_tile(std::true_type{}, NS - 2, true);
