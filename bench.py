@@ -5,7 +5,7 @@ batch=1, 300 proposals, no dense-align  (BASELINE.json configs[1]).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one pass of the hot path over one synthetic stereo pair per GPU (batch = 1 per forward; by default two
+One step = one pass of the hot path over one synthetic stereo pair per GPU (batch = 1 per forward; by default three
 forwards are in flight per GPU on separate HIP streams, `--streams 1` = strictly sequential, also reported):
   _StereoRCNN.forward (trunk+FPN on both eyes, stereo RPN, proposals, ROIAlign, heads)
   + detection decode + per-class NMS  (the reference's det_time region, demo.py:137-220, plus :231-257)
@@ -48,9 +48,9 @@ def parse():
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f16x3',
                     help="conv engine: f16x3 = fp32-class error-compensated split on the f16 MFMA (default, "
                          "passes the same parity tests), f32 = exact fp32 MFMA")
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--streams', type=int, default=3,
                     help='stereo pairs in flight per GPU: each forward is batch=1 on its own HIP stream and buffer set '
-                         '(default 2: the second pair fills the launch-synchronous phases of the small layers); '
+                         '(default 3: the other pairs fill the launch-synchronous phases and the idle CUs of the small layers); '
                          '--streams 1 = strictly one pair at a time (also reported as one_pair_at_a_time)')
     ap.add_argument('--gather-every', type=int, default=8,
                     help='(multi-GPU) steps whose detection records share one RCCL all_gather')
@@ -185,6 +185,7 @@ def main():
         t0 = time.perf_counter()
         run_steps(args.steps)
         finish_gathers()
+        host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / args.steps   # host time to launch one step (not a GPU time)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -270,6 +271,7 @@ def main():
                                    '(network input %dx%d), 300 proposals, forward + decode + class NMS, no dense-align'
                                    % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
                        'weights': 'seeded random init, reference state_dict schema', 'hipgraph': use_graph,
+                       'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
                        'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single,
                        'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},
             'roofline': roofline,
