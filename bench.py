@@ -52,6 +52,9 @@ def parse():
                     help='stereo pairs in flight per GPU: each forward is batch=1 on its own HIP stream and buffer set '
                          '(default 3: the other pairs fill the launch-synchronous phases and the idle CUs of the small layers); '
                          '--streams 1 = strictly one pair at a time (also reported as one_pair_at_a_time)')
+    ap.add_argument('--plans', default='',
+                    help='JSON file of autotuned conv plans: loaded if it exists (no tuning launches in this process), '
+                         'written after the run otherwise (used to keep the rocprofv3 kernel statistics free of trial plans)')
     ap.add_argument('--gather-every', type=int, default=8,
                     help='(multi-GPU) steps whose detection records share one RCCL all_gather')
     ap.add_argument('--height', type=int, default=375)
@@ -113,6 +116,7 @@ def main():
     gather_stream = torch.cuda.Stream() if use_dist else None
 
     S = max(1, args.streams)
+    plans_loaded = bool(args.plans) and os.path.exists(args.plans) and engine.load_plans(args.plans) > 0
     streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [None]
 
     # detections of G consecutive steps are packed into one buffer and gathered by ONE RCCL all_gather
@@ -271,7 +275,7 @@ def main():
                                    '(network input %dx%d), 300 proposals, forward + decode + class NMS, no dense-align'
                                    % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
                        'weights': 'seeded random init, reference state_dict schema', 'hipgraph': use_graph,
-                       'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
+                       'host_enqueue_ms_per_step': round(host_enqueue_ms, 3), 'plans_preloaded': plans_loaded,
                        'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single,
                        'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},
             'roofline': roofline,
@@ -279,6 +283,8 @@ def main():
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(3, args.height, args.width)
         print(json.dumps(res), flush=True)
+    if args.plans and not plans_loaded and rank == 0:
+        engine.save_plans(args.plans)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -107,6 +107,23 @@ _CANDIDATES = [(2, 2, 4, 2), (2, 1, 4, 2), (1, 2, 4, 2), (1, 1, 4, 2)]
 _CANDIDATES_F16S = [(4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
 
 
+def save_plans(path):
+    """Write the tuned plans (shape key -> plan) as JSON: a later process on the same GPU model can skip the tuning launches."""
+    import json
+    with open(path, 'w') as f:
+        json.dump([[list(k), list(v)] for k, v in _TUNED.items()], f)
+
+
+def load_plans(path):
+    """Adopt plans written by save_plans(); shapes not in the file are still tuned on first use.  Returns the count."""
+    import json
+    with open(path) as f:
+        rows = json.load(f)
+    for k, v in rows:
+        _TUNED[tuple(k)] = tuple(v)
+    return len(rows)
+
+
 def _shape_key(cw, B, H, W, OH, OW, x_cstride, precision, fmts=(0, 0, 0)):
     return (precision, B, H, W, OH, OW, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, cw.mode, x_cstride) + tuple(fmts)
 
