@@ -47,6 +47,19 @@ __device__ __forceinline__ void wait_vm_barrier()
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// debug form of the above (only when the stamp hook is armed): how long the wave sat in the vmcnt wait and in the barrier
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier_timed(unsigned long long &w_vm, unsigned long long &w_bar)
+{
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long t2 = __builtin_readcyclecounter();
+    w_vm += t1 - t0;
+    w_bar += t2 - t1;
+}
+
 extern __shared__ __attribute__((aligned(1024))) _Float16 smem[];
 
 // MR/NR: per-WAVE tile in 32x32 MFMA tiles; WM x 2 waves per workgroup -> workgroup tile (32*MR*WM) x (64*NR).
@@ -275,6 +288,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     }
     if (p.stamp) st2 = __builtin_readcyclecounter();
     Frag f0, f1;
+    unsigned long long w_vm = 0, w_bar = 0;                   // debug: time in the steady-state vmcnt waits / barriers
     read_frag(f0, smem, 0);
     int cs = 0, ls = NS - 1;                                  // compute stage / load stage of the ring
     // One K tile.  Entry: slice 0 of tile kt is in f0.  Phase A: fetch slice 1, run slice 0's MFMAs with the DMA of
@@ -301,7 +315,8 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
         // slice 1 has landed in registers -- said with the builtin so that the compiler's own wait-count tracking knows
         // it (it cannot see into the asm below) and puts no lgkmcnt wait between the next fetch and slice 1's MFMAs
         __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0), vmcnt / expcnt untouched
-        if (DMA) wait_vm_barrier<(NS - 2) * LPT>();
+        if (DMA && p.stamp) wait_vm_barrier_timed<(NS - 2) * LPT>(w_vm, w_bar);
+        else if (DMA) wait_vm_barrier<(NS - 2) * LPT>();
         else if (NS >= 4 && n_after == 1) wait_vm_barrier<LPT>();
         else wait_vm_barrier<0>();
         ls = (ls + 1 == NS) ? 0 : ls + 1;
@@ -396,6 +411,8 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
         if (p.stamp && t == 0) {
             unsigned long long *o = p.stamp + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
             o[8] = rt0;
+            o[10] = w_vm;
+            o[11] = w_bar;
             o[9] = __builtin_amdgcn_s_memrealtime();
             o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4;
             o[5] = __builtin_readcyclecounter();

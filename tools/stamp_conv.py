@@ -47,6 +47,7 @@ names = ['set-up', 'first tile', 'K loop', 'acc -> LDS', 'bias/res/store']
 print('%s plan %s: %d workgroups (%d stamped), kernel %.1f us by events (includes the launch call)' % (name, plan, nblk, len(st), e0.elapsed_time(e1) * 1e3))
 for i, n in enumerate(names):
     print('  %-16s median %7d clk  p90 %7d' % (n, np.median(ph[:, i]), np.percentile(ph[:, i], 90)))
+print('  of the K loop, wave 0 sat in the vmcnt wait (data not landed) median %7d clk, in the barrier median %7d clk' % (np.median(st[:, 10]), np.median(st[:, 11])))
 tot = st[:, 5] - st[:, 0]
 print('  %-16s median %7d clk  p90 %7d' % ('workgroup total', np.median(tot), np.percentile(tot, 90)))
 # launch shape on the chip-wide 100 MHz clock
