@@ -20,6 +20,10 @@
 #include "conv_common.h"
 #include <type_traits>
 
+#ifndef SRCNN_PB_MAX_NS
+#define SRCNN_PB_MAX_NS 2          // ring depths up to this use the issue-behind-the-barrier DMA schedule (see the kernel)
+#endif
+
 namespace srcnn {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -272,36 +276,45 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
             }
     };
 
-    // ---- prologue: fill NS-1 stages, wait for the first, fetch its first slice
+    // ---- prologue: fill the ring, wait for the first tile, fetch its first slice.
+    // Two issue schedules for the DMA of a K tile (PB, per ring depth):
+    //   PB = false: tile kt+NS-1 is issued during phase A of tile kt (between slice 0's MFMAs) -> NS-1 tiles in flight;
+    //   PB = true : tile kt+NS is issued during phase B of tile kt, right behind the barrier that frees the stage tile kt
+    //               occupied -> NS tiles in flight, half a K tile more latency cover from the same LDS.  The shallow
+    //               rings need it (a 2-stage ring otherwise waits for every tile: profiles/stamp_conv_r01.txt).
+    constexpr bool PB = (NS <= SRCNN_PB_MAX_NS);
+    constexpr int PRE = PB ? NS : NS - 1;                     // tiles issued before the first MFMA
     const int nk = kt_end - kt_begin;
     if (p.stamp) st1 = __builtin_readcyclecounter();
     {
-        const int pre = min(NS - 1, nk);
+        const int pre = min(PRE, nk);
         for (int i = 0; i < pre; ++i) {
 #pragma unroll
             for (int pc = 0; pc < LPT; ++pc) dma_piece(pc, smem + i * STAGE);
             advance();
         }
-        if (NS >= 4 && pre == 3) wait_vm_barrier<2 * LPT>();
-        else if (NS >= 3 && pre == 2) wait_vm_barrier<LPT>();
+        if (PRE >= 4 && pre == 4) wait_vm_barrier<3 * LPT>();
+        else if (PRE >= 3 && pre == 3) wait_vm_barrier<2 * LPT>();
+        else if (PRE >= 2 && pre == 2) wait_vm_barrier<LPT>();
         else wait_vm_barrier<0>();
     }
     if (p.stamp) st2 = __builtin_readcyclecounter();
     Frag f0, f1;
     unsigned long long w_vm = 0, w_bar = 0;                   // debug: time in the steady-state vmcnt waits / barriers
     read_frag(f0, smem, 0);
-    int cs = 0, ls = NS - 1;                                  // compute stage / load stage of the ring
-    // One K tile.  Entry: slice 0 of tile kt is in f0.  Phase A: fetch slice 1, run slice 0's MFMAs with the DMA of
-    // tile kt+NS-1 slotted between them.  Phase B: wait until tile kt+1 (only) has landed, barrier (every wave has
-    // finished reading this stage, everybody's part of tile kt+1 is visible), fetch slice 0 of tile kt+1 and run
-    // slice 1's MFMAs over that fetch.  LDS latency and DMA issue never stall the matrix pipe of a wave in steady state.
+    int cs = 0, ls = NS - 1;                                  // compute stage / load stage (PB = false) of the ring
+    // One K tile.  Entry: slice 0 of tile kt is in f0.  Phase A: run slice 0's MFMAs, fetching slice 1 behind the first
+    // of them (and, PB = false, with the DMA pieces of tile kt+NS-1 slotted between them).  Then wait until tile kt+1
+    // (only) has landed, barrier (every wave has finished reading this stage, everybody's part of tile kt+1 is visible).
+    // Phase B: run slice 1's MFMAs, fetching slice 0 of tile kt+1 behind the first of them (and, PB = true, with the DMA
+    // pieces of tile kt+NS going into the stage just freed).  LDS latency and DMA issue never stall a wave's MFMAs.
     auto k_tile = [&](auto with_dma, int n_after, bool has_next) {
         constexpr bool DMA = decltype(with_dma)::value;
         const _Float16 *cbase = smem + cs * STAGE;
-        _Float16 *lbase = smem + ls * STAGE;
+        _Float16 *lbase = smem + (PB ? cs : ls) * STAGE;
         mfma_slice(f0, [&](int m) {
             read_slot(f1, cbase, 1, m);                      // slice 1: not needed before phase B
-            if (DMA) {
+            if (DMA && !PB) {
 #pragma unroll
                 for (int pc = 0; pc < LPT; ++pc)
                     if (1 + pc * (NM - 1) / LPT == m) {
@@ -311,12 +324,13 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                     }
             }
         });
-        if (DMA) advance();
+        if (DMA && !PB) advance();
         // slice 1 has landed in registers -- said with the builtin so that the compiler's own wait-count tracking knows
         // it (it cannot see into the asm below) and puts no lgkmcnt wait between the next fetch and slice 1's MFMAs
         __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0), vmcnt / expcnt untouched
-        if (DMA && p.stamp) wait_vm_barrier_timed<(NS - 2) * LPT>(w_vm, w_bar);
-        else if (DMA) wait_vm_barrier<(NS - 2) * LPT>();
+        // tiles issued after tile kt+1 at this point: kt+2 .. min(kt+NS-1, last) in either schedule
+        if (n_after == NS - 2 && p.stamp) wait_vm_barrier_timed<(NS - 2) * LPT>(w_vm, w_bar);
+        else if (n_after == NS - 2) wait_vm_barrier<(NS - 2) * LPT>();
         else if (NS >= 4 && n_after == 1) wait_vm_barrier<LPT>();
         else wait_vm_barrier<0>();
         ls = (ls + 1 == NS) ? 0 : ls + 1;
@@ -325,11 +339,21 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
         __builtin_amdgcn_sched_barrier(0);
         mfma_slice(f1, [&](int m) {
             if (has_next) read_slot(f0, nbase, 0, m);        // slice 0 of the next tile: needed at the next phase A
+            if (DMA && PB) {
+#pragma unroll
+                for (int pc = 0; pc < LPT; ++pc)
+                    if (1 + pc * (NM - 1) / LPT == m) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma_piece(pc, lbase);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
         });
+        if (DMA && PB) advance();
     };
     int kt = kt_begin;
-    for (; kt + NS - 1 < kt_end; ++kt) k_tile(std::true_type{}, NS - 2, true);
-    for (; kt < kt_end; ++kt) k_tile(std::false_type{}, kt_end - 2 - kt, kt + 1 < kt_end);
+    for (; kt + PRE < kt_end; ++kt) k_tile(std::true_type{}, NS - 2, true);
+    for (; kt < kt_end; ++kt) k_tile(std::false_type{}, min(NS - 2, kt_end - 2 - kt), kt + 1 < kt_end);
     if (p.stamp) st3 = __builtin_readcyclecounter();
     if (NX > 0) {
 #pragma unroll
