@@ -378,6 +378,40 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     const int cq = p.mode == 1 ? (p.Cout >> 2) : p.Cout;     // channels per output pixel (deconv: Cout = 4 taps x cq)
     if ((cq & 7) == 0 && (p.ycs & 7) == 0 && (p.yco & 7) == 0 && (!p.res || (p.rcs & 7) == 0)) {
         float *tile = reinterpret_cast<float *>(smem);       // [BM][BN] floats <= the two operand stages
+        // thread -> (8-channel group g, rows r0 + it * RSTEP): the group is the same in every iteration, so bias and column
+        // tests are loop invariants, and the NG residual groups of the thread are independent 32-byte loads that are all
+        // put in flight BEFORE the accumulators go through the LDS (one memory latency per workgroup instead of one per
+        // iteration: the conv3 + residual layers of the trunk are epilogue-bound, profiles/stamp_conv_r01.txt)
+        constexpr int GROUPS = BN / 8, NG = BM * GROUPS / NTHREADS, RSTEP = NTHREADS / GROUPS;
+        static_assert(BM * GROUPS % NTHREADS == 0 && NTHREADS % GROUPS == 0, "epilogue mapping");
+        const int g = t % GROUPS, r0 = t / GROUPS;
+        const int col = n0 + g * 8;
+        const bool col_ok = col < p.Cout;
+        // deconv (mode 1): column = (tap ij, channel co); the 8-channel group never straddles a tap
+        const int ij = p.mode == 1 ? col / cq : 0;
+        const int co = col - ij * cq;
+        const bool use_res = p.res && !split && col_ok;
+        uint4 res_a[NG], res_b[NG];
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const int row = m0 + r0 + it * RSTEP;
+            res_a[it] = make_uint4(0, 0, 0, 0);
+            res_b[it] = make_uint4(0, 0, 0, 0);
+            if (use_res && row < p.M) {
+                const char *q = reinterpret_cast<const char *>(p.res) + ((size_t)row * p.rcs + (size_t)col) * 4;
+                res_a[it] = *reinterpret_cast<const uint4 *>(q);
+                res_b[it] = *reinterpret_cast<const uint4 *>(q + 16);
+            }
+        }
+        float bias8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+        if (p.bias && !split && col_ok) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co);
+            const float4 b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -389,48 +423,51 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                 }
         __syncthreads();
         if (p.stamp) st4 = __builtin_readcyclecounter();
-        constexpr int GROUPS = BN / 8;
-        for (int gidx = t; gidx < BM * GROUPS; gidx += NTHREADS) {
-            const int r = gidx / GROUPS, g = gidx - r * GROUPS;
-            const int row = m0 + r, col = n0 + g * 8;
-            if (row >= p.M || col >= p.Cout) continue;
-            float8 v;
-            const float4 a = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8);
-            const float4 b = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8 + 4);
-            v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
-            v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
-            if (split) {
-                float *dst = p.partial + ((size_t)blockIdx.y * p.M + row) * p.Cout + col;
-                *reinterpret_cast<float4 *>(dst) = a;
-                *reinterpret_cast<float4 *>(dst + 4) = b;
-                continue;
-            }
-            // deconv (mode 1): column = (tap ij, channel co); the 8-channel group never straddles a tap
-            const int ij = p.mode == 1 ? col / cq : 0;
-            const int co = col - ij * cq;
-            if (p.bias) {
-                const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co);
-                const float4 b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4);
-                v.v[0] += b0.x; v.v[1] += b0.y; v.v[2] += b0.z; v.v[3] += b0.w;
-                v.v[4] += b1.x; v.v[5] += b1.y; v.v[6] += b1.z; v.v[7] += b1.w;
-            }
-            if (p.res) {
-                const float8 rr = act_load8(p.res, p.res_fmt, (size_t)row, p.rcs, col >> 3);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v.v[e] += rr.v[e];
-            }
-            if (p.relu) {
+        for (int it = 0; it < NG; ++it) {
+            const int r = r0 + it * RSTEP;
+            const int row = m0 + r;
+            if (row < p.M && col_ok) {
+                float8 v;
+                const float4 a = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8);
+                const float4 b = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8 + 4);
+                v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
+                v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+                if (split) {
+                    float *dst = p.partial + ((size_t)blockIdx.y * p.M + row) * p.Cout + col;
+                    *reinterpret_cast<float4 *>(dst) = a;
+                    *reinterpret_cast<float4 *>(dst + 4) = b;
+                } else {
+                    if (p.bias) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+                        for (int e = 0; e < 8; ++e) v.v[e] += bias8[e];
+                    }
+                    if (p.res) {
+                        if (p.res_fmt == 0) {
+                            v.v[0] += __uint_as_float(res_a[it].x); v.v[1] += __uint_as_float(res_a[it].y);
+                            v.v[2] += __uint_as_float(res_a[it].z); v.v[3] += __uint_as_float(res_a[it].w);
+                            v.v[4] += __uint_as_float(res_b[it].x); v.v[5] += __uint_as_float(res_b[it].y);
+                            v.v[6] += __uint_as_float(res_b[it].z); v.v[7] += __uint_as_float(res_b[it].w);
+                        } else {                                  // SPLIT16 group: [8 x f16 hi][8 x f16 lo]
+                            const half8 hi = __builtin_bit_cast(half8, res_a[it]), lo = __builtin_bit_cast(half8, res_b[it]);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v.v[e] += (float)hi[e] + (float)lo[e];
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+                    }
+                    size_t opix = (size_t)row;
+                    if (p.mode == 1) {                           // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j)
+                        const int ohw = p.OH * p.OW;
+                        const int bb = row / ohw, rem = row - bb * ohw;
+                        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                        opix = ((size_t)bb * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
+                    }
+                    act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + co) >> 3, v);
+                }
             }
-            size_t opix = (size_t)row;
-            if (p.mode == 1) {                                   // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j)
-                const int ohw = p.OH * p.OW;
-                const int b = row / ohw, rem = row - b * ohw;
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                opix = ((size_t)b * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
-            }
-            act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + co) >> 3, v);
         }
         if (p.stamp && t == 0) {
             unsigned long long *o = p.stamp + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
