@@ -124,3 +124,22 @@ def test_fixture_is_deterministic():
     assert all(torch.equal(s1[k], s2[k]) for k in s1)
     l, r, info = fixture.make_inputs(3, 375, 1242)
     assert tuple(l.shape) == (1, 3, 600, 1987) and info.tolist() == [[600.0, 1987.0, pytest.approx(1.6)]]
+
+
+def test_tuned_plans_round_trip(tmp_path):
+    """engine.save_plans / load_plans (bench.py --plans): keys and plans survive the JSON file unchanged."""
+    saved = dict(engine._TUNED)
+    try:
+        engine._TUNED.clear()
+        key = ('f16x3', 2, 38, 125, 38, 125, 256, 256, 3, 3, 1, 1, 0, 256, 1, 1, 0)
+        engine._TUNED[key] = (2, 2, 8, 4, 1)
+        engine._TUNED[('f32', 1, 8, 8, 8, 8, 32, 64, 1, 1, 1, 0, 0, 32, 0, 0, 0)] = (1, 1, 4, 2, 3)
+        path = str(tmp_path / 'plans.json')
+        engine.save_plans(path)
+        before = dict(engine._TUNED)
+        engine._TUNED.clear()
+        assert engine.load_plans(path) == 2
+        assert engine._TUNED == before
+    finally:
+        engine._TUNED.clear()
+        engine._TUNED.update(saved)
