@@ -1,6 +1,6 @@
 """Sums rocprofv3 --pmc counters per kernel family over the steady-state bench steps (dev tool).
 
-    python tools/pmc_sum.py <dir with pass*/ or <COUNTER>/ sub-directories>  [skip_first_steps]
+    python tools/pmc_sum.py <dir with pass*/ or <COUNTER>/ sub-directories>  [skip_first_steps]  [traffic.json]
 Counts steps by stem_pack_kernel launches (2 per step); the first `skip` steps (autotuning, warm-up) are dropped.
 """
 import collections, csv, glob, os, sys
@@ -33,3 +33,12 @@ for f in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), r
 for c in sorted(res):
     n = max(res[c]['_steps'], 1)
     print('%-28s (%d steps): ' % (c, n) + '  '.join('%s=%.6g' % (k, v / n) for k, v in sorted(res[c].items()) if k != '_steps'))
+
+if len(sys.argv) > 3 and 'FETCH_SIZE' in res and 'WRITE_SIZE' in res:
+    import json
+    nf, nw = max(res['FETCH_SIZE']['_steps'], 1), max(res['WRITE_SIZE']['_steps'], 1)
+    json.dump({'conv_fetch_size_kb_per_step': res['FETCH_SIZE']['conv engine'] / nf,
+               'conv_write_size_kb_per_step': res['WRITE_SIZE']['conv engine'] / nw,
+               'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the conv-engine launches of one '
+                       'bench step (bench.py --streams 1, plans preloaded); FETCH_SIZE still uncorrected here'},
+              open(sys.argv[3], 'w'))

@@ -29,6 +29,6 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
   D=$O/pmc/$(echo $C | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --streams 1 --plans /tmp/plans_${TAG}.json > $D.log 2>&1
 done
-python $R/tools/pmc_sum.py $O/pmc 5 > $O/pmc_${TAG}_f16x3_bench_sums.txt 2>&1
+python $R/tools/pmc_sum.py $O/pmc 5 $O/pmc_${TAG}_traffic.json > $O/pmc_${TAG}_f16x3_bench_sums.txt 2>&1
 rm -rf $O/pmc
 ls -la $O
