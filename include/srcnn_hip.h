@@ -140,8 +140,12 @@ SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t wor
 SRCNN_API int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, float scale, float *out_nchw, int OH, int OW,
                      srcnn_stream_t stream);
 /* stem input repack: NCHW (B,3,H,W) -> zero-bordered NHWC4 (B, H+6, W+8, 4) so that the 7x7/2
- * stem (resnet.py:109) becomes 7 taps of 32 contiguous floats for the conv engine. */
-SRCNN_API int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, srcnn_stream_t stream);
+ * stem (resnet.py:109) becomes 7 taps of 32 contiguous floats for the conv engine (srcnn_conv2d with Cin = 32,
+ * x_cstride = 4, KH = 7, KW = 1, stride 2, pad 0).  out_format SRCNN_FMT_SPLIT16: the same bytes hold, per padded row,
+ * one [8 x f16 hi][8 x f16 lo] group per two pixels (groups aligned to the row start; an odd last pixel is not
+ * written -- the stem never reads it), which is what the DMA form of the f16x3 engine takes as x_format. */
+SRCNN_API int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, int out_format,
+                              srcnn_stream_t stream);
 /* MaxPool2d(3, stride 2, pad 0, ceil_mode) NHWC (resnet.py:113). */
 SRCNN_API int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y, int OH, int OW,
                             int y_format, srcnn_stream_t stream);

@@ -314,7 +314,13 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     SRCNN_REQUIRE((unsigned)a.x_fmt <= 1 && (unsigned)a.y_fmt <= 1 && (unsigned)a.res_fmt <= 1, "bad format");
     if (d->precision == 0)
         SRCNN_REQUIRE(a.x_fmt == 0 && a.y_fmt == 0 && (a.res_fmt == 0 || !d->residual), "fp32 engine needs F32 formats");
-    if (a.x_fmt == 1) SRCNN_REQUIRE(d->x_cstride % 8 == 0, "SPLIT16 needs channel strides that are multiples of 8");
+    // SPLIT16 input: every 32-element K-tile run must start on a group boundary.  Channel strides that are multiples of 8
+    // give that for any geometry; the packed stem image (srcnn_stem_pack: x_cstride 4, groups aligned per row) gives it
+    // for even strides with KW = 1 and no padding.
+    if (a.x_fmt == 1)
+        SRCNN_REQUIRE(d->x_cstride % 8 == 0 ||
+                          (d->x_cstride == 4 && d->KW == 1 && d->pad == 0 && d->stride % 2 == 0 && d->Cin == 32),
+                      "SPLIT16 needs channel strides that are multiples of 8 (or the packed-stem geometry)");
     if (a.y_fmt == 1) SRCNN_REQUIRE(d->y_cstride % 8 == 0 && d->y_coffset % 8 == 0, "SPLIT16 output alignment");
     if (d->precision == 1 && a.x_fmt == 0) SRCNN_REQUIRE(a.y_fmt == 0 && a.res_fmt == 0, "f16x3 with F32 input writes F32");
     a.zero_page = nullptr;

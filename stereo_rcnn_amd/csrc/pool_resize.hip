@@ -31,6 +31,49 @@ __global__ void stem_pack_kernel(const float *__restrict__ im, int B, int H, int
     }
 }
 
+// Same image in the SPLIT16 layout the DMA conv engine reads: per padded row, every two pixels (8 floats of the NHWC4 row)
+// become one 32-byte group [8 x f16 hi][8 x f16 lo] at the same byte offset the floats had.  Groups are aligned to the
+// start of each ROW (the row pitch, (W+8)*16 B, need not be a multiple of 32 B): every 8-pixel tap run of the stride-2
+// stem starts on an even pixel, i.e. on a group boundary.  An odd last pixel of a row is never read by the stem and
+// is not written.
+__global__ void stem_pack_split16_kernel(const float *__restrict__ im, int B, int H, int W, char *__restrict__ out)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int HP = H + 6, WP = W + 8, GP = WP / 2;
+    const size_t total = (size_t)B * HP * GP;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int gp = (int)(idx % GP);
+        const int yp = (int)((idx / GP) % HP);
+        const int b = (int)(idx / ((size_t)GP * HP));
+        const int y = yp - 3;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if ((unsigned)y < (unsigned)H) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int x = 2 * gp + q - 3;
+                if ((unsigned)x < (unsigned)W) {
+                    const float *p = im + (size_t)b * 3 * H * W + (size_t)y * W + x;
+                    v[4 * q + 0] = p[0];
+                    v[4 * q + 1] = p[(size_t)H * W];
+                    v[4 * q + 2] = p[(size_t)2 * H * W];
+                }
+            }
+        }
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hi[e] = (_Float16)v[e];
+            lo[e] = (_Float16)(v[e] - (float)hi[e]);
+        }
+        char *dst = out + ((size_t)b * HP + yp) * WP * 16 + (size_t)gp * 32;
+        *reinterpret_cast<h8 *>(dst) = hi;
+        *reinterpret_cast<h8 *>(dst + 16) = lo;
+    }
+}
+
 // works on 8-channel groups; input F32, output F32 or SPLIT16
 __global__ void maxpool3x3s2_kernel(const float *__restrict__ x, int B, int H, int W, int C, float *__restrict__ y,
                                     int OH, int OW, int yfmt)
@@ -186,10 +229,17 @@ static inline int grid_for(size_t total, int threads) { return (int)std::min<siz
 
 extern "C" {
 
-int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, srcnn_stream_t stream)
+int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, int out_format, srcnn_stream_t stream)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(im_nchw && out && B > 0 && H > 0 && W > 0, "bad args");
+    SRCNN_REQUIRE((unsigned)out_format <= 1, "bad format");
+    if (out_format == 1) {
+        const size_t groups = (size_t)B * (H + 6) * ((W + 8) / 2);
+        hipLaunchKernelGGL(stem_pack_split16_kernel, dim3(grid_for(groups, 256)), dim3(256), 0, as_stream(stream), im_nchw, B,
+                           H, W, reinterpret_cast<char *>(out));
+        return check_launch("srcnn_stem_pack");
+    }
     const size_t total = (size_t)B * (H + 6) * (W + 8);
     hipLaunchKernelGGL(stem_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), im_nchw, B, H, W,
                        reinterpret_cast<float4 *>(out));

@@ -250,12 +250,15 @@ def preprocess(img_rgb_u8, target_short=600, max_size=2484):
     return out, scale
 
 
-def stem_pack(im_nchw, out, batch_offset=0):
+def stem_pack(im_nchw, out, batch_offset=0, out_fmt=0):
+    """NCHW image -> zero-bordered NHWC4 for the stem conv; out_fmt FMT_SPLIT16 writes the same buffer in the layout the
+    DMA conv engine reads (pass x_fmt=FMT_SPLIT16 to conv2d)."""
     B, C, H, W = im_nchw.shape
     assert C == 3
     L = _lib.lib()
     off = batch_offset * (H + 6) * (W + 8) * 4 * 4
-    _lib.check(L.srcnn_stem_pack(_lib.ptr(im_nchw), B, H, W, out.data_ptr() + off, _lib.stream()), "srcnn_stem_pack")
+    _lib.check(L.srcnn_stem_pack(_lib.ptr(im_nchw), B, H, W, out.data_ptr() + off, out_fmt, _lib.stream()),
+               "srcnn_stem_pack")
 
 
 def maxpool3x3s2_ceil(x, B, H, W, C, y, OH, OW, y_fmt=0):

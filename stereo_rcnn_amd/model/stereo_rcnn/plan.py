@@ -158,12 +158,12 @@ class Plan(object):
     def trunk(self):
         w, N = self.w, self.N
         H, W = self.H, self.W
-        engine.stem_pack(self.im_left, self.packed, 0)
-        engine.stem_pack(self.im_right, self.packed, self.B)
+        f = self.fmt                                  # SPLIT16 activations (f16x3 engine) or F32
+        engine.stem_pack(self.im_left, self.packed, 0, out_fmt=f)
+        engine.stem_pack(self.im_right, self.packed, self.B, out_fmt=f)
         sh, sw = self.stem_hw
-        engine.conv2d(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, x_cstride=4)
+        engine.conv2d(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, x_cstride=4, x_fmt=f)
         ph, pw = self.c1_hw
-        f = self.fmt
         engine.maxpool3x3s2_ceil(self.stem_out, N, sh, sw, 64, self.c1, ph, pw, y_fmt=f)
         x, xh, xw = self.c1, ph, pw
         for li, blocks in enumerate(w.layers):

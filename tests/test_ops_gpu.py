@@ -211,11 +211,15 @@ def test_conv_f16s_every_plan(dev, plan, case):
         engine._TUNED, engine.AUTOTUNE = saved_tuned, saved_flag
 
 
-@pytest.mark.parametrize("precision", ['f32', 'f16x3'])
-def test_conv_stem_vs_torch_cpu(dev, precision):
+@pytest.mark.parametrize("precision,W", [('f32', 131), ('f16x3', 131), ('f16x3+split16', 131), ('f16x3+split16', 130)])
+def test_conv_stem_vs_torch_cpu(dev, precision, W):
+    """7x7/2 stem through the packed NHWC4 image; '+split16' = the packed image in SPLIT16 form read by the DMA engine
+    (odd and even padded widths: the SPLIT16 groups are aligned per row)."""
     from stereo_rcnn_amd import engine
     g = torch.Generator().manual_seed(1)
-    B, H, W = 2, 75, 131
+    B, H = 2, 75
+    xfmt = 1 if precision.endswith('+split16') else 0
+    precision = precision.split('+')[0]
     x = torch.randn(B, 3, H, W, generator=g) * 50
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.01
     bnp = {'weight': torch.rand(64, generator=g) + 0.5, 'bias': torch.randn(64, generator=g),
@@ -225,10 +229,10 @@ def test_conv_stem_vs_torch_cpu(dev, precision):
     refp = F.max_pool2d(ref, 3, 2, 0, ceil_mode=True)
     cw = engine.prep_stem(w, bnp, device=dev)
     packed = torch.empty((B, H + 6, W + 8, 4), device=dev)
-    engine.stem_pack(x.to(dev), packed)
+    engine.stem_pack(x.to(dev), packed, out_fmt=xfmt)
     OH, OW = ref.shape[2:]
     y = torch.empty((B, OH, OW, 64), device=dev)
-    engine.conv2d(cw, packed, B, H + 6, W + 8, y, OH, OW, x_cstride=4, precision=precision)
+    engine.conv2d(cw, packed, B, H + 6, W + 8, y, OH, OW, x_cstride=4, precision=precision, x_fmt=xfmt)
     assert float((y.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 1e-4
     PH, PW = refp.shape[2:]
     p = torch.empty((B, PH, PW, 64), device=dev)
