@@ -12,11 +12,19 @@
 //     keeps ds_read_b128 conflict-free is applied on the SOURCE side: lane (row=l>>2, slot=l&3)
 //     fetches chunk slot ^ ((row>>2)&3) of its row;
 //   * zero padding (image borders, M/N tails) = lanes pointed at a zero page in HBM;
-//   * NS-stage LDS ring: the loads of tile t+NS-1 are issued before the MFMAs of tile t; the one
-//     barrier per K tile is preceded by a hand-written `s_waitcnt vmcnt(n)` that waits only for the
-//     OLDEST tile in flight (vector-memory results return in order), so up to NS-1 tiles of DMA stay
-//     outstanding across barriers -- the L2 -> LDS path (~56 B/clk/CU) runs at throughput instead of
-//     one latency per K tile.
+//   * NS-stage LDS ring; the one barrier per K tile is preceded by a hand-written `s_waitcnt vmcnt(n)`
+//     that waits only for the OLDEST tile in flight (vector-memory results return in order), so NS-1
+//     (or NS, see PB below) tiles of DMA stay outstanding across barriers -- the L2 -> LDS path
+//     (~56 B/clk/CU) runs at throughput instead of one latency per K tile;
+//   * the K loop is software-pipelined by hand (k_tile below): a K tile is two 16-wide slices; the
+//     operand fragments of a slice are fetched from LDS while the MFMAs of the previous slice run, and
+//     the DMA instructions of the tile being prefetched are pinned one per two MFMAs (sched_barrier)
+//     instead of issued as a block.  All waves of a workgroup are phase-locked by the barrier, so any
+//     block of non-MFMA work (DMA issue, LDS wait) would idle the matrix pipe on every SIMD at once;
+//   * per-lane source cursors: the (tap, channel-tile) address of a lane's row is re-derived only when
+//     the tap changes, otherwise advanced by one 64-bit add per K tile;
+//   * epilogue: residual groups and bias are loaded before the accumulators are transposed through the
+//     LDS, then bias / residual / ReLU / SPLIT16 re-split on 8 channels per lane, 16-byte stores.
 #include "conv_common.h"
 #include <type_traits>
 
