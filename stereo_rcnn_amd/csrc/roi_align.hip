@@ -125,6 +125,82 @@ __global__ void pyramid_roi_align_kernel(PyramidArgs pa, int channels, const flo
     }
 }
 
+// value of one lattice point for 8 consecutive channels; `at8(y, x)` fetches the 8-channel group.  Same arithmetic per
+// channel as lattice_point() above.
+template <typename Fetch8>
+__device__ __forceinline__ float8 lattice_point8(float h, float w, int height, int width, Fetch8 at8)
+{
+    float8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.v[e] = 0.0f;
+    if (h < 0 || h >= height || w < 0 || w >= width) return r;
+    const int hstart = (int)fminf(floorf(h), (float)(height - 2));
+    const int wstart = (int)fminf(floorf(w), (float)(width - 2));
+    const float h_ratio = h - (float)hstart;
+    const float w_ratio = w - (float)wstart;
+    const double hr1 = 1. - (double)h_ratio, wr1 = 1. - (double)w_ratio;
+    const float8 ul = at8(hstart, wstart), ur = at8(hstart, wstart + 1);
+    const float8 dl = at8(hstart + 1, wstart), dr = at8(hstart + 1, wstart + 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float dl_h = dl.v[e] * h_ratio;
+        const float dr_hw = dr.v[e] * h_ratio * w_ratio;
+        const double v = (double)ul.v[e] * hr1 * wr1 + (double)ur.v[e] * hr1 * (double)w_ratio + (double)dl_h * wr1 +
+                         (double)dr_hw;
+        r.v[e] = (float)v;
+    }
+    return r;
+}
+
+// The form the forward uses: one thread per (roi, output row, 8-channel group), block (C/8, rows) of one or two wavefronts,
+// grid (ceil(A/rows), n).
+// A thread walks the A+1 lattice columns of its two lattice rows, keeps the previous column, and emits one 32-byte output
+// group per step: every tap is a 32-byte load (both activation formats), every store 2 x 16 bytes, and the 32 groups of a
+// row read 1 KB contiguous per tap.  (The per-channel kernel above issued 2-byte accesses: 8x the memory instructions.)
+template <int A>
+__global__ void pyramid_roi_align8_kernel(PyramidArgs pa, int channels, const float *__restrict__ rois,
+                                          float *__restrict__ out, int out_cstride, int out_coffset, int mfmt, int ofmt)
+{
+    const int n = blockIdx.y, py = blockIdx.x * blockDim.y + threadIdx.y, g = threadIdx.x;
+    if (py >= A) return;
+    const float *r = rois + (size_t)n * 5;
+    // level routing, stereo_rcnn.py:113-119 (natural log; round half away from zero; clamp 2..5)
+    float bh = r[4] - r[2] + 1.0f;
+    float bw = r[3] - r[1] + 1.0f;
+    float lv = logf(sqrtf(bh * bw) / 224.0f) + 4.0f;
+    lv = copysignf(floorf(fabsf(lv) + 0.5f), lv);
+    lv = fminf(fmaxf(lv, 2.0f), 5.0f);
+    const int l = __builtin_amdgcn_readfirstlane((int)lv - 2);   // same roi for the whole block
+    const int height = pa.mh[l], width = pa.mw[l];
+    const RoiGeom geo = roi_geom(r, pa.scale[l], A + 1, A + 1);
+    const float *base = pa.maps[l];
+    const size_t img = (size_t)geo.batch * height * width;
+    auto at8 = [&](int y, int x) { return act_load8(base, mfmt, img + (size_t)y * width + x, channels, g); };
+    const float h0 = (float)py * geo.bin_h + geo.start_h;
+    const float h1 = (float)(py + 1) * geo.bin_h + geo.start_h;
+    const float w0 = (float)0 * geo.bin_w + geo.start_w;                         // the reference's expression at px = 0
+    float8 top_prev = lattice_point8(h0, w0, height, width, at8);
+    float8 bot_prev = lattice_point8(h1, w0, height, width, at8);
+#pragma unroll 2
+    for (int px = 1; px <= A; ++px) {
+        const float w = (float)px * geo.bin_w + geo.start_w;
+        const float8 top = lattice_point8(h0, w, height, width, at8);
+        const float8 bot = lattice_point8(h1, w, height, width, at8);
+        float8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s = top_prev.v[e];
+            s = s + top.v[e];
+            s = s + bot_prev.v[e];
+            s = s + bot.v[e];
+            o.v[e] = s * 0.25f;
+        }
+        act_store8(out, ofmt, (size_t)(n * A + py) * A + (px - 1), out_cstride, (out_coffset >> 3) + g, o);
+        top_prev = top;
+        bot_prev = bot;
+    }
+}
+
 }  // namespace srcnn
 
 extern "C" {
@@ -167,6 +243,17 @@ int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, c
         pa.mw[l] = mw_host[l];
         // python: feat_maps[i].size(2) / im_info[0][0] -> double, narrowed to float at the C boundary
         pa.scale[l] = (float)((double)mh_host[l] / (double)im_height);
+    }
+    if (out_cstride % 8 == 0 && out_coffset % 8 == 0) {
+        const int G = channels / 8, rows = G <= 32 ? 64 / G : 1;   // one or two wavefronts per block: thousands of small blocks
+        dim3 grid8((A + rows - 1) / rows, num_rois), block8(G, rows);
+        if (A == 7)
+            hipLaunchKernelGGL(pyramid_roi_align8_kernel<7>, grid8, block8, 0, as_stream(stream), pa, channels, rois, out,
+                               out_cstride, out_coffset, maps_format, out_format);
+        else
+            hipLaunchKernelGGL(pyramid_roi_align8_kernel<14>, grid8, block8, 0, as_stream(stream), pa, channels, rois, out,
+                               out_cstride, out_coffset, maps_format, out_format);
+        return check_launch("srcnn_pyramid_roi_align");
     }
     dim3 grid(A, num_rois), block(channels);
     if (A == 7)
