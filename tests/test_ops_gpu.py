@@ -99,9 +99,10 @@ def test_roi_align_avg_module(dev):
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("A", [7, 14])
-def test_pyramid_roi_align_fused(dev, A):
-    """Fused NHWC kernel == per-level legacy op + avg-pool + level routing of the oracle."""
+@pytest.mark.parametrize("A,pad_c", [(7, 0), (14, 0), (7, 4), (14, 4)])
+def test_pyramid_roi_align_fused(dev, A, pad_c):
+    """Fused NHWC kernel == per-level legacy op + avg-pool + level routing of the oracle.  pad_c = 0: 8-channel-group
+    kernel (output strides multiples of 8, what the forward uses); pad_c = 4: the per-channel kernel behind it."""
     import ctypes
     from stereo_rcnn_amd import _lib
     from oracle import net as onet
@@ -120,15 +121,16 @@ def test_pyramid_roi_align_fused(dev, A):
     # oracle: pyramid_roi_feat handles only one batch index per call through rois[:,0]; it passes rois through
     ref = onet.pyramid_roi_feat([torch.from_numpy(m) for m in maps], torch.from_numpy(rois), im_info, kpts=(A == 14))
     tm = [torch.from_numpy(m).to(dev).permute(0, 2, 3, 1).contiguous() for m in maps]
-    out = torch.zeros((n, A, A, 2 * C), device=dev)
+    CS, CO = 2 * C + pad_c, C + pad_c                        # output channel stride / offset
+    out = torch.zeros((n, A, A, CS), device=dev)
     ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in tm])
     mh = (ctypes.c_int * 4)(*[h for h, _ in hw]); mw = (ctypes.c_int * 4)(*[w for _, w in hw])
     tr = torch.from_numpy(rois).to(dev)
-    _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, C, 600.0, tr.data_ptr(), n, A, out.data_ptr(), 2 * C, C,
+    _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, C, 600.0, tr.data_ptr(), n, A, out.data_ptr(), CS, CO,
                                                   0, 0, _lib.stream()))
-    got = out[:, :, :, C:].permute(0, 3, 1, 2).cpu().numpy()
+    got = out[:, :, :, CO:].permute(0, 3, 1, 2).cpu().numpy()
     lv_dev = onet.roi_levels(torch.from_numpy(rois))
-    assert float(out[:, :, :, :C].abs().sum()) == 0.0          # other channel slice untouched
+    assert float(out[:, :, :, :CO].abs().sum()) == 0.0         # other channel slice untouched
     assert np.array_equal(got, ref.numpy()), float(np.abs(got - ref.numpy()).max())
 
 
