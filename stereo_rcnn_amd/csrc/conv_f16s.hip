@@ -359,6 +359,9 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
         });
         if (DMA && PB) advance();
     };
+    // 8-wave workgroups: the second-dispatched half loses every VALU arbitration to its older SIMD sibling; one static
+    // priority raise for that half (no per-phase flips) evens the pair out (MI355X_MICROARCH.md, two waves per SIMD)
+    if (WM == 4 && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
     int kt = kt_begin;
     for (; kt + PRE < kt_end; ++kt) k_tile(std::true_type{}, NS - 2, true);
     for (; kt < kt_end; ++kt) k_tile(std::false_type{}, min(NS - 2, kt_end - 2 - kt), kt + 1 < kt_end);
