@@ -38,8 +38,8 @@ ENGINE_DESC = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--graph', action='store_true',
                     help='replay the forward as one hipGraph instead of launching eagerly (measured slower on MI355X: the '
                          'replay serialises the side-stream branches; eager launches are not CPU-bound here)')
