@@ -106,41 +106,38 @@ __global__ void maxpool3x3s2_kernel(const float *__restrict__ x, int B, int H, i
 // y = bilinear(top, align_corners=True -> (H,W)) + lateral.  Index/weight arithmetic follows
 // ATen's upsample_bilinear2d (area_pixel_compute_scale: (in-1)/(out-1); h1 = (int)h1r;
 // lambda = h1r - h1), accumulation order w0*(... ) as written there.
+// grid (ceil(W * C/8 / 256), B * H): one output row per blockIdx.y, so the row geometry (source rows, vertical weights) is
+// wave-uniform and the per-thread index arithmetic is one division by the group count.
 __global__ void upsample_add_kernel(const float *__restrict__ top, int TH, int TW, const float *__restrict__ lat,
                                     int B, int H, int W, int C, float *__restrict__ y, int top_fmt, int yfmt)
 {
+    (void)B;
     const float rh = H > 1 ? (float)(TH - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(TW - 1) / (float)(W - 1) : 0.f;
     const int G = C / 8;
-    const size_t total = (size_t)B * H * W * G;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(idx % G);
-        size_t r = idx / G;
-        const int w = (int)(r % W);
-        r /= W;
-        const int h = (int)(r % H);
-        const int b = (int)(r / H);
-        const float h1r = rh * (float)h;
-        const int h1 = (int)h1r;
-        const int h1p = (h1 < TH - 1) ? 1 : 0;
-        const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
-        const float w1r = rw * (float)w;
-        const int w1 = (int)w1r;
-        const int w1p = (w1 < TW - 1) ? 1 : 0;
-        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-        const size_t t0 = ((size_t)b * TH + h1) * TW + w1;
-        const float8 a = act_load8(top, top_fmt, t0, C, g), bb = act_load8(top, top_fmt, t0 + w1p, C, g);
-        const float8 cc = act_load8(top, top_fmt, t0 + (size_t)h1p * TW, C, g);
-        const float8 d = act_load8(top, top_fmt, t0 + (size_t)h1p * TW + w1p, C, g);
-        const size_t pix = ((size_t)b * H + h) * W + w;
-        const float8 l = act_load8(lat, 0, pix, C, g);
-        float8 o;
+    const int row = blockIdx.y;                      // b * H + h
+    const int b = row / H, h = row - b * H;
+    const float h1r = rh * (float)h;
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < TH - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const size_t trow0 = ((size_t)b * TH + h1) * TW, trow1 = trow0 + (size_t)h1p * TW;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)(W * G)) return;
+    const int w = (int)(idx / (unsigned)G), g = (int)(idx - (unsigned)w * (unsigned)G);
+    const float w1r = rw * (float)w;
+    const int w1 = (int)w1r;
+    const int w1p = (w1 < TW - 1) ? 1 : 0;
+    const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+    const float8 a = act_load8(top, top_fmt, trow0 + w1, C, g), bb = act_load8(top, top_fmt, trow0 + w1 + w1p, C, g);
+    const float8 cc = act_load8(top, top_fmt, trow1 + w1, C, g), d = act_load8(top, top_fmt, trow1 + w1 + w1p, C, g);
+    const size_t pix = (size_t)row * W + w;
+    const float8 l = act_load8(lat, 0, pix, C, g);
+    float8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            o.v[e] = (h0l * (w0l * a.v[e] + w1l * bb.v[e]) + h1l * (w0l * cc.v[e] + w1l * d.v[e])) + l.v[e];
-        act_store8(y, yfmt, pix, C, g, o);
-    }
+    for (int e = 0; e < 8; ++e)
+        o.v[e] = (h0l * (w0l * a.v[e] + w1l * bb.v[e]) + h1l * (w0l * cc.v[e] + w1l * d.v[e])) + l.v[e];
+    act_store8(y, yfmt, pix, C, g, o);
 }
 
 // NHWC activation format conversion on 8-channel groups
@@ -265,8 +262,8 @@ int srcnn_upsample_add(const float *top, int TH, int TW, const float *lateral, i
     using namespace srcnn;
     SRCNN_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     SRCNN_REQUIRE((unsigned)top_format <= 1 && (unsigned)y_format <= 1, "bad format");
-    const size_t total = (size_t)B * H * W * (C / 8);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), top, TH, TW,
+    SRCNN_REQUIRE((long long)B * H <= 65535 && (long long)W * (C / 8) < (1LL << 31), "map too large");
+    hipLaunchKernelGGL(upsample_add_kernel, dim3((W * (C / 8) + 255) / 256, B * H), dim3(256), 0, as_stream(stream), top, TH, TW,
                        lateral, B, H, W, C, y, top_format, y_format);
     return check_launch("srcnn_upsample_add");
 }
