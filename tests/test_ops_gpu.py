@@ -26,7 +26,7 @@ def _rand_dets(rng, n, w=1987.0, h=600.0, cluster=True):
     return np.concatenate([b, sc[:, None]], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 4097, 6000])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 4097, 6000, 16384])     # 16384 = the documented maximum
 @pytest.mark.parametrize("thresh", [0.7, 0.3])
 def test_nms_bit_exact(dev, n, thresh):
     from stereo_rcnn_amd.model.nms.nms_wrapper import nms
@@ -49,6 +49,10 @@ def test_nms_edge_cases(dev):
     # all identical boxes: only the first survives
     d = np.tile(np.array([[3, 4, 50, 60, 0.5]], np.float32), (200, 1))
     assert nms(torch.from_numpy(d).to(dev), 0.7).view(-1).tolist() == [0]
+    # one box more than the documented maximum: refused loudly, never truncated
+    big = torch.zeros((16385, 5), device=dev)
+    with pytest.raises(RuntimeError):
+        nms(big, 0.7)
 
 
 def test_nms_legacy_symbol(dev):
