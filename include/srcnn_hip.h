@@ -52,8 +52,10 @@ SRCNN_API const char *srcnn_last_error(void);
  * dets (n, dim>=4) float32 [x1,y1,x2,y2,(score)], ALREADY score-sorted.
  * keep_out (n) int32, num_out (1) int32 -- both on the device, as in the
  * reference (nms_gpu.py:8-9).  The greedy reduction also runs on the device:
- * nothing is copied to the host.  n <= 16384 boxes per problem.  Keep lists are bit-identical to the reference's own
+ * nothing is copied to the host.  Keep lists are bit-identical to the reference's own
  * kernel (built for gfx950 and run on the MI355X by tests/test_ref_kernels_gpu.py).
+ * LIMIT: n <= 16384 boxes per problem (the reference's RPN uses 6000, cfg.TEST.RPN_PRE_NMS_TOP_N); a larger n
+ * returns SRCNN_ERR_ARG (tests/test_ops_gpu.py covers 16384 and 16385).
  */
 SRCNN_API size_t srcnn_nms_workspace_bytes(int n);
 SRCNN_API int srcnn_nms(int *keep_out, const float *dets, int *num_out, int n, int dim, float thresh,
@@ -168,7 +170,11 @@ SRCNN_API int srcnn_rpn_score(const float *head, int B, int hw, int head_cstride
 /* Whole _ProposalLayer.forward (proposal_layer.py:42-145): anchors (generate_anchors.py:112-173),
  * decode+clip (bbox_transform.py:79-104,177-185), stable descending sort / top pre_nms,
  * NMS(left) & NMS(right), sorted intersection, first post_nms, zero pad, batch index in col 0.
- * probs (B, A, 2), deltas (B, A, 6); level_hw_host: nlevels x {H, W}; rois_* (B, post_nms, 5). */
+ * probs (B, A, 2), deltas (B, A, 6); level_hw_host: nlevels x {H, W}; rois_* (B, post_nms, 5).
+ * LIMITS: specialised to the reference's anchor configuration (config.py: FPN_ANCHOR_SCALES {32,64,128,256,512} one per
+ * level, FPN_FEAT_STRIDES {4,8,16,32,64}, ANCHOR_RATIOS {0.5,1,2}, i.e. nlevels == 5 and 3 anchors per location:
+ * num_anchors must equal 3 * sum(H_l * W_l) and stay below 4M); pre_nms <= 8192 (radix top-K buffer), post_nms <= pre_nms.  Anything else
+ * returns SRCNN_ERR_ARG with the reason in srcnn_last_error(). */
 SRCNN_API size_t srcnn_proposal_workspace_bytes(int B, int num_anchors, int pre_nms, int post_nms);
 SRCNN_API int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num_anchors,
                          const int *level_hw_host, int nlevels, const float *im_info /* (B,3) device */,
@@ -209,8 +215,10 @@ SRCNN_API int srcnn_pack_detections(const float *scores, const float *boxes_left
  * upsample of dense_align.py:256-257 is done inside (workspace).  boxes (R,4) and borders (R,2)
  * in ORIGINAL-image pixels (borders = keypoints[:,3:5]), poses (R,7) [x,y,z,w,h,l,theta].
  * scale = im_info[0,2]; p2_00/p2_02/p2_12 = P2 focal/cx/cy; p2_03_minus_p3_03 = P2[0,3]-P3[0,3]
- * (host doubles, as in the reference).  max_pixels bounds the per-object sample count (extra
- * samples are dropped).  Outputs status (R) and best_dis (R) float32 on the device. */
+ * (host doubles, as in the reference).  max_pixels bounds the per-object sample count; the reference's lattice has at
+ * most 113 x 46 points, so 8192 can never overflow -- an object whose lattice does not fit a smaller bound is reported
+ * with status -1 (never silently truncated).  Outputs status (R: 1 ok, 0 no valid pixel, -1 overflow) and best_dis (R)
+ * float32 on the device. */
 SRCNN_API size_t srcnn_dense_align_workspace_bytes(int H, int W, int R, int max_pixels);
 SRCNN_API int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W, double scale,
                       double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03,

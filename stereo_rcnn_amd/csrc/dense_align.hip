@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ b
         if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
     }
-    if (tid == 0) cnt[r] = min(s_base, max_pixels);
+    if (tid == 0) {
+        cnt[r] = min(s_base, max_pixels);
+        cnt[gridDim.x + r] = s_base > max_pixels ? s_base : 0;      // overflow: reported as status -1, never silently truncated
+    }
 }
 
 // ------------------------------------------------------------------ bilinear tap (grid_sample, align_corners, border)
@@ -297,7 +300,7 @@ __global__ void finish_kernel(const float *__restrict__ poses, const float *__re
         best_dis[r] = fbf / poses[r * 7 + 2];
         return;
     }
-    status[r] = cnt[r] > 0 ? 1.f : 0.f;                                  // :276-277
+    status[r] = cnt[R + r] ? -1.f : (cnt[r] > 0 ? 1.f : 0.f);            // :276-277; -1 = lattice did not fit max_pixels
     best_dis[r] = fbf / (best_depth[r] * (float)cal.scale2) + 0.5f;      // :298
 }
 
@@ -314,7 +317,7 @@ static DaLayout da_layout(int H, int W, int R, int max_pixels)
     L.up_l = take(img);
     L.up_r = take(img);
     L.uvz = take((size_t)R * max_pixels * 3 * sizeof(float));
-    L.cnt = take((size_t)R * sizeof(int));
+    L.cnt = take((size_t)2 * R * sizeof(int));                  // [R] valid samples, [R] overflow flags
     L.left_val = take((size_t)R * max_pixels * 3 * sizeof(float));
     L.depth_enum = take((size_t)50 * R * sizeof(float));
     L.cost = take((size_t)50 * R * sizeof(float));

@@ -3,7 +3,17 @@ import torch
 
 from ... import _lib
 
-MAX_PIXELS = 8192    # per-object sample bound (the reference's lattice is <= ~45 x 113 points)
+# per-object sample bound.  The reference's lattice (dense_align.py:42-45) has at most 113 columns (a border span w gives
+# w // max(w // 56, 1) + 1 <= 113 points) and 0.4 * 113 + 1 = 46 rows, i.e. <= 5198 points, so 8192 cannot overflow; if a
+# caller lowers it, an object whose lattice does not fit gets status -1 and `check_status` raises (never a silent truncation).
+MAX_PIXELS = 8192
+
+
+def check_status(status_host):
+    """Raise if the native call reported a lattice overflow (status -1) for any object."""
+    if (status_host < 0).any():
+        raise RuntimeError("srcnn_dense_align: sample lattice larger than MAX_PIXELS=%d" % MAX_PIXELS)
+    return status_host
 
 
 def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses):
@@ -17,7 +27,7 @@ def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses):
         keypoints: rois x 5 (kpt, kpt_type, prob, left_border, right_border in the origin image)
         poses: rois x 7 (x, y, z, w, h, l, theta)
     Returns:
-        solve_status: 1 = success, 0 = failed (no valid pixel)   (rois)
+        solve_status: 1 = success, 0 = failed (no valid pixel), -1 = lattice overflow (see check_status)   (rois)
         best_dis: aligned disparity in the origin image          (rois)
     """
     assert im_left.is_cuda, "device tensors required (no CPU path)"

@@ -66,6 +66,8 @@ class _StereoRCNN(nn.Module):
         self._init_weights()
         self.invalidate()
 
+    MAX_PLANS = 16          # LRU bound of the per-(B, H, W, slot) plan cache (see _get_plan)
+
     def invalidate(self):
         """Drop the engine-side copies of the weights (call after editing parameters in place)."""
         self._weights = None
@@ -101,9 +103,16 @@ class _StereoRCNN(nn.Module):
             self._weights = Weights(self.state_dict(), dev)
             self._plans = {}
         key = (B, H, W, slot)
-        if key not in self._plans:
-            self._plans[key] = Plan(self._weights, B, H, W)
-        return self._plans[key]
+        plan = self._plans.pop(key, None)
+        if plan is None:
+            # a plan pre-allocates every activation of its (B, H, W) -- ~2 GB at B = 1, 600 x 1987 -- plus side streams.  KITTI has
+            # four frame sizes (x `slot`s in flight); the cache keeps the MAX_PLANS most recently used and drops the oldest, so
+            # arbitrary-size inputs cannot grow device memory without bound.
+            while len(self._plans) >= self.MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
+            plan = Plan(self._weights, B, H, W)
+        self._plans[key] = plan                      # (re)insert as the most recently used
+        return plan
 
     def PyramidRoI_Feat(self, feat_maps, rois, im_info, kpts=False, single_level=None):
         """stereo_rcnn.py:110-139 with the reference's NCHW in / NCHW out contract.

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import postprocess
-from .model.dense_align.dense_align import align_parallel
+from .model.dense_align.dense_align import align_parallel, check_status
 from .model.utils import box_estimator, kitti_utils
 from .model.utils.config import cfg
 
@@ -30,6 +30,12 @@ def _solve_task(task):
         return status, (np.asarray(state, dtype=np.float64) if status or np.ndim(state) else None)
     state, z = box_estimator.solve_x_y_theta_from_kpt(im_shape, calib, *args)
     return np.asarray(state, dtype=np.float64), float(z)
+
+
+def _alpha32(alpha):
+    """The 3-DoF rectification reads alpha back from the float32 `poses_all` tensor (demo.py:313 -> poses[7]), the 4-DoF
+    solve uses the float64 atan2 result directly (demo.py:288-293): mirror both."""
+    return float(np.float32(alpha))
 
 
 def _noop(_):
@@ -132,10 +138,10 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
                  for o in solved])
     succ, dis_final = align_parallel(calib, float(im_info.view(-1, 3)[0, 2]), im_left_data, im_right_data, boxes, kp,
                                      poses)                   # demo.py:306-308
-    succ, dis_final = succ.cpu().numpy(), dis_final.cpu().numpy()
+    succ, dis_final = check_status(succ.cpu().numpy()), dis_final.cpu().numpy()
     todo = [i for i in range(len(solved)) if succ[i] > 0]                                      # demo.py:311-319
     res3 = run([(3, tuple(im_shape), calib.p2, calib.p3,
-                 (solved[i]['alpha'], solved[i]['dim'], solved[i]['box_left'], float(dis_final[i]), solved[i]['kpts']))
+                 (_alpha32(solved[i]['alpha']), solved[i]['dim'], solved[i]['box_left'], float(dis_final[i]), solved[i]['kpts']))
                 for i in todo])
     for i, (state, z) in zip(todo, res3):
         o = solved[i]
@@ -233,10 +239,10 @@ def detect_3d_stream(model, frames, pool, eval_thresh=0.05, class_index=1, dense
             p.stage = 3
         elif p.stage == 3:                                     # aligned disparities -> 3-DoF tasks
             p.event.synchronize()
-            succ, dis = p.succ_host.numpy(), p.dis_host.numpy()
+            succ, dis = check_status(p.succ_host.numpy()), p.dis_host.numpy()
             p.todo = [i for i in range(len(p.solved)) if succ[i] > 0]
             p.pending = pool.submit([(3, tuple(im_shape), calib.p2, calib.p3,
-                                      (p.solved[i]['alpha'], p.solved[i]['dim'], p.solved[i]['box_left'], float(dis[i]),
+                                      (_alpha32(p.solved[i]['alpha']), p.solved[i]['dim'], p.solved[i]['box_left'], float(dis[i]),
                                        p.solved[i]['kpts'])) for i in p.todo])
             p.stage = 4
         elif p.stage == 4:                                     # rectified poses
