@@ -136,11 +136,15 @@ typedef struct srcnn_conv_desc {
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
 
-/* A0 preprocessing (demo.py:103-129, blob.py:39-64): uint8 RGB (H,W,3) on the device -> float32 (3,OH,OW)
- * BGR planes, PIXEL_MEANS subtracted, bilinear-resized by `scale` (OpenCV INTER_LINEAR geometry).
- * OH/OW as cv2.resize computes them: round(H*scale), round(W*scale). */
-SRCNN_API int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, float scale, float *out_nchw, int OH, int OW,
-                     srcnn_stream_t stream);
+/* A0 preprocessing (demo.py:103-129, blob.py:39-64): uint8 RGB (H,W,3) on the device -> BGR, PIXEL_MEANS subtracted
+ * (in double, stored float32, as numpy's float32 -= float64), then cv2.resize(img, None, None, fx=scale, fy=scale,
+ * INTER_LINEAR) restated operation by operation from OpenCV's float path (oracle/preprocess.py cites it): bit-equal
+ * to that restatement.  OH/OW MUST be what cv::resize derives: cvRound(H*scale), cvRound(W*scale) (ties to even).
+ * Outputs (either may be NULL): out_nchw = float32 (3,OH,OW) planes, the network input forward()/dense alignment take;
+ * packed = the stem's zero-bordered NHWC4 input (1, OH+6, OW+8, 4) exactly as srcnn_stem_pack would write it from
+ * out_nchw, in packed_format F32 or SPLIT16 -- the fused form: no float32 intermediate is re-read to feed the stem. */
+SRCNN_API int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, double scale, float *out_nchw, int OH, int OW,
+                     float *packed, int packed_format, srcnn_stream_t stream);
 /* stem input repack: NCHW (B,3,H,W) -> zero-bordered NHWC4 (B, H+6, W+8, 4) so that the 7x7/2
  * stem (resnet.py:109) becomes 7 taps of 32 contiguous floats for the conv engine (srcnn_conv2d with Cin = 32,
  * x_cstride = 4, KH = 7, KW = 1, stride 2, pad 0).  out_format SRCNN_FMT_SPLIT16: the same bytes hold, per padded row,

@@ -15,5 +15,8 @@ no tests or golden vectors of its own - SURVEY.md 8(c)):
     (tests/test_ref_kernels_gpu.py): bit-equal.
   * demo.py's decode and per-class NMS blocks (script code) are sliced out of the file and exec'd on the reference
     network's outputs; postprocess.py gives the same numbers exactly.
-Not pinned: OpenCV's resize in the preprocessing (cv2 is absent offline).
+  * OpenCV's float INTER_LINEAR resize of the preprocessing (third-party arithmetic; opencv-python is unpinned in the
+    reference's requirements.txt and absent here) is restated from the published algorithm (oracle/preprocess.py cites
+    resize.cpp) and pinned to hand-computed known answers + a second loop-level transcription
+    (tests/test_preprocess_cpu.py) -- not to outputs of cv2 itself, which cannot be produced in this image.
 """

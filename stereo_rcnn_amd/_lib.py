@@ -51,7 +51,7 @@ _SIGNATURES = {
     "srcnn_act_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
     "srcnn_conv2d_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "srcnn_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_size_t, c_void_p]),
-    "srcnn_preprocess": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "srcnn_preprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_stem_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_maxpool3x3s2_ceil": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "srcnn_upsample_add": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,

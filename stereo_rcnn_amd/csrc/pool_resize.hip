@@ -154,33 +154,107 @@ __global__ void act_convert_kernel(const void *__restrict__ x, int xfmt, void *_
     }
 }
 
-// A0 (demo.py:103-129, blob.py:39-64): uint8 RGB (H, W, 3) -> float32 BGR planes, minus PIXEL_MEANS,
-// bilinear resize by `scale` with OpenCV INTER_LINEAR geometry (half-pixel centres, source = (dst+0.5)/scale-0.5,
-// border replicate).  Mean subtraction happens BEFORE the resize, as in the reference.
-__global__ void preprocess_kernel(const unsigned char *__restrict__ img, int H, int W, float *__restrict__ out, int OH,
-                                  int OW, float inv_scale, float m0, float m1, float m2)
+// A0 (demo.py:103-129, blob.py:39-64): uint8 RGB (H, W, 3) -> float32 BGR, minus PIXEL_MEANS, resized by
+// cv2.resize(img, None, None, fx=s, fy=s, INTER_LINEAR).  The resize follows OpenCV's published float path operation by
+// operation (modules/imgproc/src/resize.cpp; restated and pinned in oracle/preprocess.py): tap position
+// (float)((d + 0.5) * (1/s) - 0.5) in double then float, cvFloor, float fraction; horizontal taps clamp AND zero the
+// fraction at the borders, vertical taps clip the two rows but keep the fraction; HResizeLinear S[sx]*a0 + S[sx+1]*a1,
+// VResizeLinear S0*b0 + S1*b1, each product and sum rounded to float32 on its own (this file is built with
+// -ffp-contract=off).  Mean subtraction happens BEFORE the resize and in double, as numpy does for float32 -= float64.
+struct ResizeTap {
+    int s0, s1;
+    float w0, w1;
+    bool copy;     // horizontal only: dx >= xmax, D = S[cols-1] * 1.f
+};
+
+__device__ __forceinline__ ResizeTap resize_tap(int d, int n_src, double step, bool horizontal)
 {
-    const size_t total = (size_t)OH * OW;
+    ResizeTap t;
+    float f = (float)(((double)d + 0.5) * step - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    t.copy = false;
+    if (horizontal) {
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= n_src - 1) { s = n_src - 1; f = 0.f; t.copy = true; }
+        t.s0 = s;
+        t.s1 = min(s + 1, n_src - 1);
+    } else {
+        t.s0 = min(max(s, 0), n_src - 1);
+        t.s1 = min(max(s + 1, 0), n_src - 1);
+    }
+    t.w1 = f;
+    t.w0 = 1.f - f;
+    return t;
+}
+
+__device__ __forceinline__ float u8_minus_mean(unsigned char v, double mean) { return (float)((double)v - mean); }
+
+// resized BGR value of output pixel (oy, ox): bgr[0..2]
+__device__ __forceinline__ void preprocess_pixel(const unsigned char *__restrict__ img, int H, int W, int oy, int ox,
+                                                 double step, float bgr[3])
+{
+    const ResizeTap tx = resize_tap(ox, W, step, true), ty = resize_tap(oy, H, step, false);
+    const unsigned char *r0 = img + (size_t)ty.s0 * W * 3, *r1 = img + (size_t)ty.s1 * W * 3;
+    const double mean[3] = {102.9801, 115.9465, 122.7717};        // PIXEL_MEANS (config.py:170), BGR
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {          // output channel c = B,G,R  <-  input channel 2-c
+        const int ic = 2 - c;
+        const float a = u8_minus_mean(r0[tx.s0 * 3 + ic], mean[c]), b = u8_minus_mean(r0[tx.s1 * 3 + ic], mean[c]);
+        const float cc = u8_minus_mean(r1[tx.s0 * 3 + ic], mean[c]), d = u8_minus_mean(r1[tx.s1 * 3 + ic], mean[c]);
+        const float h0 = tx.copy ? a : a * tx.w0 + b * tx.w1;
+        const float h1 = tx.copy ? cc : cc * tx.w0 + d * tx.w1;
+        bgr[c] = h0 * ty.w0 + h1 * ty.w1;
+    }
+}
+
+// One thread per PAIR of padded stem-input pixels (the 32-byte group of the packed layouts, see stem_pack*_kernel):
+// computes the (up to) two resized pixels once and writes them wherever asked -- the planar float32 network input
+// (what forward() / dense alignment take) and/or the zero-bordered NHWC4 stem input in F32 or SPLIT16 form, so that
+// no float32 intermediate has to be re-read to feed the stem.
+__global__ void preprocess_pack_kernel(const unsigned char *__restrict__ img, int H, int W, double step, int OH, int OW,
+                                       float *__restrict__ planar, char *__restrict__ packed, int packed_fmt)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int HP = OH + 6, WP = OW + 8, GP = (WP + 1) / 2;
+    const size_t total = (size_t)HP * GP, plane = (size_t)OH * OW;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % OW), oy = (int)(idx / OW);
-        // ATen upsample_bilinear2d(align_corners=False, given scale): src = scale*(dst+0.5)-0.5, clamped at 0
-        float sy = inv_scale * ((float)oy + 0.5f) - 0.5f;
-        float sx = inv_scale * ((float)ox + 0.5f) - 0.5f;
-        sy = sy < 0.f ? 0.f : sy;
-        sx = sx < 0.f ? 0.f : sx;
-        const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
-        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-        const unsigned char *p00 = img + ((size_t)y0 * W + x0) * 3, *p01 = img + ((size_t)y0 * W + x1) * 3;
-        const unsigned char *p10 = img + ((size_t)y1 * W + x0) * 3, *p11 = img + ((size_t)y1 * W + x1) * 3;
-        const float mean[3] = {m0, m1, m2};
+        const int gp = (int)(idx % GP), yp = (int)(idx / GP);
+        const int y = yp - 3;
+        float v[8];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {      // output channel c = B,G,R  <-  input channel 2-c
-            const int ic = 2 - c;
-            const float a = (float)p00[ic] - mean[c], b = (float)p01[ic] - mean[c];
-            const float cc = (float)p10[ic] - mean[c], d = (float)p11[ic] - mean[c];
-            out[(size_t)c * total + idx] = hy * (hx * a + lx * b) + ly * (hx * cc + lx * d);
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if ((unsigned)y < (unsigned)OH) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int x = 2 * gp + q - 3;
+                if ((unsigned)x < (unsigned)OW) {
+                    preprocess_pixel(img, H, W, y, x, step, v + 4 * q);
+                    if (planar) {
+                        float *o = planar + (size_t)y * OW + x;
+                        o[0] = v[4 * q + 0];
+                        o[plane] = v[4 * q + 1];
+                        o[2 * plane] = v[4 * q + 2];
+                    }
+                }
+            }
+        }
+        if (!packed) continue;
+        char *dst = packed + (size_t)yp * WP * 16 + (size_t)gp * 32;
+        const bool second = 2 * gp + 1 < WP;            // odd row length: the last group holds one pixel only
+        if (packed_fmt == 0) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            if (second) *reinterpret_cast<float4 *>(dst + 16) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (second) {                            // SPLIT16 groups are whole or absent (stem_pack_split16_kernel)
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (_Float16)v[e];
+                lo[e] = (_Float16)(v[e] - (float)hi[e]);
+            }
+            *reinterpret_cast<h8 *>(dst) = hi;
+            *reinterpret_cast<h8 *>(dst + 16) = lo;
         }
     }
 }
@@ -281,15 +355,18 @@ int srcnn_act_convert(const void *x, int x_format, void *y, int y_format, long l
     return check_launch("srcnn_act_convert");
 }
 
-int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, float scale, float *out_nchw, int OH, int OW,
-                     srcnn_stream_t stream)
+int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, double scale, float *out_nchw, int OH, int OW,
+                     float *packed, int packed_format, srcnn_stream_t stream)
 {
     using namespace srcnn;
-    SRCNN_REQUIRE(img_rgb && out_nchw && H > 0 && W > 0 && OH > 0 && OW > 0 && scale > 0.f, "bad args");
-    // PIXEL_MEANS (config.py:170), BGR, narrowed to float32 after the float32-minus-float64 subtraction of the reference
-    const size_t total = (size_t)OH * OW;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), img_rgb, H, W,
-                       out_nchw, OH, OW, 1.0f / scale, 102.9801f, 115.9465f, 122.7717f);
+    SRCNN_REQUIRE(img_rgb && (out_nchw || packed) && H > 0 && W > 0 && OH > 0 && OW > 0 && scale > 0.0, "bad args");
+    SRCNN_REQUIRE((unsigned)packed_format <= 1, "bad format");
+    // cv::resize derives the output size itself (cvRound = nearest, ties to even); a caller passing another size is in error
+    SRCNN_REQUIRE(OH == (int)nearbyint((double)H * scale) && OW == (int)nearbyint((double)W * scale),
+                  "OH/OW must be cvRound(H*scale), cvRound(W*scale)");
+    const size_t total = (size_t)(OH + 6) * ((OW + 8 + 1) / 2);
+    hipLaunchKernelGGL(preprocess_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), img_rgb, H, W,
+                       1.0 / scale, OH, OW, out_nchw, reinterpret_cast<char *>(packed), packed_format);
     return check_launch("srcnn_preprocess");
 }
 

@@ -234,18 +234,28 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")
 
 
-def preprocess(img_rgb_u8, target_short=600, max_size=2484):
+def preprocess_size(H, W, target_short=600):
+    """(OH, OW, im_scale) of the reference's resize: im_scale = target / short side (demo.py:113-114), output size as
+    cv2.resize derives it from fx/fy: cvRound(H*s), cvRound(W*s) -- Python's round() is the same ties-to-even."""
+    scale = float(target_short) / float(min(H, W))
+    return int(round(H * scale)), int(round(W * scale)), scale
+
+
+def preprocess(img_rgb_u8, target_short=600, max_size=2484, packed=None, packed_fmt=0, planar=True):
     """A0 on the device: uint8 RGB (H, W, 3) device tensor -> (1, 3, OH, OW) float32 network input and im_scale
-    (demo.py:103-129: RGB->BGR, -PIXEL_MEANS, bilinear resize so that the short side is `target_short`)."""
+    (demo.py:103-129: RGB->BGR, -PIXEL_MEANS, cv2.resize INTER_LINEAR so that the short side is `target_short`;
+    bit-equal to the OpenCV restatement oracle/preprocess.py).  `packed`: optional pre-allocated stem input buffer
+    ((OH+6) x (OW+8) x 4 floats, see srcnn_stem_pack) written in the same pass in `packed_fmt` (the fused form);
+    planar=False skips the float32 planes (detector-only callers that feed the stem through `packed`)."""
     assert img_rgb_u8.is_cuda and img_rgb_u8.dtype == torch.uint8 and img_rgb_u8.dim() == 3
     img = img_rgb_u8.contiguous()
     H, W = int(img.shape[0]), int(img.shape[1])
-    scale = float(target_short) / float(min(H, W))
-    OH, OW = int(H * scale), int(W * scale)          # floor, == cv2's round for the KITTI sizes; see tests
-    out = torch.empty((1, 3, OH, OW), dtype=torch.float32, device=img.device)
-    _lib.check(_lib.lib().srcnn_preprocess(img.data_ptr(), H, W, scale, out.data_ptr(), OH, OW, _lib.stream()),
+    OH, OW, scale = preprocess_size(H, W, target_short)
+    out = torch.empty((1, 3, OH, OW), dtype=torch.float32, device=img.device) if planar else None
+    _lib.check(_lib.lib().srcnn_preprocess(img.data_ptr(), H, W, scale, out.data_ptr() if planar else None, OH, OW,
+                                           packed.data_ptr() if packed is not None else None, packed_fmt, _lib.stream()),
                "srcnn_preprocess")
-    if OW > max_size:
+    if planar and OW > max_size:                       # blob.py:59-61 (inert for KITTI)
         out = out[:, :, :, :max_size].contiguous()
     return out, scale
 

@@ -147,6 +147,7 @@ class Plan(object):
         self.left_prob = e(R, G)
         self.right_prob = e(R, G)
         self.graphs = {}
+        self.packed_fmt = -1    # format `packed` currently holds for the inputs of the NEXT run (-1: none, pack in trunk())
         self.fmt = 0            # activation format of the internal buffers for the current/last run
         # independent branches of the forward (FPN laterals, small RPN levels, box head vs keypoint head) are
         # issued on side streams with event fork/join, so eager runs AND the captured hipGraph execute them
@@ -159,8 +160,10 @@ class Plan(object):
         w, N = self.w, self.N
         H, W = self.H, self.W
         f = self.fmt                                  # SPLIT16 activations (f16x3 engine) or F32
-        engine.stem_pack(self.im_left, self.packed, 0, out_fmt=f)
-        engine.stem_pack(self.im_right, self.packed, self.B, out_fmt=f)
+        if self.packed_fmt != f:                      # set_images() already wrote the stem input in this format otherwise
+            engine.stem_pack(self.im_left, self.packed, 0, out_fmt=f)
+            engine.stem_pack(self.im_right, self.packed, self.B, out_fmt=f)
+        self.packed_fmt = -1                          # consumed: the next forward packs again unless set_images() ran
         sh, sw = self.stem_hw
         engine.conv2d(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, x_cstride=4, x_fmt=f)
         ph, pw = self.c1_hw
@@ -347,6 +350,27 @@ class Plan(object):
         self.im_right.copy_(im_right, non_blocking=True)
         self.im_info.copy_(im_info.view(self.B, 3), non_blocking=True)
 
+    def set_images(self, img_left_u8, img_right_u8, precision='f32', target_short=600):
+        """Fused A0 (B = 1): uint8 RGB device images -> this plan's network-input planes (kept: dense alignment reads
+        them) AND its packed stem input, one pass per eye (srcnn_preprocess); trunk() then skips the stem_pack launches.
+        Returns im_scale."""
+        assert self.B == 1, "set_images feeds one stereo pair"
+        fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
+        L = _lib.lib()
+        scale = None
+        per_image = (self.H + 6) * (self.W + 8) * 4 * 4
+        for i, (img, planar) in enumerate(((img_left_u8, self.im_left), (img_right_u8, self.im_right))):
+            assert img.is_cuda and img.dtype == torch.uint8 and img.dim() == 3
+            img = img.contiguous()
+            H0, W0 = int(img.shape[0]), int(img.shape[1])
+            OH, OW, scale = engine.preprocess_size(H0, W0, target_short)
+            assert (OH, OW) == (self.H, self.W), "plan was built for another input size"
+            _lib.check(L.srcnn_preprocess(img.data_ptr(), H0, W0, scale, planar.data_ptr(), OH, OW,
+                                          self.packed.data_ptr() + i * per_image, fmt, _lib.stream()), "srcnn_preprocess")
+        self.im_info.copy_(torch.tensor([[self.H, self.W, scale]], dtype=torch.float32), non_blocking=True)
+        self.packed_fmt = fmt
+        return scale
+
     def run(self, use_graph=False, precision='f32'):
         """precision: 'f32' (exact fp32 MFMA engine) or 'f16x3' (3-term split on the f16 MFMA)."""
         prev = engine.PRECISION
@@ -358,6 +382,7 @@ class Plan(object):
             if not use_graph:
                 self.launch_all()
                 return
+            self.packed_fmt = -1                  # a captured graph always contains the stem_pack launches
             if precision not in self.graphs:
                 self.launch_all()                 # warm-up: sizes every workspace, splits weights, before capture
                 torch.cuda.synchronize()

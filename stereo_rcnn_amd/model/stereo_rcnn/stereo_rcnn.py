@@ -143,6 +143,23 @@ class _StereoRCNN(nn.Module):
         B, _, H, W = im_left_data.shape
         plan = self._get_plan(int(B), int(H), int(W), slot)
         plan.set_inputs(im_left_data, im_right_data, im_info)
+        return self._run(plan)
+
+    def forward_images(self, img_left_u8, img_right_u8, target_short=None, slot=0):
+        """Extension: the reference's preprocessing (demo.py:103-129) fused in front of the forward.  uint8 RGB
+        (H, W, 3) DEVICE images -> (the forward's 15-tuple, im_left_data, im_right_data, im_info); the network-input planes
+        and the stem's packed input are produced in one pass per eye, the float32 planes are returned because the dense
+        alignment takes them (demo.py:306-308) -- they alias the plan's buffers until the next call on this slot."""
+        if self.training:
+            raise NotImplementedError("training forward is out of scope; call .eval()")
+        short = cfg.TEST.SCALES[0] if target_short is None else target_short
+        H0, W0 = int(img_left_u8.shape[0]), int(img_left_u8.shape[1])
+        OH, OW, _ = engine.preprocess_size(H0, W0, short)
+        plan = self._get_plan(1, OH, OW, slot)
+        plan.set_images(img_left_u8, img_right_u8, self.precision, short)
+        return self._run(plan), plan.im_left, plan.im_right, plan.im_info
+
+    def _run(self, plan):
         plan.run(self.use_graph, self.precision)
         o = plan.outputs()
         self.RCNN_loss_cls = 0

@@ -316,12 +316,62 @@ def test_proposal_layer_ties_and_selection(dev, pre_nms, quant):
     assert float((rr.cpu() - rr_ref).abs().max()) < 2e-3
 
 
-@pytest.mark.parametrize("hw,short", [((375, 1242), 600), ((120, 400), 192), ((370, 1224), 600)])
-def test_preprocess_kernel_vs_host(dev, hw, short):
-    """A0: device preprocessing == the host restatement (fixture.preprocess: torch bilinear, align_corners=False)."""
+@pytest.mark.parametrize("hw,short", [((375, 1242), 600), ((370, 1224), 600), ((374, 1238), 600), ((376, 1241), 600),
+                                      ((120, 400), 192), ((37, 53), 100), ((64, 48), 31)])
+def test_preprocess_kernel_bit_exact_vs_opencv_restatement(dev, hw, short):
+    """A0: device preprocessing == oracle/preprocess.py (OpenCV's float INTER_LINEAR path restated operation by operation)
+    BIT FOR BIT, on every KITTI frame size (370..376 x 1224..1242), an up-scale with a non-dyadic factor and a down-scale."""
+    from oracle import preprocess as opre
     from stereo_rcnn_amd import engine, fixture
     l, _ = fixture.synthetic_pair(7, hw[0], hw[1])
-    ref, s_ref = fixture.preprocess(l, short)
+    ref, s_ref = opre.prepare_image(l, short)
     got, s = engine.preprocess(torch.from_numpy(l).to(dev), short)
     assert s == s_ref and tuple(got.shape) == tuple(ref.shape)
-    assert float((got.cpu() - ref).abs().max()) < 2e-4      # values are up to 150; float32 interpolation rounding
+    assert torch.equal(got.cpu(), torch.from_numpy(ref))
+    # also within interpolation rounding of the torch restatement the synthetic fixtures were generated with
+    if round(hw[0] * s) == int(hw[0] * s) and round(hw[1] * s) == int(hw[1] * s) and s > 1:
+        old, _ = fixture.preprocess(l, short)
+        assert float((got.cpu() - old).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_preprocess_fused_stem_pack(dev, fmt):
+    """(f)2: the packed stem input written by the fused pass == srcnn_stem_pack of the planar output, byte for byte,
+    in both formats (odd padded row length: 1987 + 8)."""
+    from stereo_rcnn_amd import engine, fixture
+    l, _ = fixture.synthetic_pair(9, 375, 1242)
+    img = torch.from_numpy(l).to(dev)
+    OH, OW, _ = engine.preprocess_size(375, 1242, 600)
+    packed = torch.full((1, OH + 6, OW + 8, 4), 7.0, device=dev)
+    planar, _ = engine.preprocess(img, 600, packed=packed, packed_fmt=fmt)
+    want = torch.full((1, OH + 6, OW + 8, 4), 7.0, device=dev)
+    engine.stem_pack(planar, want, 0, out_fmt=fmt)
+    torch.cuda.synchronize()
+    assert torch.equal(packed.view(torch.int32), want.view(torch.int32))
+    only_packed = torch.full_like(packed, 7.0)
+    none, _ = engine.preprocess(img, 600, packed=only_packed, packed_fmt=fmt, planar=False)
+    assert none is None and torch.equal(only_packed.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_forward_images_equals_forward_of_preprocessed(dev, precision):
+    """forward_images (fused A0 -> stem) gives exactly the forward of the separately preprocessed tensors."""
+    from stereo_rcnn_amd import engine, fixture
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    m = resnet(('__background__', 'Car'), 101, pretrained=False)
+    m.create_architecture()
+    m.load_state_dict(fixture.make_state_dict(3))
+    m.cuda().eval()
+    m.precision = precision
+    l, r = fixture.synthetic_pair(3, 120, 400)
+    lu, ru = torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)
+    with torch.no_grad():
+        out_f, iml, imr, info = m.forward_images(lu, ru, target_short=192)
+        out_f = [o.clone() for o in out_f[:8]]
+        iml, info = iml.clone(), info.clone()
+        tl, s = engine.preprocess(lu, 192)
+        tr, _ = engine.preprocess(ru, 192)
+        assert torch.equal(tl, iml) and float(info[0, 2]) == float(torch.tensor(s, dtype=torch.float32))
+        out = m(tl, tr, info)
+    for a, b in zip(out_f, out[:8]):
+        assert torch.equal(a, b)
