@@ -206,9 +206,14 @@ SRCNN_API int srcnn_class_nms(const float *scores, int n, int n_cls, int j, cons
                     float score_thresh, float nms_thresh, int *keep_idx, int *num_keep,
                     void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
 
-/* fixed-size, zero-padded detection record of one image for the multi-GPU gather (new: the reference writes
- * per-image txt files instead, kitti_utils.py:456-460): rec ((n+1), rec_cols>=20) float32, row 0 = [count],
- * row 1+r = [score, left box 4, right box 4, dim_orien 5, kpts 5, roi index] of the r-th kept detection. */
+/* fixed-size, zero-padded detection record of one image: what the 3-D stage works on in place and what the multi-GPU
+ * gather moves (new: the reference writes per-image txt files instead, kitti_utils.py:456-460).
+ * rec ((n+1), rec_cols) float32, row 0 = [count, 0...], row 1+r = the r-th kept detection (descending score):
+ *   0 score | 1-4 left box | 5-8 right box | 9-13 dim_orien (w,h,l,sin,cos) | 14-18 kpts (u,type,prob,left,right border)
+ *   19 roi index | 20 4-DoF status | 21-24 x,y,z,theta of the 4-DoF solve (float32, = the reference's poses_all)
+ *   25 dense-alignment status | 26 aligned disparity | 27-30 final x,y,z,theta | 31 alpha (poses_all[:,7])
+ * srcnn_pack_detections fills columns 0-19 (rec_cols >= 20) and zeroes the rest; the 3-D calls need SRCNN_REC_COLS. */
+#define SRCNN_REC_COLS 32
 SRCNN_API int srcnn_pack_detections(const float *scores, const float *boxes_left, const float *boxes_right,
                           const float *dim_orien, const float *kpts, const int *keep_idx, const int *num_keep,
                           int n, int n_cls, int j, int rec_cols, float *rec, srcnn_stream_t stream);
@@ -226,9 +231,51 @@ SRCNN_API int srcnn_pack_detections(const float *scores, const float *boxes_left
 SRCNN_API size_t srcnn_dense_align_workspace_bytes(int H, int W, int R, int max_pixels);
 SRCNN_API int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W, double scale,
                       double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03,
-                      const float *boxes, const float *borders, const float *poses, int R, int max_pixels,
+                      const float *boxes, const float *borders, const float *poses,
+                      const float *valid /* (R) or NULL: rows with valid <= 0 are skipped (status 0), so a fixed-size
+                                            batch can be aligned without compacting it on the host */,
+                      int R, int max_pixels,
                       float *status, float *best_dis, void *workspace, size_t workspace_bytes,
                       srcnn_stream_t stream);
+
+/* ------------------------------------------------------------ 3-D stage on the device (A13, A14, A17)
+ * All three work IN PLACE on one image's record (see srcnn_pack_detections), asynchronously, no host round trip.
+ * srcnn_infer_boundary: kitti_utils.py:398-437 (occlusion "depth line" over the image columns from the left boxes) and
+ *   the replacement rule of demo.py:262-265 -- columns 17/18 are overwritten where the regressed borders are narrower
+ *   than half the inferred ones.  workspace: srcnn_box3d_workspace_bytes(n, im_w).
+ * srcnn_solve_4dof: demo.py:282-302 = box_estimator.py:169-385 for every row with score > eval_thresh: scipy's Newton-CG
+ *   (optimize/_optimize.py:_minimize_newtoncg + MINPACK-2 dcsrch / wolfe2 line searches) restated in double precision,
+ *   one detection per workgroup.  Writes columns 20-24, 27-31 and state4 (n,4) doubles (x, y, z, theta).
+ * srcnn_align_inputs: the arrays align_parallel takes (boxes (n,4), borders (n,2), poses (n,7), valid (n)) from the record.
+ * srcnn_solve_3dof: demo.py:311-319 = box_estimator.py:387-545 for rows whose 4-DoF solve and dense alignment
+ *   succeeded (align_status / best_dis (n) from srcnn_dense_align, or both NULL = no alignment): columns 25-30 and
+ *   state (n,4) doubles (x, y, z = f b / disparity, theta).
+ * P2 / P3 entries are host doubles as in the reference (calib.p2[0,0], [0,2], [1,2], p2[0,3] - p3[0,3]). */
+SRCNN_API size_t srcnn_box3d_workspace_bytes(int n, int im_w);
+SRCNN_API int srcnn_infer_boundary(float *rec, int n, int rec_cols, int im_w, void *workspace, size_t workspace_bytes,
+                         srcnn_stream_t stream);
+SRCNN_API int srcnn_solve_4dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                     double p2_03_minus_p3_03, float eval_thresh, double *state4, srcnn_stream_t stream);
+SRCNN_API int srcnn_align_inputs(const float *rec, int n, int rec_cols, float *boxes, float *borders, float *poses, float *valid,
+                       srcnn_stream_t stream);
+SRCNN_API int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                     double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
+                     srcnn_stream_t stream);
+/* the same solver code compiled for the host (HOST pointers, no GPU needed): the reference's
+ * solve_x_y_z_theta_from_kpt(im_shape, calib, alpha, dim, box_left, box_right, kpts) -> (status, state) and
+ * solve_x_y_theta_from_kpt(im_shape, calib, alpha, dim, box_left, disparity, kpts) -> (state, z), flattened.
+ * newton_status (may be NULL): scipy's OptimizeResult.status (0 ok, 1 maxiter, 2 line search, 3 CG / NaN), -1 = early-out. */
+SRCNN_API int srcnn_solve_4dof_host(int im_h, int im_w, double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03,
+                          double alpha, const double *dim3, const double *box_left4, const double *box_right4,
+                          const double *kpts5, double *state4, int *newton_status);   /* returns status 0 / 1 */
+SRCNN_API int srcnn_solve_3dof_host(int im_h, int im_w, double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03,
+                          double alpha, const double *dim3, const double *box_left4, double disparity,
+                          const double *kpts5, double *state3, double *z, int *newton_status);
+/* cost and the reference's (non-)gradient of either problem at (x, y, z, theta): box_right4 NULL = the 3-DoF terms */
+SRCNN_API int srcnn_solver_evaluate_host(int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                               double p2_03_minus_p3_03, double alpha, const double *dim3, const double *box_left4,
+                               const double *box_right4_or_null, const double *kpts5, const double *xyzt, double *cost,
+                               double *grad4);
 
 /* ------------------------------------------------------------------ profiling hooks
  * When enabled, every conv-engine launch is bracketed by hipEvents on its stream; the

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrcnn_hip.so")
 
 FMT_F32, FMT_SPLIT16 = 0, 1     # SRCNN_FMT_* (include/srcnn_hip.h)
+REC_COLS = 32                   # SRCNN_REC_COLS: detection record row (include/srcnn_hip.h lists the columns)
 
 c_int, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_double,
                                                 ctypes.c_void_p, ctypes.c_size_t)
@@ -73,8 +74,21 @@ _SIGNATURES = {
     "srcnn_pack_detections": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_dense_align_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "srcnn_dense_align": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_double,
-                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
-                                  c_void_p]),
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    "srcnn_box3d_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "srcnn_infer_boundary": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "srcnn_solve_4dof": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_float,
+                                 c_void_p, c_void_p]),
+    "srcnn_align_inputs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srcnn_solve_3dof": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
+    "srcnn_solve_4dof_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srcnn_solve_3dof_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
+                                      c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srcnn_solver_evaluate_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srcnn_prof_enable": (c_int, [c_int]),
     "srcnn_prof_read": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_double),
                                 ctypes.POINTER(ctypes.c_longlong)]),

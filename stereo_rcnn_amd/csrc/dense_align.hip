@@ -100,12 +100,17 @@ __device__ void build_box(const float *pose, BoxGeom &g)
 
 // one workgroup (256 threads) per object
 __global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ boxes, const float *__restrict__ borders,
-                                                     const float *__restrict__ poses, DaCalib cal, int max_pixels,
+                                                     const float *__restrict__ poses, const float *__restrict__ valid,
+                                                     DaCalib cal, int max_pixels,
                                                      float *__restrict__ uvz, int *__restrict__ cnt)
 {
     __shared__ int wave_cnt[4];
     __shared__ int s_base;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (valid && !(valid[r] > 0.f)) {            // masked row of a fixed-size batch: an object with no sample (status 0)
+        if (tid == 0) { cnt[r] = 0; cnt[gridDim.x + r] = 0; }
+        return;
+    }
     const float sc = (float)cal.scale2;
     // box_left * scale, keypoints * scale: float32 tensor * python float (dense_align.py:261-262)
     const double b0 = (double)(boxes[r * 4 + 0] * sc), b1 = (double)(boxes[r * 4 + 1] * sc);
@@ -337,8 +342,8 @@ size_t srcnn_dense_align_workspace_bytes(int H, int W, int R, int max_pixels)
 
 int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W, double scale, double p2_00,
                       double p2_02, double p2_12, double p2_03_minus_p3_03, const float *boxes, const float *borders,
-                      const float *poses, int R, int max_pixels, float *status, float *best_dis, void *workspace,
-                      size_t workspace_bytes, srcnn_stream_t stream)
+                      const float *poses, const float *valid, int R, int max_pixels, float *status, float *best_dis,
+                      void *workspace, size_t workspace_bytes, srcnn_stream_t stream)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(im_left && im_right && boxes && borders && poses && status && best_dis, "null pointer");
@@ -366,7 +371,7 @@ int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W,
     float *best = reinterpret_cast<float *>(ws + L.best);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(upsample2x_kernel, dim3(4096, 1, 2), dim3(256), 0, st, im_left, im_right, H, W, up_l, up_r);
-    hipLaunchKernelGGL(sample_kernel, dim3(R), dim3(256), 0, st, boxes, borders, poses, cal, max_pixels, uvz, cnt);
+    hipLaunchKernelGGL(sample_kernel, dim3(R), dim3(256), 0, st, boxes, borders, poses, valid, cal, max_pixels, uvz, cnt);
     hipLaunchKernelGGL(left_sample_kernel, dim3(cdiv(max_pixels, 256), R), dim3(256), 0, st, up_l, uvz, cnt, max_pixels,
                        cal, left_val);
     for (int stage = 0; stage < 2; ++stage) {

@@ -16,7 +16,7 @@ def check_status(status_host):
     return status_host
 
 
-def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses):
+def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses, valid=None):
     """Dense alignment for multiple objects, depth enumeration in parallel.
 
     Inputs (as the reference):
@@ -26,6 +26,8 @@ def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses):
         box_left: rois x 4 in the origin image
         keypoints: rois x 5 (kpt, kpt_type, prob, left_border, right_border in the origin image)
         poses: rois x 7 (x, y, z, w, h, l, theta)
+        valid (extension): optional rois float32 mask; rows <= 0 are skipped (status 0) -- lets a fixed-size batch
+               straight from the device-side 4-DoF solve be aligned without compacting it on the host
     Returns:
         solve_status: 1 = success, 0 = failed (no valid pixel), -1 = lattice overflow (see check_status)   (rois)
         best_dis: aligned disparity in the origin image          (rois)
@@ -48,6 +50,7 @@ def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses):
     _lib.check(L.srcnn_dense_align(im_l.data_ptr(), im_r.data_ptr(), H, W, float(scale),
                                    float(calib.p2[0, 0]), float(calib.p2[0, 2]), float(calib.p2[1, 2]),
                                    float(calib.p2[0, 3] - calib.p3[0, 3]), boxes.data_ptr(), borders.data_ptr(),
-                                   poses.data_ptr(), R, MAX_PIXELS, status.data_ptr(), best_dis.data_ptr(),
+                                   poses.data_ptr(), valid.data_ptr() if valid is not None else None, R, MAX_PIXELS,
+                                   status.data_ptr(), best_dis.data_ptr(),
                                    ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_dense_align")
     return status, best_dis

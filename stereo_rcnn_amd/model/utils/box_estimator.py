@@ -178,3 +178,53 @@ def solve_x_y_theta_from_kpt(im_shape, calib, alpha, dim, box_left, disparity, k
                    method='Newton-CG', jac=lambda s: t.evaluate(s[0], s[1], z, s[2], True)[1][[0, 1, 3]],
                    options={'disp': False})
     return res.x, z
+
+
+# ------------------------------------------------------------------------------------------------ native solvers
+# The same two functions without scipy / Python in the loop: csrc/box_solver.h restates scipy's Newton-CG (its CG loop, the
+# MINPACK-2 dcsrch line search and the wolfe2 fall-back) in double precision; the device pipeline runs it as kernels
+# (srcnn_solve_4dof / srcnn_solve_3dof on the detection record), these two call the identical code compiled for the host.
+def _calib_args(calib):
+    return float(calib.p2[0, 0]), float(calib.p2[0, 2]), float(calib.p2[1, 2]), float(calib.p2[0, 3] - calib.p3[0, 3])
+
+
+def _dbl(values, n):
+    import ctypes
+    return (ctypes.c_double * n)(*[float(v) for v in list(values)[:n]])
+
+
+def solve_x_y_z_theta_from_kpt_native(im_shape, calib, alpha, dim, box_left, box_right, kpts, return_status=False):
+    """`solve_x_y_z_theta_from_kpt` on the native solver (host build).  Same arguments and (status, state) result."""
+    import ctypes
+    from ... import _lib
+    state, ns = (ctypes.c_double * 4)(), ctypes.c_int(0)
+    status = _lib.lib().srcnn_solve_4dof_host(int(im_shape[0]), int(im_shape[1]), *_calib_args(calib), float(alpha), _dbl(dim, 3),
+                                              _dbl(box_left, 4), _dbl(box_right, 4), _dbl(kpts, 5), state, ctypes.byref(ns))
+    if ns.value == -1:                      # the early-out of :186-187 returns (0, 0)
+        return (0, 0, -1) if return_status else (0, 0)
+    out = np.array(list(state), dtype=np.float64)
+    return (status, out, ns.value) if return_status else (status, out)
+
+
+def solve_x_y_theta_from_kpt_native(im_shape, calib, alpha, dim, box_left, disparity, kpts, return_status=False):
+    """`solve_x_y_theta_from_kpt` on the native solver (host build).  Same arguments and (state, z) result."""
+    import ctypes
+    from ... import _lib
+    state, z, ns = (ctypes.c_double * 3)(), ctypes.c_double(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().srcnn_solve_3dof_host(int(im_shape[0]), int(im_shape[1]), *_calib_args(calib), float(alpha),
+                                                _dbl(dim, 3), _dbl(box_left, 4), float(disparity), _dbl(kpts, 5), state,
+                                                ctypes.byref(z), ctypes.byref(ns)), "srcnn_solve_3dof_host")
+    out = np.array(list(state), dtype=np.float64)
+    return (out, z.value, ns.value) if return_status else (out, z.value)
+
+
+def evaluate_native(im_shape, calib, alpha, dim, box_left, box_right, kpts, xyzt):
+    """(cost, reference-gradient (4)) of the native restatement at (x, y, z, theta); box_right None = the 3-DoF terms."""
+    import ctypes
+    from ... import _lib
+    cost, g = ctypes.c_double(0), (ctypes.c_double * 4)()
+    _lib.check(_lib.lib().srcnn_solver_evaluate_host(int(im_shape[0]), int(im_shape[1]), *_calib_args(calib), float(alpha),
+                                                     _dbl(dim, 3), _dbl(box_left, 4),
+                                                     None if box_right is None else _dbl(box_right, 4), _dbl(kpts, 5),
+                                                     _dbl(xyzt, 4), ctypes.byref(cost), g), "srcnn_solver_evaluate_host")
+    return cost.value, np.array(list(g), dtype=np.float64)

@@ -33,11 +33,11 @@ NAMES = ['rois_left', 'rois_right', 'cls_prob', 'bbox_pred', 'dim_orien_pred', '
          'right_border_prob']
 
 
-def reference_model(seed, layers=101):
+def reference_model(seed, layers=101, sd=None):
     from model.stereo_rcnn.resnet import resnet
     net = resnet(('__background__', 'Car'), layers, pretrained=False)
     net.create_architecture()
-    net.load_state_dict(fixture.make_state_dict(seed))
+    net.load_state_dict(fixture.make_state_dict(seed) if sd is None else sd)
     net.eval()
     return net
 
@@ -52,6 +52,13 @@ def net_golden(net, seed, h, w, short, tag):
     d['spec'] = np.asarray([seed, h, w, short])
     np.savez_compressed(os.path.join(HERE, 'reference_net_%s.npz' % tag), **d)
     print('reference_net_%s.npz' % tag, {k: v.shape for k, v in d.items()})
+
+
+def net_outputs(net, l, r, info):
+    z, nb = torch.zeros(1, 1, 5), torch.zeros(1)
+    with torch.no_grad():
+        out = net(l, r, info, z, z, z, z, z, nb)      # the reference's 9-argument eval call (demo.py:137-140)
+    return {n: out[i].detach().numpy().astype(np.float32) for i, n in enumerate(NAMES)}
 
 
 def net_golden_batch2(net):
@@ -254,15 +261,17 @@ def _demo_slice(start_marker, end_marker):
     return textwrap.dedent('\n'.join(lines[a:b + 1]))
 
 
-def decode_golden():
+def decode_golden(g=None, info=None):
     """demo.py is a script, so its decode block (:143-224) and the per-class filter / sort / NMS block (:231-251) are
-    sliced out of the file by content markers and exec'd on the reference network's own outputs."""
+    sliced out of the file by content markers and exec'd on the reference network's own outputs (default: the small
+    seeded case; `g` / `info`: another forward's outputs and its im_info)."""
     from bbox_transform import bbox_transform_inv, kpts_transform_inv, border_transform_inv, clip_boxes
     from model.utils.config import cfg
     from model.nms.nms_wrapper import nms
-    g = np.load(os.path.join(HERE, 'reference_net_small_r101_seed3.npz'))
-    seed, h, w, short = [int(v) for v in g['spec']]
-    _, _, info = fixture.make_inputs(seed, h, w, target_short=short)
+    if g is None:
+        g = np.load(os.path.join(HERE, 'reference_net_small_r101_seed3.npz'))
+        seed, h, w, short = [int(v) for v in g['spec']]
+        _, _, info = fixture.make_inputs(seed, h, w, target_short=short)
     ns = {'torch': torch, 'np': np, 'cfg': cfg, 'kitti_classes': np.asarray(['__background__', 'Car']), 'xrange': range,
           'bbox_transform_inv': bbox_transform_inv, 'kpts_transform_inv': kpts_transform_inv,
           'border_transform_inv': border_transform_inv, 'clip_boxes': clip_boxes, 'nms': nms, 'eval_thresh': 0.05,
@@ -282,18 +291,22 @@ def decode_golden():
 
 
 # ---------------------------------------------------------------------------- the post-network flow of demo.py (:259-326)
-def pipeline_golden():
+def pipeline_golden(d=None, inputs=None, hw=None):
     """Border replacement, 4-DoF solve, dense alignment and 3-DoF rectification exactly as demo.py strings them together:
-    the three blocks are sliced out of the script and exec'd on the per-class detections of decode_golden()."""
+    the three blocks are sliced out of the script and exec'd on the per-class detections of decode_golden() (default: the
+    small seeded case; d / inputs=(l, r, info) / hw=(h, w) of the original image: another frame)."""
     import types
     import box_estimator as rbe
     import kitti_utils as rku
     from model.dense_align import dense_align as rda
     import math as m
-    d = decode_golden()
-    g = np.load(os.path.join(HERE, 'reference_net_small_r101_seed3.npz'))
-    seed, h, w, short = [int(v) for v in g['spec']]
-    l, r, info = fixture.make_inputs(seed, h, w, target_short=short)
+    if d is None:
+        d = decode_golden()
+        g = np.load(os.path.join(HERE, 'reference_net_small_r101_seed3.npz'))
+        seed, h, w, short = [int(v) for v in g['spec']]
+        l, r, info = fixture.make_inputs(seed, h, w, target_short=short)
+    else:
+        (l, r, info), (h, w) = inputs, hw
 
     class _Scalar03(object):              # torch 0.3: indexing a tensor down to one element gave a Python number
         def __init__(self, t):
@@ -353,6 +366,34 @@ def _pipeline_blocks(ns, solved):
     return out
 
 
+# ---------------------------------------------------------------------------- BASELINE configs[0]: the demo pair
+def demo_pair_golden(net):
+    """demo.py:100-326 on the reference's own demo/left.png + right.png + calib.txt (a NATURAL image: other score / tie
+    statistics, ROI level mix and dense-alignment cost landscape than the smooth synthetic fixtures), seeded weights
+    fixture.demo_state_dict (the trained checkpoint is an external download; see there for the 1/8 objectness scale).  PNGs are decoded with PIL (scipy.misc.imread did the same through PIL)
+    and the decoded uint8 arrays are committed (demo_pair_u8.npz) so that no test needs /root/reference or a decoder;
+    preprocessing = demo.py:107-124 with cv2.resize replaced by its restatement oracle/preprocess.py (cv2 is absent)."""
+    from PIL import Image
+    from oracle import preprocess as opre
+    left = np.asarray(Image.open('/root/reference/demo/left.png').convert('RGB'))
+    right = np.asarray(Image.open('/root/reference/demo/right.png').convert('RGB'))
+    assert left.shape == (375, 1242, 3) and left.dtype == np.uint8
+    np.savez_compressed(os.path.join(HERE, 'demo_pair_u8.npz'), left=left, right=right,
+                        calib=np.frombuffer(open('/root/reference/demo/calib.txt', 'rb').read(), np.uint8))
+    tl, s = opre.prepare_image(left)
+    tr, _ = opre.prepare_image(right)
+    l, r = torch.from_numpy(tl), torch.from_numpy(tr)
+    info = torch.tensor([[l.shape[2], l.shape[3], s]], dtype=torch.float32)        # demo.py:122-123
+    d = net_outputs(net, l, r, info)
+    d['input_shape'] = np.asarray(l.shape)
+    d['input_sha256'] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(tl).tobytes()).digest(), np.uint8)
+    dec = decode_golden(d, info)
+    d.update(dec)
+    d.update(pipeline_golden(dec, (l, r, info), (375, 1242)))
+    np.savez_compressed(os.path.join(HERE, 'reference_demo_pair_r101_seed3.npz'), **d)
+    print('reference_demo_pair_r101_seed3.npz', {k: v.shape for k, v in d.items()})
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['net', 'misc']
     if 'net' in which:
@@ -360,6 +401,8 @@ if __name__ == '__main__':
         net_golden(net, 3, 120, 400, 192, 'small_r101_seed3')
         net_golden(net, 3, 375, 1242, 600, 'full_r101_seed3')
         net_golden_batch2(net)
+    if 'demo' in which:
+        demo_pair_golden(reference_model(3, sd=fixture.demo_state_dict(3)))
     if 'misc' in which:
         d = {}
         d.update(anchors_golden())

@@ -93,7 +93,7 @@ def _cases(misc):
         yield alpha, dim, bl, br, kpts
 
 
-@pytest.mark.parametrize("impl", ['oracle', 'product'])
+@pytest.mark.parametrize("impl", ['oracle', 'product', 'native'])
 def test_solver_cost_and_gradient_equal_reference_closures(misc, impl):
     """f_kpt / j_kpt and f_rect / j_rect of the reference (captured from inside its solve functions) evaluated at the
     start point and three perturbed points: both restatements reproduce cost AND the reference's (quirky) gradient."""
@@ -110,6 +110,12 @@ def test_solver_cost_and_gradient_equal_reference_closures(misc, impl):
             c3, g3 = obe._cost_and_grad(obe._Problem(im_shape, calib, alpha, dim, bl, None, kpts, False), 0.5)
             f4 = lambda p: (c4(*p), g4(*p))
             f3 = lambda p: (c3(p[0], p[1], z3, p[2]), g3(p[0], p[1], z3, p[2])[[0, 1, 3]])
+        elif impl == 'native':           # csrc/box_solver.h compiled for the host (the device kernels run the same code)
+            f4 = lambda p: pbe.evaluate_native(im_shape, calib, alpha, dim, bl, br, kpts, p)
+
+            def f3(p):
+                c, g = pbe.evaluate_native(im_shape, calib, alpha, dim, bl, None, kpts, [p[0], p[1], z3, p[2]])
+                return c, g[[0, 1, 3]]
         else:
             t4 = pbe._Terms(im_shape, calib, alpha, dim, bl, br, kpts)
             t3 = pbe._Terms(im_shape, calib, alpha, dim, bl, None, kpts)
@@ -130,13 +136,17 @@ def test_solver_cost_and_gradient_equal_reference_closures(misc, impl):
     assert n4 >= 90 and n3 >= 90
 
 
-@pytest.mark.parametrize("impl", ['oracle', 'product'])
+@pytest.mark.parametrize("impl", ['oracle', 'product', 'native'])
 def test_solver_solutions_vs_reference(misc, impl):
     """End points of scipy's Newton-CG: same start point and status; the end point itself is chaotic in the last bits of
     the cost evaluation, so it is compared statistically."""
     from oracle import box_estimator as obe
     from stereo_rcnn_amd.model.utils import box_estimator as pbe
     be = obe if impl == 'oracle' else pbe
+    if impl == 'native':
+        import types
+        be = types.SimpleNamespace(solve_x_y_z_theta_from_kpt=pbe.solve_x_y_z_theta_from_kpt_native,
+                                   solve_x_y_theta_from_kpt=pbe.solve_x_y_theta_from_kpt_native)
     calib, im_shape = _Calib(misc), (375, 1242, 3)
     dz, d3 = [], []
     for (alpha, dim, bl, br, kpts), r4, r3 in zip(_cases(misc), misc['solver_4dof'], misc['solver_3dof']):

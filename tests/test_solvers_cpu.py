@@ -88,6 +88,88 @@ def test_solvers_recover_pose_and_agree_statistically():
     assert np.median(err) < 0.02                 # depth recovered to ~2 % on clean synthetic observations
 
 
+def _mul_evaluate():
+    """_Terms.evaluate with every `v ** 2` written `v * v`: what the native code computes (glibc's pow(v, 2.0) differs from
+    the correctly rounded v * v in ~0.06 % of the calls; numpy scalars go through pow)."""
+    import inspect
+    import re
+    import textwrap
+    src = inspect.getsource(pbe._Terms.evaluate)
+    src = re.sub(r'(\w+) \*\* 2', r'(\1 * \1)', src).replace('(-x / z) ** 2', '((-x / z) * (-x / z))')
+    assert '** 2' not in src
+    ns = {}
+    exec(textwrap.dedent(src), {'np': np, 'm': math}, ns)
+    return ns['evaluate']
+
+
+def test_native_newton_cg_is_scipys_iteration_bit_for_bit(monkeypatch):
+    """csrc/box_solver.h (the code the device kernels run, here in its host build) against scipy.optimize's Newton-CG on
+    the same cost / gradient arithmetic: END POINTS BIT-IDENTICAL on every case, 4-DoF and 3-DoF.  I.e. the optimiser --
+    CG loop, finite-difference Hessian products, MINPACK-2 dcsrch, the wolfe2 / zoom fall-back, every stopping rule -- is
+    restated exactly; np.dot is matched as the fused multiply-add chain OpenBLAS' ddot runs on x86."""
+    monkeypatch.setattr(pbe._Terms, 'evaluate', _mul_evaluate())
+    rng = np.random.default_rng(3)
+    n4 = n3 = 0
+    for _ in range(120):
+        calib, pose, dim, bl, br, kp, alpha = _case(rng)
+        s_ref, b = pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+        s_nat, a = pbe.solve_x_y_z_theta_from_kpt_native(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+        assert s_ref == s_nat
+        if s_ref == 0 and np.ndim(b) == 0:
+            continue
+        assert np.array_equal(np.asarray(a), np.asarray(b)), (a, b)
+        n4 += 1
+        disp = calib.p2[0, 0] * ((calib.p2[0, 3] - calib.p3[0, 3]) / calib.p2[0, 0]) / pose[2]
+        r_ref, z_ref = pbe.solve_x_y_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, disp, kp)
+        r_nat, z_nat = pbe.solve_x_y_theta_from_kpt_native(IM_SHAPE, calib, alpha, dim, bl, disp, kp)
+        assert z_ref == z_nat and np.array_equal(r_nat, r_ref), (r_nat, r_ref)
+        n3 += 1
+    assert n4 >= 100 and n3 >= 100
+
+
+def test_native_solver_vs_scipy_path_as_shipped():
+    """Against the Python path as it is (`** 2` through pow): cost / gradient equal to rounding, >= 90 % of the end points
+    bit-identical, the rest are the chaotic ones set off by a last-bit pow difference."""
+    rng = np.random.default_rng(5)
+    same4, same3, d4, dc, dg = [], [], [], [], []
+    for _ in range(150):
+        calib, pose, dim, bl, br, kp, alpha = _case(rng)
+        pt = np.array(pose) + rng.normal(0, [0.3, 0.05, 1.0, 0.05])
+        c_py, g_py = pbe._Terms(IM_SHAPE, calib, alpha, dim, bl, br, kp).evaluate(pt[0], pt[1], pt[2], pt[3], True)
+        c_nat, g_nat = pbe.evaluate_native(IM_SHAPE, calib, alpha, dim, bl, br, kp, pt)
+        dc.append(abs(c_nat - c_py) / max(1.0, abs(c_py)))
+        dg.append(np.abs(g_nat - g_py).max())
+        s_ref, b = pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+        s_nat, a, newton = pbe.solve_x_y_z_theta_from_kpt_native(IM_SHAPE, calib, alpha, dim, bl, br, kp, return_status=True)
+        assert s_ref == s_nat and newton in (0, 1, 2, 3)
+        if not s_ref:
+            continue
+        same4.append(np.array_equal(np.asarray(a), np.asarray(b)))
+        d4.append(np.abs(np.asarray(a) - np.asarray(b)).max())
+        disp = calib.p2[0, 0] * ((calib.p2[0, 3] - calib.p3[0, 3]) / calib.p2[0, 0]) / pose[2]
+        r_ref, _ = pbe.solve_x_y_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, disp, kp)
+        r_nat, _ = pbe.solve_x_y_theta_from_kpt_native(IM_SHAPE, calib, alpha, dim, bl, disp, kp)
+        same3.append(np.array_equal(r_nat, r_ref))
+    assert max(dc) < 1e-13 and max(dg) < 1e-9
+    print('native vs scipy path: bit-identical 4-DoF %.3f, 3-DoF %.3f; 4-DoF L-inf median %.1e max %.1e'
+          % (np.mean(same4), np.mean(same3), np.median(d4), np.max(d4)))
+    assert np.mean(same4) >= 0.90 and np.mean(same3) >= 0.95
+
+
+def test_native_early_outs_and_status():
+    calib = KITTI_DEMO_CALIB
+    assert pbe.solve_x_y_z_theta_from_kpt_native(IM_SHAPE, calib, 0.0, (1.6, 1.5, 4.0), [100, 100, 105, 160], [90, 100, 95, 160],
+                                                 [102, 0, 1, 100, 105]) == (0, 0)
+    assert pbe.solve_x_y_z_theta_from_kpt_native(IM_SHAPE, calib, 0.0, (1.6, 1.5, 4.0), [100, 100, 200, 160], [90, 100, 190, 160],
+                                                 [150, 0, 1, 150, 152]) == (0, 0)
+    # a far object: solved, but z > 100 -> status 0 with the state returned (box_estimator.py:383-384)
+    st, state = pbe.solve_x_y_z_theta_from_kpt_native(IM_SHAPE, calib, 0.3, (1.6, 1.5, 4.0), [600, 160, 615, 172], [598, 160, 613, 172],
+                                                      [607, 0, 1, 600, 615])
+    ref = pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, 0.3, (1.6, 1.5, 4.0), [600, 160, 615, 172], [598, 160, 613, 172],
+                                         [607, 0, 1, 600, 615])
+    assert st == ref[0] == 0 and state[2] > 100 and abs(state[2] - ref[1][2]) < 1e-3 * ref[1][2]
+
+
 def test_early_outs():
     calib = KITTI_DEMO_CALIB
     assert pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, 0.0, (1.6, 1.5, 4.0), [100, 100, 105, 160], [90, 100, 95, 160],
