@@ -11,10 +11,9 @@ import time
 
 import torch
 
-from . import engine, pipeline
+from . import pipeline
 from .model.stereo_rcnn.resnet import resnet
 from .model.utils import kitti_utils
-from .model.utils.config import cfg
 from .test_net import read_png_rgb
 
 
@@ -36,13 +35,11 @@ def main(argv=None):
     model.precision = args.precision
     left, right = read_png_rgb(args.left), read_png_rgb(args.right)
     calib = kitti_utils.read_obj_calibration(args.calib)
-    l, scale = engine.preprocess(torch.from_numpy(left).to(dev), cfg.TEST.SCALES[0])
-    r, _ = engine.preprocess(torch.from_numpy(right).to(dev), cfg.TEST.SCALES[0])
-    info = torch.tensor([[l.shape[2], l.shape[3], scale]], dtype=torch.float32, device=dev)
-    pipeline.detect_3d(model, l, r, info, calib, left.shape)                    # first call: per-shape autotuning
+    lu, ru = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)
+    pipeline.detect_3d_images(model, lu, ru, calib)                             # first call: per-shape autotuning
     torch.cuda.synchronize()
     t0 = time.time()
-    objs = pipeline.detect_3d(model, l, r, info, calib, left.shape)
+    objs = pipeline.detect_3d_images(model, lu, ru, calib)                      # preprocessing .. rectified 3-D boxes, on the device
     torch.cuda.synchronize()
     dt = time.time() - t0
     with tempfile.TemporaryDirectory() as td:

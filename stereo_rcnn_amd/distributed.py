@@ -9,7 +9,10 @@ records per step (~29 KB/image: latency-bound on xGMI, issued asynchronously).
 import torch
 import torch.distributed as dist
 
-REC_COLS = 24    # [score, left box 4, right box 4, dim_orien 5, kpts 5, roi index, pad...]
+# one row per detection: [score, left box 4, right box 4, dim_orien 5, kpts 5, roi index | 4-DoF status, x y z theta (4-DoF) |
+# alignment status, disparity, final x y z theta, alpha] -- include/srcnn_hip.h SRCNN_REC_COLS; columns 20.. are filled by
+# the device 3-D stage (pipeline.launch_3d) and are zero in a detector-only record
+REC_COLS = 32
 
 
 def shard_indices(num_items, rank, world_size):
@@ -75,7 +78,9 @@ def unpack_records(rec):
     k = int(rec[0, 0])
     body = rec[1:k + 1]
     return {'scores': body[:, 0], 'boxes_left': body[:, 1:5], 'boxes_right': body[:, 5:9],
-            'dim_orien': body[:, 9:14], 'kpts': body[:, 14:19], 'roi_index': body[:, 19].long()}
+            'dim_orien': body[:, 9:14], 'kpts': body[:, 14:19], 'roi_index': body[:, 19].long(),
+            'solve_status': body[:, 20], 'pose_4dof': body[:, 21:25], 'align_status': body[:, 25], 'disparity': body[:, 26],
+            'pose': body[:, 27:31], 'alpha': body[:, 31]}
 
 
 def gather_detections(rec, async_op=False):

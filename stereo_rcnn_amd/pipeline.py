@@ -1,17 +1,28 @@
 """Stereo 3-D detection of one pair, end to end - the flow of the reference's demo.py:137-326
 (= test_net.py:131-331): network forward, decode, per-class NMS, border inference, 4-DoF box solve,
-dense alignment, 3-DoF rectification.  Device work goes through the HIP library; the two scipy
-solvers and `infer_boundary` are host code, as in the reference (see model/utils/box_estimator.py
-for why they cannot be anything else and still return the reference's boxes)."""
+dense alignment, 3-DoF rectification.
+
+Default (`solver='device'`): EVERY stage is a launch into the HIP library on one stream, working in place on
+the image's fixed-size detection record (include/srcnn_hip.h: SRCNN_REC_COLS) -- class NMS -> pack ->
+srcnn_infer_boundary -> srcnn_solve_4dof -> srcnn_dense_align (masked, fixed batch) -> srcnn_solve_3dof -- and
+ONE device-to-host copy at the end: no host round trip between the detector and the final 3-D boxes, nothing per
+object in Python.  The solvers are scipy's Newton-CG restated in double precision (csrc/box_solver.h).
+
+`solver='scipy'` keeps the reference's own arrangement (host numpy `infer_boundary`, scipy solves, optionally fanned
+out to a process pool) as the comparison path: model/utils/box_estimator.py, model/utils/kitti_utils.py."""
+import collections
+import ctypes
 import math as m
 
 import numpy as np
 import torch
 
-from . import postprocess
-from .model.dense_align.dense_align import align_parallel, check_status
+from . import _lib, postprocess
+from .model.dense_align.dense_align import MAX_PIXELS, align_parallel, check_status
 from .model.utils import box_estimator, kitti_utils
 from .model.utils.config import cfg
+
+REC_COLS = _lib.REC_COLS
 
 
 class _PlainCalib(object):
@@ -38,6 +49,11 @@ def _alpha32(alpha):
     return float(np.float32(alpha))
 
 
+def _scale32(im_info):
+    """im_info[0, 2] as the reference reads it: a float32 tensor element turned into a Python float."""
+    return float(im_info.view(-1, 3)[0, 2])
+
+
 def _noop(_):
     return None
 
@@ -49,24 +65,24 @@ def _worker_init():
 
 
 class SolverPool(object):
-    """Process pool for the host-side scipy solvers (A14 / A17).  Each solve is ~2 ms of single-threaded Python
-    (scipy's Newton-CG driver dominates, not the cost function), an image has tens of objects and the hosts of MI355X
-    boxes have hundreds of cores: fan the objects of a pair out.  Results are identical to the serial path (same
-    function, same inputs, deterministic optimiser).  Workers are spawned (not forked: the parent owns a HIP context)
-    and never touch the GPU."""
+    """Process pool for the scipy comparison path (`solver='scipy'`).  Each scipy solve is ~2 ms of single-threaded Python;
+    workers are spawned (not forked: the parent owns a HIP context), come up single-threaded and never touch the GPU.
+    `workers=None`: cpu_count / world size (ranks of one node share the host cores), at most 32 -- more is slower
+    (profiles/full_pipeline_solver_pool_r01.txt)."""
 
-    def __init__(self, workers=8):
+    def __init__(self, workers=None):
         import multiprocessing as mp
         import os
-        # the workers must come up single-threaded: BLAS / OpenMP pools sized for a 256-core host inside every worker
-        # oversubscribe the machine (measured: 16 workers 6x SLOWER than 8 without this).  The libraries read these
-        # variables when they load, i.e. in the child, which inherits the environment at spawn time.
+        if workers is None:
+            world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')) or 1)
+            workers = max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+        self.workers = int(workers)
         keys = ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS')
         saved = {k: os.environ.get(k) for k in keys}
         os.environ.update({k: '1' for k in keys})
         try:
-            self._pool = mp.get_context('spawn').Pool(int(workers), initializer=_worker_init)
-            self._pool.map(_noop, range(int(workers)))          # workers are up (and have imported) before the first pair
+            self._pool = mp.get_context('spawn').Pool(self.workers, initializer=_worker_init)
+            self._pool.map(_noop, range(self.workers))          # workers are up (and have imported) before the first pair
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -95,11 +111,98 @@ class SolverPool(object):
         self.close()
 
 
-def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh=0.05, class_index=1,
-              dense_align=True, pool=None):
-    """Returns a list of dicts (one per solved object, descending score):
-    box_left (4), box_right (4), score, dim (w,h,l), alpha, xyz (3), theta, aligned (bool).
-    `pool`: optional SolverPool; the two solver stages then run in parallel over the objects of the pair."""
+# ------------------------------------------------------------------------------------------------ device flow
+class _Stage3D(object):
+    """Device + pinned host buffers of the 3-D stage for one in-flight pair (n = rois per image)."""
+
+    def __init__(self, n, im_w, dev):
+        L = _lib.lib()
+        self.n = n
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        self.rec = f32(n + 1, REC_COLS)
+        self.state = torch.empty((2, n, 4), dtype=torch.float64, device=dev)       # [0] 4-DoF, [1] final
+        self.boxes, self.borders, self.poses, self.valid = f32(n, 4), f32(n, 2), f32(n, 7), f32(n)
+        self.align_status, self.best_dis = f32(n), f32(n)
+        self.ws = torch.empty(int(L.srcnn_box3d_workspace_bytes(n, 4096)), dtype=torch.uint8, device=dev)
+        self.rec_host = torch.empty((n + 1, REC_COLS), dtype=torch.float32, pin_memory=True)
+        self.state_host = torch.empty((2, n, 4), dtype=torch.float64, pin_memory=True)
+        self.event = torch.cuda.Event()
+
+
+_stages = {}
+
+
+def _stage(n, dev, slot):
+    key = (str(dev), n, slot)
+    if key not in _stages:
+        _stages[key] = _Stage3D(n, 4096, dev)
+    return _stages[key]
+
+
+def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape, eval_thresh=0.05, class_index=1,
+              dense_align=True, slot=0):
+    """Everything after the forward, asynchronously on the current stream.  out: the forward's tuple; scale: im_info[0, 2] as a
+    Python float (passing it spares a device read).  Returns a handle for collect_3d()."""
+    L = _lib.lib()
+    det = postprocess.decode_detections(*out[:8], im_info)
+    keep_idx, num = postprocess.class_nms_device(det, class_index, eval_thresh, cfg.TEST.NMS)
+    n = int(keep_idx.shape[0])
+    assert int(im_shape[1]) <= 4095, "image wider than the 3-D stage's column buffer"
+    st = _stage(n, keep_idx.device, slot)
+    from . import distributed as sdist
+    sdist.pack_records_device(det, keep_idx, num, class_index, out=st.rec)
+    s = _lib.stream()
+    cal = (float(calib.p2[0, 0]), float(calib.p2[0, 2]), float(calib.p2[1, 2]), float(calib.p2[0, 3] - calib.p3[0, 3]))
+    im_h, im_w = int(im_shape[0]), int(im_shape[1])
+    _lib.check(L.srcnn_infer_boundary(st.rec.data_ptr(), n, REC_COLS, im_w, st.ws.data_ptr(), st.ws.numel(), s),
+               "srcnn_infer_boundary")
+    _lib.check(L.srcnn_solve_4dof(st.rec.data_ptr(), n, REC_COLS, im_h, im_w, cal[0], cal[1], cal[2], cal[3],
+                                  float(eval_thresh), st.state[0].data_ptr(), s), "srcnn_solve_4dof")
+    if dense_align:
+        _lib.check(L.srcnn_align_inputs(st.rec.data_ptr(), n, REC_COLS, st.boxes.data_ptr(), st.borders.data_ptr(),
+                                        st.poses.data_ptr(), st.valid.data_ptr(), s), "srcnn_align_inputs")
+        _, _, H, W = im_left_data.shape
+        ws = _lib.workspace(L.srcnn_dense_align_workspace_bytes(H, W, n, MAX_PIXELS), im_left_data.device, "dense_align")
+        _lib.check(L.srcnn_dense_align(_lib.ptr(im_left_data), _lib.ptr(im_right_data), H, W, float(scale), cal[0], cal[1],
+                                       cal[2], cal[3], st.boxes.data_ptr(), st.borders.data_ptr(), st.poses.data_ptr(),
+                                       st.valid.data_ptr(), n, MAX_PIXELS, st.align_status.data_ptr(),
+                                       st.best_dis.data_ptr(), ws.data_ptr(), ws.numel(), s), "srcnn_dense_align")
+        _lib.check(L.srcnn_solve_3dof(st.rec.data_ptr(), n, REC_COLS, im_h, im_w, cal[0], cal[1], cal[2], cal[3],
+                                      st.align_status.data_ptr(), st.best_dis.data_ptr(), st.state[1].data_ptr(), s),
+                   "srcnn_solve_3dof")
+    st.rec_host.copy_(st.rec, non_blocking=True)
+    st.state_host.copy_(st.state, non_blocking=True)
+    st.event.record()
+    return st
+
+
+def collect_3d(st):
+    """Wait for a launch_3d() handle and turn its record into the object list detect_3d returns."""
+    st.event.synchronize()
+    rec, state = st.rec_host.numpy(), st.state_host.numpy()
+    k = int(rec[0, 0])
+    objs = []
+    for i in range(k):
+        row = rec[1 + i]
+        if not row[20] > 0:                                    # 4-DoF status (demo.py:293)
+            continue
+        if row[25] < 0:
+            check_status(row[25:26])                           # lattice overflow: raises
+        aligned = bool(row[25] > 0)
+        xyz4 = state[0, i, 0:3].copy()
+        o = {'box_left': row[1:5].copy(), 'box_right': row[5:9].copy(), 'score': float(row[0]),
+             'dim': row[9:12].astype(np.float64), 'alpha': m.atan2(float(row[12]), float(row[13])),
+             'xyz': state[1, i, 0:3].copy() if aligned else xyz4, 'theta': float(state[1, i, 3] if aligned else state[0, i, 3]),
+             'kpts': row[14:19].copy(), 'aligned': aligned, 'xyz_init': xyz4, 'theta_init': float(state[0, i, 3]),
+             'roi_index': int(row[19])}
+        if aligned:
+            o['disparity'] = float(row[26])
+        objs.append(o)
+    return objs
+
+
+# ------------------------------------------------------------------------------------------------ scipy comparison flow
+def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index, dense_align, pool):
     with torch.no_grad():
         out = model(im_left_data, im_right_data, im_info)
         det = postprocess.decode_detections(*out[:8], im_info)
@@ -127,7 +230,7 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
                            'score': float(dets_left[i, 4]), 'dim': dim_orien[i, 0:3].astype(np.float64), 'alpha': alpha,
                            'xyz': np.array(state[0:3], dtype=np.float64), 'theta': float(state[3]),
                            'kpts': kpts[i].copy(), 'aligned': False,
-                           'xyz_init': np.array(state[0:3], dtype=np.float64)})   # 4-DoF solve, before alignment
+                           'xyz_init': np.array(state[0:3], dtype=np.float64), 'theta_init': float(state[3])})
     if not solved or not dense_align:
         return solved
     dev = im_left_data.device
@@ -136,8 +239,7 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
     kp = f32([o['kpts'] for o in solved])
     poses = f32([[o['xyz'][0], o['xyz'][1], o['xyz'][2], o['dim'][0], o['dim'][1], o['dim'][2], o['theta']]
                  for o in solved])
-    succ, dis_final = align_parallel(calib, float(im_info.view(-1, 3)[0, 2]), im_left_data, im_right_data, boxes, kp,
-                                     poses)                   # demo.py:306-308
+    succ, dis_final = align_parallel(calib, _scale32(im_info), im_left_data, im_right_data, boxes, kp, poses)   # demo.py:306-308
     succ, dis_final = check_status(succ.cpu().numpy()), dis_final.cpu().numpy()
     todo = [i for i in range(len(solved)) if succ[i] > 0]                                      # demo.py:311-319
     res3 = run([(3, tuple(im_shape), calib.p2, calib.p3,
@@ -152,21 +254,76 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
     return solved
 
 
+# ------------------------------------------------------------------------------------------------ public entry points
+def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh=0.05, class_index=1,
+              dense_align=True, pool=None, solver='device', slot=0):
+    """One preprocessed pair -> list of dicts (one per solved object, descending score):
+    box_left (4), box_right (4), score, dim (w,h,l), alpha, xyz (3), theta, aligned (bool), xyz_init / theta_init (the 4-DoF
+    solve), disparity (aligned objects), kpts (5, borders after the inference step).
+    solver: 'device' (default; native Newton-CG kernels, one D2H copy) or 'scipy' (host numpy + scipy, optional `pool`)."""
+    if solver == 'scipy':
+        return _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
+                                dense_align, pool)
+    with torch.no_grad():
+        out = model(im_left_data, im_right_data, im_info, slot=slot)
+        st = launch_3d(out, im_left_data, im_right_data, im_info, _scale32(im_info), calib, im_shape, eval_thresh,
+                       class_index, dense_align, slot)
+    return collect_3d(st)
+
+
+def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, class_index=1, dense_align=True, slot=0,
+                     wait=True):
+    """The same from the decoded uint8 RGB images on the device: preprocessing fused in front of the forward
+    (model.forward_images), then the device 3-D flow.  wait=False returns the handle for collect_3d()."""
+    with torch.no_grad():
+        out, iml, imr, info = model.forward_images(img_left_u8, img_right_u8, slot=slot)
+        from . import engine
+        scale = float(np.float32(engine.preprocess_size(int(img_left_u8.shape[0]), int(img_left_u8.shape[1]),
+                                                        cfg.TEST.SCALES[0])[2]))
+        st = launch_3d(out, iml, imr, info, scale, calib, tuple(img_left_u8.shape), eval_thresh, class_index, dense_align, slot)
+    return collect_3d(st) if wait else st
+
+
+def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=3, solver='device'):
+    """Generator form for a sequence of pairs: yields one object list per frame, in order, with up to `slots` pairs in flight
+    on their own HIP streams.  frames: iterable of (im_left_data, im_right_data, im_info, calib, im_shape[, scale]) with device
+    tensors, or (img_left_u8, img_right_u8, calib) with uint8 device images (fused preprocessing).  Per pair the results are
+    those of detect_3d (same launches).  solver='scipy' (needs `pool`) keeps the staged host/scipy arrangement."""
+    if solver == 'scipy':
+        for objs in _detect_3d_stream_scipy(model, frames, pool, eval_thresh, class_index, dense_align, min(slots, 2)):
+            yield objs
+        return
+    streams = [torch.cuda.Stream() for _ in range(max(1, slots))]
+    inflight = collections.deque()
+    for k, frame in enumerate(frames):
+        slot = k % len(streams)
+        if len(inflight) == len(streams):                      # the slot's buffers are still in use by the oldest pair
+            yield collect_3d(inflight.popleft())
+        s = streams[slot]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(s):
+            if len(frame) == 3:
+                st = detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align, slot, wait=False)
+            else:
+                l, r, info, calib, im_shape = frame[:5]
+                scale = float(np.float32(frame[5])) if len(frame) > 5 else _scale32(info)
+                out = model(l, r, info, slot=slot)
+                st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot)
+        inflight.append(st)
+    while inflight:
+        yield collect_3d(inflight.popleft())
+
+
 class _Pair(object):
-    """One stereo pair on its way through the streaming pipeline."""
+    """One stereo pair on its way through the staged scipy pipeline."""
     __slots__ = ('frame', 'stream', 'stage', 'rec_host', 'event', 'cand', 'alphas', 'pending', 'solved', 'dets', 'succ_host',
                  'dis_host', 'todo', 'objs')
 
 
-def detect_3d_stream(model, frames, pool, eval_thresh=0.05, class_index=1, dense_align=True, slots=2):
-    """Generator form of detect_3d for a sequence of pairs: yields one object list per frame, in order, and keeps the GPU,
-    the host thread and the solver pool busy at the same time.  frames: iterable of (im_left_data, im_right_data, im_info,
-    calib, im_shape) with device tensors.  Per pair the stages are
-        forward + decode + class NMS + record packing (GPU, async)  ->  borders + 4-DoF tasks (host -> pool, async)
-        ->  dense alignment (GPU, async)  ->  3-DoF tasks (pool, async)  ->  results;
-    every loop iteration launches the next pair's forward and moves each pair in flight ONE stage on, so a wait is always
-    on work that was started an iteration earlier.  Same per-pair results as detect_3d (same kernels, same solver calls)."""
-    import collections
+def _detect_3d_stream_scipy(model, frames, pool, eval_thresh, class_index, dense_align, slots):
+    """The scipy arrangement, staged: forward + decode + class NMS + record (GPU, async) -> borders + 4-DoF tasks (host ->
+    pool, async) -> dense alignment (GPU, async) -> 3-DoF tasks (pool, async) -> results; every loop iteration launches the
+    next pair's forward and moves each pair in flight one stage on."""
     from . import distributed as sdist
     streams = [torch.cuda.Stream() for _ in range(max(1, slots))]
     inflight = collections.deque()
@@ -218,7 +375,8 @@ def detect_3d_stream(model, frames, pool, eval_thresh=0.05, class_index=1, dense
                     p.solved.append({'box_left': dl[i, 0:4].copy(), 'box_right': dr[i, 0:4].copy(), 'score': float(dl[i, 4]),
                                      'dim': do[i, 0:3].astype(np.float64), 'alpha': alpha,
                                      'xyz': np.array(state[0:3], dtype=np.float64), 'theta': float(state[3]),
-                                     'kpts': kpts[i].copy(), 'aligned': False, 'xyz_init': np.array(state[0:3], dtype=np.float64)})
+                                     'kpts': kpts[i].copy(), 'aligned': False, 'xyz_init': np.array(state[0:3], dtype=np.float64),
+                                     'theta_init': float(state[3])})
             if not p.solved or not dense_align:
                 p.objs, p.stage = p.solved, 9
                 return
@@ -226,7 +384,7 @@ def detect_3d_stream(model, frames, pool, eval_thresh=0.05, class_index=1, dense
             dev = l.device
             f32 = lambda rows: torch.tensor(np.asarray(rows), dtype=torch.float32).to(dev, non_blocking=True)
             with torch.no_grad(), torch.cuda.stream(p.stream):
-                succ, dis = align_parallel(calib, p.frame[5] if len(p.frame) > 5 else float(info.view(-1, 3)[0, 2]), l, r,
+                succ, dis = align_parallel(calib, float(np.float32(p.frame[5])) if len(p.frame) > 5 else _scale32(info), l, r,
                                            f32([o['box_left'] for o in p.solved]), f32([o['kpts'] for o in p.solved]),
                                            f32([[o['xyz'][0], o['xyz'][1], o['xyz'][2], o['dim'][0], o['dim'][1], o['dim'][2],
                                                  o['theta']] for o in p.solved]))

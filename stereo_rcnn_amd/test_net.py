@@ -1,7 +1,7 @@
 """KITTI split evaluation driver - the reference's test_net.py:62-345 (config 4 of BASELINE.json), MI355X layout:
 one process per GPU, image ids sharded `i mod world` (the reference loops over them on one GPU with batch size 1),
-every frame: PNG decode on the host -> preprocessing, forward, decode, NMS, 3-D solve, dense alignment, rectification
-(`pipeline.detect_3d`) -> one KITTI result file per frame (`kitti_utils.write_detection_results`, test_net.py:329-330).
+every frame: PNG decode on the host -> uint8 images to the device -> preprocessing, forward, decode, NMS, borders, 3-D solve,
+dense alignment, rectification, all on the device (`pipeline.detect_3d_stream`) -> one KITTI result file per frame (`kitti_utils.write_detection_results`, test_net.py:329-330).
 Result files are per frame, so ranks never write to the same file; there is no collective besides the final barrier.
 
     python -m stereo_rcnn_amd.test_net --kitti-root <.../object/training> --split val.txt --checkpoint model.pth --result-dir out
@@ -36,10 +36,13 @@ def read_png_rgb(path):
         return np.asarray(im.convert('RGB'), dtype=np.uint8)
 
 
-def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4):
+def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4,
+              solver='device', slots=3):
     """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds).
-    With a SolverPool the frames go through pipeline.detect_3d_stream (GPU and solver stages of consecutive frames
-    overlap) and PNG decoding runs `prefetch` frames ahead on host threads; without one, frame by frame."""
+    Frames go through pipeline.detect_3d_stream: PNG decoding runs `prefetch` frames ahead on host threads, the decoded
+    uint8 images are copied to the device and everything else -- preprocessing, forward, decode, NMS, borders, 4-DoF solve,
+    dense alignment, 3-DoF rectification -- is device work with `slots` pairs in flight (solver='device').
+    solver='scipy' (with a SolverPool) runs the reference's host arrangement instead: the comparison path."""
     import collections
     import concurrent.futures as cf
     t0, n_obj = time.time(), 0
@@ -66,19 +69,22 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
 
     def to_device(loaded):
         left, right, calib = loaded
-        l, scale = engine.preprocess(torch.from_numpy(left).to(device), cfg.TEST.SCALES[0])
-        r, _ = engine.preprocess(torch.from_numpy(right).to(device), cfg.TEST.SCALES[0])
-        info = torch.tensor([[l.shape[2], l.shape[3], scale]], dtype=torch.float32).to(device)
         calibs.append(calib)
+        lu, ru = torch.from_numpy(left).to(device, non_blocking=True), torch.from_numpy(right).to(device, non_blocking=True)
+        if solver == 'device':
+            return (lu, ru, calib)                              # preprocessing is fused in front of the forward
+        l, scale = engine.preprocess(lu, cfg.TEST.SCALES[0])
+        r, _ = engine.preprocess(ru, cfg.TEST.SCALES[0])
+        info = torch.tensor([[l.shape[2], l.shape[3], scale]], dtype=torch.float32).to(device)
         return (l, r, info, calib, left.shape, float(scale))
 
     def results():
-        if pool is not None:
-            for objs in pipeline.detect_3d_stream(model, frames(), pool):
+        if solver == 'device' or pool is not None:
+            for objs in pipeline.detect_3d_stream(model, frames(), pool, solver=solver, slots=slots):
                 yield objs
         else:
             for f in frames():
-                yield pipeline.detect_3d(model, *f[:5])
+                yield pipeline.detect_3d(model, *f[:5], solver='scipy')
 
     for k, (frame, objs) in enumerate(zip(ids, results())):
         calib = calibs.popleft()
@@ -97,7 +103,9 @@ def main(argv=None):
     ap.add_argument('--split', required=True, help='text file with one frame id per line (e.g. data/kitti/splits/val.txt)')
     ap.add_argument('--checkpoint', required=True, help="torch checkpoint with a 'model' state_dict (reference schema) or a bare state_dict")
     ap.add_argument('--result-dir', required=True)
-    ap.add_argument('--solver-workers', type=int, default=8)
+    ap.add_argument('--solver', choices=['device', 'scipy'], default='device',
+                    help="3-D stage: 'device' = native Newton-CG kernels (default), 'scipy' = the reference's host arrangement")
+    ap.add_argument('--solver-workers', type=int, default=0, help='scipy path: worker processes (0 = cpu_count / ranks, <= 32)')
     ap.add_argument('--precision', choices=['f16x3', 'f32'], default='f16x3')
     args = ap.parse_args(argv)
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
@@ -117,9 +125,12 @@ def main(argv=None):
     model.precision = args.precision
     ids = read_split(args.split)
     mine = [ids[i] for i in shard_indices(len(ids), rank, world)]
-    with pipeline.SolverPool(args.solver_workers) as pool:
-        frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, pool,
-                                     log=(lambda s: print('[rank %d] %s' % (rank, s), flush=True)))
+    log = lambda s: print('[rank %d] %s' % (rank, s), flush=True)
+    if args.solver == 'scipy':
+        with pipeline.SolverPool(args.solver_workers or None) as pool:
+            frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, pool, log=log, solver='scipy')
+    else:
+        frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, log=log)
     print('[rank %d] %d frames, %d objects, %.1f s (%.1f frames/s)' % (rank, frames, objs, dt, frames / max(dt, 1e-9)), flush=True)
     if use_dist:
         torch.distributed.barrier()

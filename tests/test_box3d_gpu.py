@@ -1,0 +1,211 @@
+"""The 3-D stage on the device: infer_boundary + border replacement, 4-DoF solve, masked dense
+alignment, 3-DoF rectification -- each kernel against its host counterpart / the reference goldens, then the whole flow."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(dl, dr, do, kp, n=300):
+    from stereo_rcnn_amd import _lib
+    k = dl.shape[0]
+    rec = np.zeros((n + 1, _lib.REC_COLS), np.float32)
+    rec[0, 0] = k
+    rec[1:k + 1, 0] = dl[:, 4]
+    rec[1:k + 1, 1:5] = dl[:, :4]
+    rec[1:k + 1, 5:9] = dr[:, :4]
+    rec[1:k + 1, 9:14] = do
+    rec[1:k + 1, 14:19] = kp
+    return rec
+
+
+def _boundary(rec, im_w, dev):
+    from stereo_rcnn_amd import _lib
+    L = _lib.lib()
+    n = rec.shape[0] - 1
+    t = torch.from_numpy(rec).to(dev)
+    ws = torch.empty(int(L.srcnn_box3d_workspace_bytes(n, im_w)), dtype=torch.uint8, device=dev)
+    _lib.check(L.srcnn_infer_boundary(t.data_ptr(), n, _lib.REC_COLS, im_w, ws.data_ptr(), ws.numel(), _lib.stream()))
+    return t.cpu().numpy()
+
+
+def test_infer_boundary_kernel_vs_reference_golden(dev):
+    """kitti_utils.infer_boundary run by the reference code (reference_misc.npz: ib_*) and the replacement rule of
+    demo.py:262-265 on the demo pair's detections (reference_demo_pair: pipe_kpts_after_borders): exact."""
+    m = np.load(os.path.join(GOLD, 'reference_misc.npz'))
+    b = m['ib_boxes']
+    k = b.shape[0]
+    dl = np.concatenate((b, np.ones((k, 1), np.float32)), 1)
+    kp = np.zeros((k, 5), np.float32)                      # zero-width regressed borders: always replaced
+    out = _boundary(_record(dl, dl, np.zeros((k, 5), np.float32), kp), 1242, dev)
+    assert np.array_equal(out[1:k + 1, 17:19], m['ib_left_right'])
+    for name, im_w in (('reference_demo_pair_r101_seed3.npz', 1242),):
+        g = np.load(os.path.join(GOLD, name))
+        out = _boundary(_record(g['cls_dets_left'], g['cls_dets_right'], g['cls_dim_orien'], g['cls_kpts']), im_w, dev)
+        kk = g['cls_kpts'].shape[0]
+        assert np.array_equal(out[1:kk + 1, 14:19], g['pipe_kpts_after_borders'])
+    # the small synthetic frame (120 x 400): reference_misc pipe_*
+    out = _boundary(_record(m['cls_dets_left'], m['cls_dets_right'], m['cls_dim_orien'], m['cls_kpts']), 400, dev)
+    assert np.array_equal(out[1:m['cls_kpts'].shape[0] + 1, 14:19], m['pipe_kpts_after_borders'])
+
+
+def test_infer_boundary_kernel_random_vs_host(dev):
+    from stereo_rcnn_amd.model.utils import kitti_utils
+    rng = np.random.default_rng(4)
+    for _ in range(10):
+        n = int(rng.integers(1, 40))
+        x1 = rng.uniform(0, 1100, n); w = rng.uniform(20, 300, n); y2 = rng.uniform(150, 374, n)
+        dl = np.stack([x1, y2 - rng.uniform(20, 120, n), np.minimum(x1 + w, 1241), y2, rng.uniform(0.1, 1, n)], 1).astype(np.float32)
+        kp = np.zeros((n, 5), np.float32)
+        kp[:, 3] = dl[:, 0] + rng.uniform(0, 60, n)
+        kp[:, 4] = dl[:, 2] - rng.uniform(0, 60, n)
+        want = kp.copy()
+        inf = kitti_utils.infer_boundary((375, 1242, 3), dl)
+        for i in range(n):
+            if float(want[i, 4]) - float(want[i, 3]) < 0.5 * (float(inf[i, 1]) - float(inf[i, 0])):
+                want[i, 3:5] = inf[i]
+        out = _boundary(_record(dl, dl, np.zeros((n, 5), np.float32), kp), 1242, dev)
+        assert np.array_equal(out[1:n + 1, 14:19], want)
+
+
+def _cases(n, seed):
+    from test_solvers_cpu import _case
+    rng = np.random.default_rng(seed)
+    rows = []
+    while len(rows) < n:
+        calib, pose, dim, bl, br, kp, alpha = _case(rng)
+        f32 = lambda v: np.asarray(v, np.float32)
+        rows.append((f32(bl), f32(br), f32(dim), f32(kp), np.float32(math.sin(alpha)), np.float32(math.cos(alpha)), pose))
+    return calib, rows
+
+
+def test_solve_kernels_vs_host_build(dev):
+    """srcnn_solve_4dof / srcnn_solve_3dof (device) against the SAME code compiled for the host (which is bit-identical to
+    scipy's iteration, tests/test_solvers_cpu.py): status equal; end points equal except where the device libm's cos / sin /
+    atan2 differ from glibc's in the last bit on a chaotic case."""
+    from stereo_rcnn_amd import _lib
+    from stereo_rcnn_amd.model.utils import box_estimator as pbe
+    L = _lib.lib()
+    calib, rows = _cases(250, 11)
+    k = len(rows)
+    dl = np.array([np.append(r[0], 0.9) for r in rows], np.float32)
+    dr = np.array([np.append(r[1], 0.9) for r in rows], np.float32)
+    do = np.array([np.concatenate((r[2], [r[4], r[5]])) for r in rows], np.float32)
+    kp = np.array([r[3] for r in rows], np.float32)
+    rec = torch.from_numpy(_record(dl, dr, do, kp)).to(dev)
+    n = rec.shape[0] - 1
+    state = torch.zeros((2, n, 4), dtype=torch.float64, device=dev)
+    cal = (float(calib.p2[0, 0]), float(calib.p2[0, 2]), float(calib.p2[1, 2]), float(calib.p2[0, 3] - calib.p3[0, 3]))
+    _lib.check(L.srcnn_solve_4dof(rec.data_ptr(), n, _lib.REC_COLS, 375, 1242, *cal, 0.05, state[0].data_ptr(), _lib.stream()))
+    # aligned disparity = the true one of the case
+    fb = cal[3]
+    dis = torch.tensor([fb / r[6][2] for r in rows] + [1.0] * (n - k), dtype=torch.float32, device=dev)
+    ast = torch.ones(n, dtype=torch.float32, device=dev)
+    _lib.check(L.srcnn_solve_3dof(rec.data_ptr(), n, _lib.REC_COLS, 375, 1242, *cal, ast.data_ptr(), dis.data_ptr(),
+                                  state[1].data_ptr(), _lib.stream()))
+    torch.cuda.synchronize()
+    got_rec, got = rec.cpu().numpy(), state.cpu().numpy()
+    same4, same3, d4, d3 = [], [], [], []
+    for i, r in enumerate(rows):
+        alpha = math.atan2(float(r[4]), float(r[5]))
+        st, want = pbe.solve_x_y_z_theta_from_kpt_native((375, 1242, 3), calib, alpha, r[2], r[0], r[1], r[3])
+        assert int(got_rec[1 + i, 20]) == st
+        if np.ndim(want) == 0:
+            continue
+        d4.append(np.abs(got[0, i] - want).max())
+        same4.append(np.array_equal(got[0, i], want))
+        assert np.array_equal(got_rec[1 + i, 21:25], want.astype(np.float32)) or not same4[-1]
+        if st:
+            s3, z = pbe.solve_x_y_theta_from_kpt_native((375, 1242, 3), calib, float(got_rec[1 + i, 31]), r[2], r[0],
+                                                        float(dis[i]), r[3])
+            want3 = np.array([s3[0], s3[1], z, s3[2]])
+            d3.append(np.abs(got[1, i] - want3).max())
+            same3.append(np.array_equal(got[1, i], want3))
+    print('device vs host build: bit-identical 4-DoF %.3f (L-inf median %.1e max %.1e), 3-DoF %.3f (max %.1e)'
+          % (np.mean(same4), np.median(d4), np.max(d4), np.mean(same3), np.max(d3)))
+    assert np.mean(same4) >= 0.85 and np.mean(same3) >= 0.9
+    assert np.quantile(d4, 0.9) < 1e-4 and np.quantile(d3, 0.95) < 1e-4
+
+
+def test_masked_dense_alignment_equals_compacted(dev):
+    """srcnn_dense_align with a validity mask over a fixed batch == the compacted call on the valid rows only."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture
+    from stereo_rcnn_amd.model.dense_align.dense_align import align_parallel
+    m = np.load(os.path.join(GOLD, 'reference_misc.npz'))
+    l, r, info = fixture.make_inputs(3, 375, 1242)
+    l, r = l.to(dev), r.to(dev)
+    boxes, kp, poses = (torch.from_numpy(m['da3_' + k]).to(dev) for k in ('boxes', 'kpts', 'poses'))
+    R = boxes.shape[0]
+    st0, dis0 = align_parallel(calib, float(info[0, 2]), l, r, boxes, kp, poses)
+    assert np.array_equal(st0.cpu().numpy(), m['da3_status'])
+    valid = torch.zeros(2 * R, device=dev)
+    valid[0::2] = 1
+    pad = lambda t: torch.stack((t, torch.zeros_like(t)), 1).view(2 * R, -1)
+    st1, dis1 = align_parallel(calib, float(info[0, 2]), l, r, pad(boxes), pad(kp), pad(poses), valid=valid)
+    assert torch.equal(st1[0::2], st0) and torch.equal(dis1[0::2][st0 > 0], dis0[st0 > 0])
+    assert float(st1[1::2].abs().max()) == 0
+
+
+def _model(dev, sd, precision='f16x3'):
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    mdl = resnet(('__background__', 'Car'), 101)
+    mdl.create_architecture()
+    mdl.load_state_dict(sd)
+    mdl.cuda().eval()
+    mdl.precision = precision
+    return mdl
+
+
+def test_device_flow_vs_scipy_flow(dev):
+    """detect_3d with the native device solvers vs the reference's host arrangement (numpy infer_boundary + scipy) on the
+    same forward: same objects and borders; 4-DoF end points bit-comparable for the bulk, aligned disparity equal wherever
+    the 4-DoF end points are."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    l, r, info = fixture.make_inputs(3, 200, 660, target_short=320)
+    args = (mdl, l.to(dev), r.to(dev), info.to(dev), calib, (200, 660, 3))
+    a = pipeline.detect_3d(*args)
+    b = pipeline.detect_3d(*args, solver='scipy')
+    assert len(a) == len(b) > 0
+    same_init, d4, ddis = 0, [], []
+    for x, y in zip(a, b):
+        assert np.array_equal(x['box_left'], y['box_left']) and np.array_equal(x['kpts'], y['kpts']) and x['score'] == y['score']
+        d4.append(max(np.abs(x['xyz_init'] - y['xyz_init']).max(), abs(x['theta_init'] - y['theta_init'])))
+        if np.abs(x['xyz_init'] - y['xyz_init']).max() < 1e-6:
+            same_init += 1
+            assert x['aligned'] == y['aligned']
+            if x['aligned']:
+                ddis.append(abs(x['disparity'] - y['disparity']))
+    print('device vs scipy flow: %d objects, same 4-DoF end point %d, L-inf 4-DoF median %.1e; |d disparity| max %.1e'
+          % (len(a), same_init, np.median(d4), max(ddis, default=0.0)))
+    assert same_init >= 0.6 * len(a)
+    assert max(ddis, default=0.0) < 2e-3
+
+
+def test_streaming_equals_serial_and_images_entry(dev):
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    frames, pairs = [], []
+    for seed in (3, 4, 5, 6):
+        lu, ru = fixture.synthetic_pair(seed, 120, 400)
+        pairs.append((torch.from_numpy(lu).to(dev), torch.from_numpy(ru).to(dev), calib))
+    import stereo_rcnn_amd.model.utils.config as C
+    short = C.cfg.TEST.SCALES[0]
+    serial = [pipeline.detect_3d_images(mdl, *p) for p in pairs]
+    streamed = list(pipeline.detect_3d_stream(mdl, pairs + pairs, slots=3))
+    assert len(streamed) == 8
+    for want, got in zip(serial + serial, streamed):
+        assert len(want) == len(got)
+        for x, y in zip(want, got):
+            assert np.array_equal(x['box_left'], y['box_left']) and x['aligned'] == y['aligned']
+            assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta']

@@ -130,3 +130,109 @@ def test_oracle_post_network_flow_on_demo_pair(pair, gold, tmp_path):
     print('3-DoF rectified box, oracle vs reference: max |dz| %.2e, L-inf(x,y,theta) per object %s'
           % (max(dz), np.array2string(np.asarray(dxyt), precision=2)))
     assert max(dz) < 1e-9 and np.median(dxyt) < 1e-4
+
+
+# ================================================================================================ GPU part
+def _model(dev, precision):
+    from stereo_rcnn_amd import fixture
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    mdl = resnet(('__background__', 'Car'), 101, pretrained=False)
+    mdl.create_architecture()
+    mdl.load_state_dict(fixture.demo_state_dict(3))
+    mdl.cuda().eval()
+    mdl.precision = precision
+    return mdl
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ['f16x3', 'f32'])
+def test_hip_forward_on_demo_pair_vs_reference_code(dev, pair, gold, precision):
+    """uint8 images -> fused preprocessing -> forward, both conv engines, against the reference code's outputs on the
+    same natural image: network input bit-equal; proposals matched by coordinates; regressions within 1e-4."""
+    mdl = _model(dev, precision)
+    lu, ru = torch.from_numpy(pair['left']).to(dev), torch.from_numpy(pair['right']).to(dev)
+    with torch.no_grad():
+        out, iml, imr, info = mdl.forward_images(lu, ru)
+    torch.cuda.synchronize()
+    assert hashlib.sha256(np.ascontiguousarray(iml.cpu().numpy()).tobytes()).digest() == gold['input_sha256'].tobytes()
+    assert [float(v) for v in info.cpu()[0]] == [600.0, 1987.0, float(np.float32(1.6))]
+    ref_l, ref_r = _rows(gold['rois_left']), _rows(gold['rois_right'])
+    rl, rr = out[0][0].cpu(), out[1][0].cpu()
+    d = (ref_l[:, None, 1:] - rl[None, :, 1:]).abs().amax(2)
+    best, idx = d.min(1)
+    ok = best < 5e-2
+    frac = float(ok.float().mean())
+    errs = {'rois_right': float((rr[idx[ok]] - ref_r[ok]).abs().max())}
+    for k, t in (('cls_prob', out[2][0]), ('bbox_pred', out[3][0]), ('dim_orien_pred', out[4][0]), ('kpts_prob', out[5]),
+                 ('left_border_prob', out[6]), ('right_border_prob', out[7])):
+        errs[k] = float((t.cpu()[idx[ok]] - _rows(gold[k])[ok]).abs().max())
+    print('demo pair, %s engine vs reference code: matched proposals %d/300, max abs errors %s'
+          % (precision, int(ok.sum()), {k: '%.1e' % v for k, v in errs.items()}))
+    assert frac >= 0.97, frac
+    assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, errs
+    assert all(v < 2e-3 for v in errs.values()), errs
+
+
+@pytest.mark.gpu
+def test_hip_decode_class_nms_and_borders_on_demo_pair(dev, pair, gold):
+    """Product decode / class NMS / infer_boundary kernels on the REFERENCE network's outputs for the demo pair."""
+    from stereo_rcnn_amd import _lib, distributed as sdist
+    from stereo_rcnn_amd import postprocess as hpost
+    t = lambda k: torch.from_numpy(gold[k]).to(dev)
+    info = torch.tensor([[600.0, 1987.0, 1.6]], device=dev)
+    det = hpost.decode_detections(t('rois_left'), t('rois_right'), t('cls_prob'), t('bbox_pred'), t('dim_orien_pred'),
+                                  t('kpts_prob'), t('left_border_prob'), t('right_border_prob'), info)
+    for a, b, tol in (('scores', 'dec_scores', 0.0), ('boxes_left', 'dec_boxes_left', 2e-3), ('boxes_right', 'dec_boxes_right', 2e-3),
+                      ('kpts', 'dec_kpts', 2e-3), ('dim_orien', 'dec_dim_orien', 1e-6)):
+        err = float(np.abs(det[a].cpu().numpy() - gold[b].reshape(tuple(det[a].shape))).max())
+        assert err <= tol, (a, err)
+    keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
+    k = int(num[0])
+    assert k == gold['cls_keep'].shape[0]
+    rec = sdist.pack_records_device(det, keep_idx, num, 1)
+    L = _lib.lib()
+    ws = torch.empty(int(L.srcnn_box3d_workspace_bytes(300, 1242)), dtype=torch.uint8, device=dev)
+    _lib.check(L.srcnn_infer_boundary(rec.data_ptr(), 300, _lib.REC_COLS, 1242, ws.data_ptr(), ws.numel(), _lib.stream()))
+    body = rec.cpu().numpy()[1:k + 1]
+    assert float(np.abs(body[:, 1:5] - gold['cls_dets_left'][:, :4]).max()) < 2e-3
+    assert float(np.abs(body[:, 5:9] - gold['cls_dets_right'][:, :4]).max()) < 2e-3
+    assert np.array_equal(body[:, 0], gold['cls_dets_left'][:, 4])
+    # borders: integers (image columns) or regressed values -- equal up to the decode's expf ulp
+    assert float(np.abs(body[:, 14:19] - gold['pipe_kpts_after_borders']).max()) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ['f16x3', 'f32'])
+def test_hip_full_flow_on_demo_pair_reports_3d_box_deltas(dev, pair, gold, tmp_path, precision):
+    """demo.py:100-326 end to end on the HIP path (uint8 images in, rectified 3-D boxes out) next to the reference code's
+    own run: the honest number for the '3D box L-inf' half of the metric, per object."""
+    from stereo_rcnn_amd import pipeline
+    mdl = _model(dev, precision)
+    calib = demo_calib(pair, tmp_path)
+    lu, ru = torch.from_numpy(pair['left']).to(dev), torch.from_numpy(pair['right']).to(dev)
+    objs = pipeline.detect_3d_images(mdl, lu, ru, calib)
+    ref_boxes, ref_pose4, ref_dis, ref_final = gold['pipe_boxes_all'], gold['pipe_poses_all'], gold['pipe_dis_final'], gold['pipe_rectified']
+    assert abs(len(objs) - ref_boxes.shape[0]) <= 2, (len(objs), ref_boxes.shape[0])
+    rows = []
+    for j in range(ref_boxes.shape[0]):
+        o = min(objs, key=lambda q: np.abs(q['box_left'] - ref_boxes[j, :4]).max())
+        if np.abs(o['box_left'] - ref_boxes[j, :4]).max() > 2e-2:
+            continue
+        d4 = max(np.abs(o['xyz_init'] - ref_pose4[j, 0:3]).max(), abs(o['theta_init'] - ref_pose4[j, 6]))
+        assert o['aligned'] == bool(gold['pipe_succ'][j] > 0)
+        dd = abs(o['disparity'] - ref_dis[j])
+        dfin = max(np.abs(o['xyz'] - ref_final[j, 0:3]).max(), abs(o['theta'] - ref_final[j, 3]))
+        rows.append((d4, dd, dfin, abs(o['xyz'][2] - ref_final[j, 2])))
+    rows = np.asarray(rows)
+    assert rows.shape[0] >= ref_boxes.shape[0] - 2
+    print('demo pair, %s engine, %d objects vs the reference run -- per object:' % (precision, rows.shape[0]))
+    print('  4-DoF L-inf(x,y,z,theta)  ', np.array2string(rows[:, 0], precision=1, max_line_width=200))
+    print('  |d aligned disparity| px  ', np.array2string(rows[:, 1], precision=1, max_line_width=200))
+    print('  final 3-D box L-inf       ', np.array2string(rows[:, 2], precision=1, max_line_width=200))
+    print('  final |dz| m              ', np.array2string(rows[:, 3], precision=1, max_line_width=200))
+    # what is well defined: where the 4-DoF end point is reproduced the alignment searches the same grid and the
+    # final box follows; elsewhere the photometric search still brackets the same minimum for most objects
+    same = rows[:, 0] < 1e-3
+    if same.any():
+        assert rows[same, 1].max() < 2e-3 and np.median(rows[same, 2]) < 1e-3
+    assert np.median(rows[:, 1]) < 0.6          # one coarse depth step of the enumeration at most, typically

@@ -24,7 +24,7 @@ def test_detect_3d_matches_oracle_pipeline(dev):
     m.cuda().eval()
     l, r, info = fixture.make_inputs(3, 200, 660, target_short=320)
     im_shape = (200, 660, 3)
-    got = pipeline.detect_3d(m, l.to(dev), r.to(dev), info.to(dev), calib, im_shape)
+    got = pipeline.detect_3d(m, l.to(dev), r.to(dev), info.to(dev), calib, im_shape, solver='scipy')
     ref = opipe.detect_3d(sd, l, r, info, calib, im_shape)
     assert len(ref) > 0 and abs(len(got) - len(ref)) <= max(2, len(ref) // 10)
     matched, same_init, ddis_same, ddis_other = 0, 0, [], []
@@ -108,12 +108,23 @@ def test_kitti_split_driver_writes_result_files(dev, tmp_path):
     for ln in lines:
         parts = ln.split()
         assert parts[0] == 'Car' and len(parts) == 16 and all(np.isfinite(float(v)) for v in parts[1:])
-    # the streaming form (solver pool + overlapped stages + prefetching decode) writes the same files
-    with pipeline.SolverPool(2) as pool:
-        frames2, n_obj2, _ = test_net.run_split(m, str(root), ids, str(tmp_path / 'result2'), dev, pool)
+    # a second run (three pairs in flight again) writes byte-identical files: the device 3-D stage is deterministic
+    frames2, n_obj2, _ = test_net.run_split(m, str(root), ids, str(tmp_path / 'result2'), dev)
     assert frames2 == 3
     for f in written:
         assert (tmp_path / 'result2' / 'data' / f).read_text() == (tmp_path / 'result' / 'data' / f).read_text()
+    # the scipy comparison arrangement (host numpy + scipy in a process pool, staged) finds the same objects per frame
+    with pipeline.SolverPool(2) as pool:
+        frames3, n_obj3, _ = test_net.run_split(m, str(root), ids, str(tmp_path / 'result3'), dev, pool, solver='scipy')
+    assert frames3 == 3
+    same = total = 0
+    for f in written:
+        a = (tmp_path / 'result3' / 'data' / f).read_text().splitlines()
+        b = (tmp_path / 'result' / 'data' / f).read_text().splitlines()
+        boxes = lambda lines: {tuple(ln.split()[4:8]) for ln in lines}
+        same += len(boxes(a) & boxes(b))
+        total += max(len(a), len(b))
+    assert total == 0 or same >= 0.8 * total
 
 
 def test_demo_entry_point(dev, tmp_path, capsys):
@@ -152,9 +163,9 @@ def test_streaming_pipeline_equals_serial(dev):
     for seed in (3, 4, 5):
         l, r, info = fixture.make_inputs(seed, 200, 660, target_short=320)
         frames.append((l.to(dev), r.to(dev), info.to(dev), calib, (200, 660, 3), float(info[0, 2])))
-    serial = [pipeline.detect_3d(m, *f[:5]) for f in frames]
+    serial = [pipeline.detect_3d(m, *f[:5], solver='scipy') for f in frames]
     with pipeline.SolverPool(2) as pool:
-        streamed = list(pipeline.detect_3d_stream(m, frames + frames, pool))
+        streamed = list(pipeline.detect_3d_stream(m, frames + frames, pool, solver='scipy'))
     assert len(streamed) == 6
     for want, got in zip(serial + serial, streamed):
         assert len(want) == len(got)
