@@ -57,6 +57,11 @@ def parse():
                          'written after the run otherwise (used to keep the rocprofv3 kernel statistics free of trial plans)')
     ap.add_argument('--gather-every', type=int, default=8,
                     help='(multi-GPU) steps whose detection records share one RCCL all_gather')
+    ap.add_argument('--no-f32-leg', action='store_true',
+                    help='skip the short exact-fp32-engine measurement that the default line carries as `engines.f32`')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / collective check without a GPU: every rank packs fake detection records on the CPU and '
+                         'gathers them over gloo; prints the JSON line with value 0 (used by the CPU tests)')
     ap.add_argument('--height', type=int, default=375)
     ap.add_argument('--width', type=int, default=1242)
     return ap.parse_args()
@@ -84,12 +89,81 @@ def cpu_baseline(seed, height, width):
                       % (width, height, l.shape[3], l.shape[2], dt)}
 
 
+def csrc_hash():
+    """sha256 over the kernel sources: stamps PMC-derived files so that a stale one is detected (profiles/pmc_*_traffic.json)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, 'stereo_rcnn_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(base, '*.hip')) + glob.glob(os.path.join(base, '*.h'))):
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: become the driver's own launch line
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>), one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, rank, world):
+    """No GPU: exercises exactly the multi-process plumbing of the benchmark -- env contract, process group, the packed
+    detection records of `--gather-every` steps in one all_gather, barrier + max-over-ranks timing -- over gloo."""
+    from stereo_rcnn_amd import distributed as sdist
+    use_dist = 'RANK' in os.environ
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+    G = max(1, args.gather_every)
+    buf = torch.zeros((G, 301, sdist.REC_COLS))
+    seen = 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        buf[k % G, 0, 0] = 1.0
+        buf[k % G, 1, 0] = float(rank)
+        if k % G == G - 1 or k == args.steps - 1:
+            out, work = sdist.gather_detections(buf)
+            if work is not None:
+                work.wait()
+            assert out.shape[0] == world and sorted(out[:, 0, 1, 0].tolist()) == [float(r) for r in range(world)]
+            seen += 1
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if use_dist:
+        dist.barrier()
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        assert world == args.gpus, "launched with %d ranks for --gpus %d" % (world, args.gpus)
+        print(json.dumps({'metric': 'stereo pairs/sec @1242x375 ResNet-101', 'value': 0.0, 'unit': 'stereo pairs/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 0.0,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'synthetic',
+                          'config': {'workload': 'DRY RUN (no GPU): launcher + gloo all_gather of %d fake record batches' % seen,
+                                     'parallelism': 'pairs sharded 1/rank, one all_gather of the detection records per %d steps' % G},
+                          'roofline': None, 'dry_run': True}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        relaunch_under_torchrun(args)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     use_dist = 'RANK' in os.environ          # launched by torch.distributed.run (any world size, incl. 1)
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    assert world == args.gpus or not use_dist, "launched with %d ranks for --gpus %d" % (world, args.gpus)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -222,11 +296,14 @@ def main():
             single = {'value': round(args.steps * world / float(e1[0]), 3), 'unit': 'stereo pairs/s',
                       'ms_per_step': round(float(e1[0]) / args.steps * 1e3, 3)}
 
-        # ---- roofline of the dominant kernel (the conv engine): HIP events recorded by the library on
-        # the launch stream around every conv launch, over the same workload (eager launches on ONE
-        # stream, so that each launch is timed alone on the chip rather than while sharing it with the
-        # side-stream branches; events cannot be read back from inside a replayed graph).
+        # ---- roofline of the dominant kernel (the conv engine).  Two executions, both reported, each next to ITS OWN step time:
+        #  * kernel level (`roofline.achieved`): HIP events recorded by the library on the launch stream around every conv
+        #    launch, eager launches on ONE stream with the side-stream branches folded in, so that each launch is timed alone
+        #    on the chip -- this is the `one_pair_at_a_time` execution, and conv_ms_per_step <= one_pair_at_a_time.ms_per_step;
+        #  * headline mode (`roofline.headline`): the same algorithmic conv FLOPs per step over the headline's measured wall
+        #    time per step (several pairs in flight share the chip, so per-launch events would time the sharing, not the kernel).
         roofline = None
+        engines = None
         if rank == 0:
             L = _lib.lib()
             model.use_graph = False
@@ -234,9 +311,14 @@ def main():
                 pl.overlap = False
             step(gather=False)
             torch.cuda.synchronize()
+            nprof = min(args.steps, 5)
+            t2 = time.perf_counter()
+            for _ in range(nprof):
+                step(gather=False)
+            torch.cuda.synchronize()
+            serial_ms = (time.perf_counter() - t2) * 1e3 / nprof        # same execution, events off
             engine.FlopCounter.enabled, engine.FlopCounter.flops, engine.FlopCounter.launches = True, 0.0, 0
             L.srcnn_prof_enable(1)
-            nprof = min(args.steps, 5)
             for _ in range(nprof):
                 step(gather=False)
             torch.cuda.synchronize()
@@ -248,20 +330,28 @@ def main():
             achieved = alg / (ms.value * 1e-3) / 1e12
             peak = PEAKS[args.precision]
             issued = 3.0 if args.precision == 'f16x3' else 1.0     # MFMA flops issued per algorithmic flop
-            # HBM-side bytes per conv launch from the committed PMC passes (counters cannot be read from inside this
-            # process): FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on gfx950, WRITE_SIZE as is
-            traffic, traffic_note = None, 'no profiles/pmc_*_traffic.json next to bench.py'
             launches = int(cnt.value // nprof)
+            alg_step = alg / nprof
+            # HBM-side bytes per conv launch: PMC counters cannot be read from inside this process, so they come from the
+            # newest committed rocprofv3 --pmc summary -- but ONLY if that file was measured on these kernel sources
+            # (it carries the sha256 of stereo_rcnn_amd/csrc/*); otherwise traffic is null, never a stale number.
+            traffic, traffic_note = None, 'no profiles/pmc_*_traffic.json next to bench.py'
             import glob
-            tj = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_*_traffic.json')))
+            tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_*_traffic.json')))
             if tj and args.precision == 'f16x3':
                 with open(tj[-1]) as f:
-                    pm = json.load(f)
-                traffic = round((2.0 * pm['conv_fetch_size_kb_per_step'] + pm['conv_write_size_kb_per_step']) * 1024.0
-                                / max(launches, 1))
-                traffic_note = ('bytes per conv launch, HBM side: (2 x FETCH_SIZE + WRITE_SIZE) of the conv-engine launches of one '
-                                'step / launches, from separate rocprofv3 --pmc passes (%s, profiles/pmc_r01_f16x3_bench.txt); '
-                                'algorithmic: ~38 MB per launch' % os.path.basename(tj[-1]))
+                    txt = f.read().strip()
+                pm = json.loads(txt) if txt else {}
+                if pm.get('csrc_sha256') != csrc_hash():
+                    traffic_note = ('%s was not measured on the current kernel sources (csrc hash differs or is absent): '
+                                    'traffic withheld' % os.path.basename(tj[-1]))
+                else:
+                    traffic = round((2.0 * pm['conv_fetch_size_kb_per_step'] + pm['conv_write_size_kb_per_step']) * 1024.0
+                                    / max(launches, 1))
+                    traffic_note = ('bytes per conv launch, HBM side: (2 x FETCH_SIZE + WRITE_SIZE) of the conv-engine launches of '
+                                    'one step / launches, separate rocprofv3 --pmc passes on these sources (%s); algorithmic: '
+                                    '~%.0f MB per launch' % (os.path.basename(tj[-1]), pm.get('algorithmic_mb_per_launch', 38)))
+            head_ms = elapsed / args.steps * 1e3
             roofline = {'bound': 'mfma', 'kernel': ENGINE_DESC[args.precision],
                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': round(achieved / peak, 4), 'traffic': traffic,
@@ -269,11 +359,44 @@ def main():
                         'issued_mfma_frac': round(achieved * issued / peak, 4),
                         'launches_per_step': launches,
                         'avg_launch_ms': round(ms.value / max(cnt.value, 1), 5),
-                        'algorithmic_gflop_per_step': round(alg / nprof / 1e9, 1),
-                        'conv_ms_per_step': round(ms.value / nprof, 3)}
-            model.use_graph = use_graph
+                        'algorithmic_gflop_per_step': round(alg_step / 1e9, 1),
+                        'conv_ms_per_step': round(ms.value / nprof, 3),
+                        'execution': 'one pair at a time, one stream, every conv launch alone on the chip',
+                        'step_ms_of_this_execution': round(serial_ms, 3),
+                        'headline': {'execution': '%d pairs in flight (the mode `value` is measured in)' % S,
+                                     'achieved': round(alg_step / (head_ms * 1e-3) / 1e12, 2),
+                                     'frac': round(alg_step / (head_ms * 1e-3) / 1e12 / peak, 4),
+                                     'issued_mfma_frac': round(alg_step / (head_ms * 1e-3) / 1e12 * issued / peak, 4),
+                                     'step_ms_of_this_execution': round(head_ms, 3)}}
+            assert ms.value / nprof <= serial_ms * 1.02, "conv time exceeds the step time of its own execution"
             for pl in model._plans.values():
                 pl.overlap = True
+            # ---- the exact-fp32 engine as a first-class figure of the same line (short: fewer steps, its own plans)
+            engines = {args.precision: {'value': round(args.steps * world / elapsed, 3), 'ms_per_step': round(head_ms, 3),
+                                        'pairs_in_flight': S}}
+            other = 'f32' if args.precision == 'f16x3' else 'f16x3'
+            if not args.no_f32_leg and world == 1:
+                model.precision = other
+                nf = max(3, min(args.steps, 12))
+                def run_other(k):
+                    if S == 1:
+                        step(0, gather=False)
+                    else:
+                        with torch.cuda.stream(streams[k % S]):
+                            step(k % S, gather=False)
+                for slot in range(S):                   # first touch per slot: autotunes this engine's plans
+                    run_other(slot)
+                    torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for k in range(nf):
+                    run_other(k)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t3
+                engines[other] = {'value': round(nf / dt, 3), 'ms_per_step': round(dt / nf * 1e3, 3), 'pairs_in_flight': S,
+                                  'steps': nf, 'peak': PEAKS[other],
+                                  'frac_headline_mode': round(alg_step / (dt / nf) / 1e12 / PEAKS[other], 4)}
+                model.precision = args.precision
+            model.use_graph = use_graph
 
     if rank == 0:
         pairs = args.steps * world
@@ -289,7 +412,7 @@ def main():
                                    % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
                        'weights': 'seeded random init, reference state_dict schema', 'hipgraph': use_graph,
                        'host_enqueue_ms_per_step': round(host_enqueue_ms, 3), 'plans_preloaded': plans_loaded,
-                       'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single,
+                       'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single, 'engines': engines,
                        'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},
             'roofline': roofline,
         }

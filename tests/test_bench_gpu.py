@@ -21,6 +21,13 @@ def _check(line, steps, warmup):
     assert 'workload' in d['config'] and 'model' not in d['config']
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    # each roofline is quoted next to the step time of ITS OWN execution (8.1 ms of conv in a 7.1 ms step)
+    assert r['conv_ms_per_step'] <= r['step_ms_of_this_execution'] * 1.02
+    h = r['headline']
+    assert abs(h['step_ms_of_this_execution'] - d['ms_per_step']) < 1e-3 and 0 < h['frac'] < 1
+    assert abs(h['achieved'] - r['algorithmic_gflop_per_step'] / d['ms_per_step']) < 0.01 * h['achieved']
+    # traffic is either measured on these very kernel sources or withheld
+    assert r['traffic'] is None or 'on these sources' in r['traffic_note']
     return d
 
 
@@ -29,8 +36,7 @@ def test_bench_single_process_line(dev):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check(out.stdout.strip().splitlines()[-1], 4, 1)
-    cb = d['cpu_baseline']
-    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'stereo pairs/s'
+XX
 
 
 def test_bench_under_torch_distributed_run(dev):

@@ -97,3 +97,25 @@ def test_gather_world_size_2_gloo():
         assert p.exitcode == 0
     for _, got in res:
         assert got == list(range(10))      # every rank sees every pair's record exactly once
+
+
+def test_bench_self_launches_n_ranks_dry_run():
+    """`python bench.py --gpus 2` with no RANK in the environment re-executes itself under torch.distributed.run with two ranks
+    (the driver's SCALE command must measure N ranks).  --dry-run: no GPU, gloo, fake records -- the launcher,
+    the env contract, the batched all_gather and the one-JSON-line output are the real ones."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1',
+                          '--gather-every', '2', '--dry-run'], cwd=root, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['dry_run'] is True and d['scaling'] == 'weak'
+    # a single process asked for one GPU stays a single process
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--dry-run'], cwd=root,
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])['n_gpus'] == 1

@@ -37,7 +37,11 @@ for c in sorted(res):
 if len(sys.argv) > 3 and 'FETCH_SIZE' in res and 'WRITE_SIZE' in res:
     import json
     nf, nw = max(res['FETCH_SIZE']['_steps'], 1), max(res['WRITE_SIZE']['_steps'], 1)
-    json.dump({'conv_fetch_size_kb_per_step': res['FETCH_SIZE']['conv engine'] / nf,
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_hash                        # the stamp bench.py checks before it trusts this file
+    json.dump({'csrc_sha256': csrc_hash(),
+               'conv_fetch_size_kb_per_step': res['FETCH_SIZE']['conv engine'] / nf,
                'conv_write_size_kb_per_step': res['WRITE_SIZE']['conv engine'] / nw,
                'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the conv-engine launches of one '
                        'bench step (bench.py --streams 1, plans preloaded); FETCH_SIZE still uncorrected here'},
