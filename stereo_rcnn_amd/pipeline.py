@@ -33,13 +33,16 @@ class _PlainCalib(object):
 
 
 def _solve_task(task):
-    """One solver call in a worker process (plain numpy in, plain numpy out)."""
+    """One solver call (plain numpy in, plain numpy out): scipy (kind 4 / 3; possibly in a worker process) or the native
+    Newton-CG compiled for the host (kind 14 / 13; in-process, ~35 us each)."""
     kind, im_shape, p2, p3, args = task
     calib = _PlainCalib(p2, p3)
-    if kind == 4:
-        status, state = box_estimator.solve_x_y_z_theta_from_kpt(im_shape, calib, *args)
+    if kind in (4, 14):
+        fn = box_estimator.solve_x_y_z_theta_from_kpt if kind == 4 else box_estimator.solve_x_y_z_theta_from_kpt_native
+        status, state = fn(im_shape, calib, *args)
         return status, (np.asarray(state, dtype=np.float64) if status or np.ndim(state) else None)
-    state, z = box_estimator.solve_x_y_theta_from_kpt(im_shape, calib, *args)
+    fn = box_estimator.solve_x_y_theta_from_kpt if kind == 3 else box_estimator.solve_x_y_theta_from_kpt_native
+    state, z = fn(im_shape, calib, *args)
     return np.asarray(state, dtype=np.float64), float(z)
 
 
@@ -202,7 +205,9 @@ def collect_3d(st):
 
 
 # ------------------------------------------------------------------------------------------------ scipy comparison flow
-def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index, dense_align, pool):
+def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index, dense_align, pool,
+                     native=False):
+    k4, k3 = (14, 13) if native else (4, 3)
     with torch.no_grad():
         out = model(im_left_data, im_right_data, im_info)
         det = postprocess.decode_detections(*out[:8], im_info)
@@ -221,7 +226,7 @@ def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shap
     run = pool.map if pool is not None else (lambda tasks: [_solve_task(t) for t in tasks])
     cand = [i for i in range(dets_left.shape[0]) if dets_left[i, -1] > eval_thresh]            # demo.py:282-283
     alphas = [m.atan2(dim_orien[i, 3], dim_orien[i, 4]) for i in cand]
-    res4 = run([(4, tuple(im_shape), calib.p2, calib.p3,
+    res4 = run([(k4, tuple(im_shape), calib.p2, calib.p3,
                  (a, dim_orien[i, 0:3], dets_left[i, 0:4], dets_right[i, 0:4], kpts[i])) for i, a in zip(cand, alphas)])
     solved = []
     for i, alpha, (status, state) in zip(cand, alphas, res4):                                    # demo.py:291-302
@@ -242,7 +247,7 @@ def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shap
     succ, dis_final = align_parallel(calib, _scale32(im_info), im_left_data, im_right_data, boxes, kp, poses)   # demo.py:306-308
     succ, dis_final = check_status(succ.cpu().numpy()), dis_final.cpu().numpy()
     todo = [i for i in range(len(solved)) if succ[i] > 0]                                      # demo.py:311-319
-    res3 = run([(3, tuple(im_shape), calib.p2, calib.p3,
+    res3 = run([(k3, tuple(im_shape), calib.p2, calib.p3,
                  (_alpha32(solved[i]['alpha']), solved[i]['dim'], solved[i]['box_left'], float(dis_final[i]), solved[i]['kpts']))
                 for i in todo])
     for i, (state, z) in zip(todo, res3):
@@ -260,10 +265,12 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
     """One preprocessed pair -> list of dicts (one per solved object, descending score):
     box_left (4), box_right (4), score, dim (w,h,l), alpha, xyz (3), theta, aligned (bool), xyz_init / theta_init (the 4-DoF
     solve), disparity (aligned objects), kpts (5, borders after the inference step).
-    solver: 'device' (default; native Newton-CG kernels, one D2H copy) or 'scipy' (host numpy + scipy, optional `pool`)."""
-    if solver == 'scipy':
+    solver: 'device' (default; native Newton-CG kernels, one D2H copy), 'host' (the reference's host arrangement with the
+    native Newton-CG compiled for the host: end points bit-identical to scipy's on identical arithmetic) or 'scipy' (host
+    numpy + scipy, optional `pool`)."""
+    if solver in ('scipy', 'host'):
         return _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
-                                dense_align, pool)
+                                dense_align, pool if solver == 'scipy' else None, native=(solver == 'host'))
     with torch.no_grad():
         out = model(im_left_data, im_right_data, im_info, slot=slot)
         st = launch_3d(out, im_left_data, im_right_data, im_info, _scale32(im_info), calib, im_shape, eval_thresh,

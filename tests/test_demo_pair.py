@@ -232,7 +232,7 @@ def test_hip_full_flow_on_demo_pair_reports_3d_box_deltas(dev, pair, gold, tmp_p
     print('  final |dz| m              ', np.array2string(rows[:, 3], precision=1, max_line_width=200))
     # what is well defined: where the 4-DoF end point is reproduced the alignment searches the same grid and the
     # final box follows; elsewhere the photometric search still brackets the same minimum for most objects
-    same = rows[:, 0] < 1e-3
+    same = rows[:, 0] < 1e-6
     if same.any():
         assert rows[same, 1].max() < 2e-3 and np.median(rows[same, 2]) < 1e-3
     assert np.median(rows[:, 1]) < 0.6          # one coarse depth step of the enumeration at most, typically
