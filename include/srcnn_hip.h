@@ -267,7 +267,10 @@ SRCNN_API int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im
  * newton_status (may be NULL): scipy's OptimizeResult.status (0 ok, 1 maxiter, 2 line search, 3 CG / NaN), -1 = early-out. */
 SRCNN_API int srcnn_solve_4dof_host(int im_h, int im_w, double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03,
                           double alpha, const double *dim3, const double *box_left4, const double *box_right4,
-                          const double *kpts5, double *state4, int *newton_status);   /* returns status 0 / 1 */
+                          const double *kpts5, double *state4, int *newton_status,
+                          int boxes_are_float32 /* the boxes hold float32 values the reference's numpy evaluates in float32
+                                                   (box-size early-outs, start disparity); the device kernels always do */);
+                          /* returns status 0 / 1 */
 SRCNN_API int srcnn_solve_3dof_host(int im_h, int im_w, double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03,
                           double alpha, const double *dim3, const double *box_left4, double disparity,
                           const double *kpts5, double *state3, double *z, int *newton_status);

@@ -84,7 +84,7 @@ _SIGNATURES = {
     "srcnn_solve_3dof": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
     "srcnn_solve_4dof_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "srcnn_solve_3dof_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
                                       c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srcnn_solver_evaluate_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p,

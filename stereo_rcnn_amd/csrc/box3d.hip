@@ -28,7 +28,7 @@ __global__ void infer_boundary_kernel(float *__restrict__ rec, int n, int cols, 
         for (int i = 0; i < k; ++i) {
             const float *b = rec + (size_t)(1 + i) * cols + C_BOXL;
             if (col < (int)b[0] || col > (int)b[2]) continue;
-            const double depth = 1050.0 / (double)b[3];
+            const double depth = (double)(1050.0f / b[3]);     // Python float / np.float32 -> float32 (as run for the goldens)
             if (pixel == 0.0) pixel = depth;
             else if (depth < pixel) pixel = (depth + pixel) / 2.0;
         }
@@ -38,7 +38,7 @@ __global__ void infer_boundary_kernel(float *__restrict__ rec, int n, int cols, 
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         float *row = rec + (size_t)(1 + i) * cols;
         const float *b = row + C_BOXL;
-        const double d = 1050.0 / (double)b[3];
+        const double d = (double)(1050.0f / b[3]);
         const int x1 = min(max((int)b[0], 0), im_w), x2 = min(max((int)b[2], 0), im_w);
         float left = b[0], right = b[2];
         const bool left_visible = !(line[x1] < d), right_visible = !(line[x2] < d);
@@ -85,7 +85,7 @@ __global__ void solve4_kernel(float *__restrict__ rec, int n, int cols, Calib c,
     load5(row + C_KPT, kp);
     const double alpha = atan2((double)row[C_SIN], (double)row[C_COS]);          // demo.py:288-290
     double st[4];
-    const int status = solve_4dof(c.im_h, c.im_w, c.f, c.cx, c.cy, c.base, alpha, dim, bl, br, kp, st, nullptr);
+    const int status = solve_4dof(c.im_h, c.im_w, c.f, c.cx, c.cy, c.base, alpha, dim, bl, br, kp, st, nullptr, true);
     for (int q = 0; q < 4; ++q) out[q] = st[q];
     row[C_ST4] = (float)status;
     for (int q = 0; q < 4; ++q) row[C_POSE4 + q] = (float)st[q];                  // poses[0..2], poses[6]
@@ -211,13 +211,13 @@ int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im_w, double
 // ---- the same solvers for host callers (no GPU involved): box_estimator.solve_* signatures flattened
 int srcnn_solve_4dof_host(int im_h, int im_w, double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03, double alpha,
                           const double *dim3, const double *box_left4, const double *box_right4, const double *kpts5,
-                          double *state4, int *newton_status)
+                          double *state4, int *newton_status, int boxes_are_float32)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(dim3 && box_left4 && box_right4 && kpts5 && state4, "null pointer");
     const Calib c = make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03);
     return boxsolve::solve_4dof(im_h, im_w, c.f, c.cx, c.cy, c.base, alpha, dim3, box_left4, box_right4, kpts5, state4,
-                                newton_status) ? 1 : 0;
+                                newton_status, boxes_are_float32 != 0) ? 1 : 0;
 }
 
 int srcnn_solve_3dof_host(int im_h, int im_w, double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03, double alpha,

@@ -73,9 +73,12 @@ SRCNN_HD void side_vertices(int view_point, double w, double l, double *vw, doub
 }
 
 // box_estimator.py:150-167
-SRCNN_HD double kpt2alpha(double kpt_pos, int kpt_type, double box0, double box2)
+// box_f32: `box` is a numpy float32 row and kpt_pos a Python float -- numpy (NEP 50, as executed where the goldens were made)
+// keeps the whole quotient in float32
+SRCNN_HD double kpt2alpha(double kpt_pos, int kpt_type, double box0, double box2, bool box_f32 = false)
 {
     double ratio = (kpt_pos - box0) / (box2 - box0);
+    if (box_f32) ratio = (double)(((float)kpt_pos - (float)box0) / ((float)box2 - (float)box0));
     ratio = ratio < 1 ? ratio : 1;         // min(1, .)
     ratio = ratio > -1 ? ratio : -1;       // max(., -1)
     const double base = kpt_type == 0 ? -kPi / 2 : (kpt_type == 1 ? kPi : (kpt_type == 2 ? kPi / 2 : 0.0));
@@ -85,7 +88,7 @@ SRCNN_HD double kpt2alpha(double kpt_pos, int kpt_type, double box0, double box2
 // Shared by both solvers (box_estimator.py:188-260 and :402-470).  box_right == nullptr: the 3-DoF problem.
 // im_h / im_w: original image size; p2_00 = f, p2_02 = cx, p2_12 = cy, base = (P2[0,3] - P3[0,3]) / f.
 SRCNN_HD void setup(Problem &t, int im_h, int im_w, double f, double cx, double cy, double base, double alpha, const double *dim,
-                    const double *box_left, const double *box_right, const double *kpts)
+                    const double *box_left, const double *box_right, const double *kpts, bool boxes_f32 = false)
 {
     const double TB = 10;     // truncate_border
     t.h = dim[1];
@@ -103,7 +106,7 @@ SRCNN_HD void setup(Problem &t, int im_h, int im_w, double f, double cx, double 
     t.obs[5] = (vb - cy) / f;
     t.obs[6] = (vt - cy) / f;
     t.truncation = ul < 2.0 * TB || ur > im_w - 2.0 * TB;
-    if (!t.truncation) alpha = kpt2alpha(kpt_pos, kpt_type, box_left[0], box_left[2]);
+    if (!t.truncation) alpha = kpt2alpha(kpt_pos, kpt_type, box_left[0], box_left[2], boxes_f32);
     t.alpha = alpha;
     side_vertices(bb2viewpoint(alpha), w, l, t.vw, t.vl);
     const int kw[4] = {-1, -1, 1, 1}, kl[4] = {-1, 1, 1, -1};       // box_estimator.py:138-146
@@ -626,15 +629,29 @@ SRCNN_HD int newton_cg(const Problem &t, double *xk, int *iterations = nullptr)
 
 // ------------------------------------------------------------------------------------------------ the two entry points
 // solve_x_y_z_theta_from_kpt (box_estimator.py:169-385).  Returns status (0 failed, 1 normal); state = (x, y, z, theta).
+// boxes_f32: box_left / box_right hold float32 values and are numpy float32 arrays in the caller being mirrored (demo.py:284-285
+// passes `.cpu().numpy()` rows): numpy then evaluates the box-size tests (:186), the start disparity (:374) and the keypoint
+// ratio of kpt2alpha (:160) in FLOAT32 arithmetic, everything else is promoted to double by the float64 calibration entries.
+// kpts is a torch tensor row there (Python floats) and dim only enters through products with doubles.
 SRCNN_HD int solve_4dof(int im_h, int im_w, double f, double cx, double cy, double base, double alpha, const double *dim,
-                        const double *box_left, const double *box_right, const double *kpts, double *state, int *newton_status)
+                        const double *box_left, const double *box_right, const double *kpts, double *state, int *newton_status,
+                        bool boxes_f32 = false)
 {
     state[0] = state[1] = state[2] = state[3] = 0;
     if (newton_status) *newton_status = -1;
-    if (kpts[4] - kpts[3] < 3 || box_left[2] - box_left[0] < 10 || box_left[3] - box_left[1] < 10) return 0;     // :186-187
+    double bw = box_left[2] - box_left[0], bh = box_left[3] - box_left[1];
+    double disparity = (box_left[0] + box_left[2]) / 2 - (box_right[0] + box_right[2]) / 2;
+    if (boxes_f32) {
+        const float l0 = (float)box_left[0], l1 = (float)box_left[1], l2 = (float)box_left[2], l3 = (float)box_left[3];
+        const float r0 = (float)box_right[0], r2 = (float)box_right[2];
+        bw = (double)(l2 - l0);
+        bh = (double)(l3 - l1);
+        const float sl = (l0 + l2) / 2, sr = (r0 + r2) / 2;
+        disparity = (double)(sl - sr);
+    }
+    if (kpts[4] - kpts[3] < 3 || bw < 10 || bh < 10) return 0;                                                   // :186-187
     Problem t;
-    setup(t, im_h, im_w, f, cx, cy, base, alpha, dim, box_left, box_right, kpts);
-    const double disparity = (box_left[0] + box_left[2]) / 2 - (box_right[0] + box_right[2]) / 2;
+    setup(t, im_h, im_w, f, cx, cy, base, alpha, dim, box_left, box_right, kpts, boxes_f32);
     const double init_z = t.f * t.bl / disparity;
     const double init_x = init_z * (t.obs[0] + t.obs[1]) / 2.0;
     const double init_y = init_z * (t.obs[5] + t.obs[6]) / 2.0 + t.h / 2.0;

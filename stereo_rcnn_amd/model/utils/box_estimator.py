@@ -198,8 +198,11 @@ def solve_x_y_z_theta_from_kpt_native(im_shape, calib, alpha, dim, box_left, box
     import ctypes
     from ... import _lib
     state, ns = (ctypes.c_double * 4)(), ctypes.c_int(0)
+    # numpy float32 box rows (what demo.py:284-285 hands over) get numpy's float32 arithmetic for the box-size tests and
+    # the start disparity, exactly as `solve_x_y_z_theta_from_kpt` above would evaluate them
+    f32 = int(getattr(box_left, 'dtype', None) == np.float32 and getattr(box_right, 'dtype', None) == np.float32)
     status = _lib.lib().srcnn_solve_4dof_host(int(im_shape[0]), int(im_shape[1]), *_calib_args(calib), float(alpha), _dbl(dim, 3),
-                                              _dbl(box_left, 4), _dbl(box_right, 4), _dbl(kpts, 5), state, ctypes.byref(ns))
+                                              _dbl(box_left, 4), _dbl(box_right, 4), _dbl(kpts, 5), state, ctypes.byref(ns), f32)
     if ns.value == -1:                      # the early-out of :186-187 returns (0, 0)
         return (0, 0, -1) if return_status else (0, 0)
     out = np.array(list(state), dtype=np.float64)

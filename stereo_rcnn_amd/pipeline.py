@@ -52,6 +52,12 @@ def _alpha32(alpha):
     return float(np.float32(alpha))
 
 
+def _f64(row):
+    """The 3-DoF call takes rows of torch tensors in the reference (demo.py:312-318: boxes_all / kpts_all slices), whose elements
+    are Python floats under torch 0.3: all arithmetic on them is double, unlike the numpy float32 rows of the 4-DoF call."""
+    return np.asarray(row, dtype=np.float64)
+
+
 def _scale32(im_info):
     """im_info[0, 2] as the reference reads it: a float32 tensor element turned into a Python float."""
     return float(im_info.view(-1, 3)[0, 2])
@@ -248,7 +254,8 @@ def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shap
     succ, dis_final = check_status(succ.cpu().numpy()), dis_final.cpu().numpy()
     todo = [i for i in range(len(solved)) if succ[i] > 0]                                      # demo.py:311-319
     res3 = run([(k3, tuple(im_shape), calib.p2, calib.p3,
-                 (_alpha32(solved[i]['alpha']), solved[i]['dim'], solved[i]['box_left'], float(dis_final[i]), solved[i]['kpts']))
+                 (_alpha32(solved[i]['alpha']), solved[i]['dim'], _f64(solved[i]['box_left']), float(dis_final[i]),
+                  _f64(solved[i]['kpts'])))
                 for i in todo])
     for i, (state, z) in zip(todo, res3):
         o = solved[i]
@@ -407,8 +414,8 @@ def _detect_3d_stream_scipy(model, frames, pool, eval_thresh, class_index, dense
             succ, dis = check_status(p.succ_host.numpy()), p.dis_host.numpy()
             p.todo = [i for i in range(len(p.solved)) if succ[i] > 0]
             p.pending = pool.submit([(3, tuple(im_shape), calib.p2, calib.p3,
-                                      (_alpha32(p.solved[i]['alpha']), p.solved[i]['dim'], p.solved[i]['box_left'], float(dis[i]),
-                                       p.solved[i]['kpts'])) for i in p.todo])
+                                      (_alpha32(p.solved[i]['alpha']), p.solved[i]['dim'], _f64(p.solved[i]['box_left']),
+                                       float(dis[i]), _f64(p.solved[i]['kpts']))) for i in p.todo])
             p.stage = 4
         elif p.stage == 4:                                     # rectified poses
             dis = p.dis_host.numpy()

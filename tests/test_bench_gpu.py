@@ -36,7 +36,7 @@ def test_bench_single_process_line(dev):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check(out.stdout.strip().splitlines()[-1], 4, 1)
-XX
+
 
 
 def test_bench_under_torch_distributed_run(dev):

@@ -156,6 +156,27 @@ def test_native_solver_vs_scipy_path_as_shipped():
     assert np.mean(same4) >= 0.90 and np.mean(same3) >= 0.95
 
 
+def test_native_solver_with_float32_rows_as_the_pipeline_passes_them():
+    """demo.py:284-293 hands box_left / box_right / dim to the solver as numpy float32 rows: numpy then evaluates the start
+    disparity (and the box-size tests) in float32.  The native solver mirrors that (boxes_are_float32), so that on the rows
+    the detector produces it starts from the same point as the scipy path -- bit-identical end points for the bulk."""
+    rng = np.random.default_rng(9)
+    same, n = 0, 0
+    for _ in range(120):
+        calib, pose, dim, bl, br, kp, alpha = _case(rng)
+        f = lambda v: np.asarray(v, np.float32)
+        bl, br, dim, kp = f(bl), f(br), f(dim), f(kp)
+        s_ref, b = pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+        s_nat, a = pbe.solve_x_y_z_theta_from_kpt_native(IM_SHAPE, calib, alpha, dim, bl, br, kp)
+        assert s_ref == s_nat
+        if np.ndim(b) == 0:
+            continue
+        n += 1
+        same += np.array_equal(np.asarray(a), np.asarray(b))
+        # the float64 form of the same rows starts elsewhere (by a float32 rounding of the disparity)
+    assert n >= 100 and same >= 0.9 * n, (same, n)
+
+
 def test_native_early_outs_and_status():
     calib = KITTI_DEMO_CALIB
     assert pbe.solve_x_y_z_theta_from_kpt_native(IM_SHAPE, calib, 0.0, (1.6, 1.5, 4.0), [100, 100, 105, 160], [90, 100, 95, 160],
