@@ -298,7 +298,7 @@ def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, 
     return collect_3d(st) if wait else st
 
 
-def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=3, solver='device'):
+def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=2, solver='device'):
     """Generator form for a sequence of pairs: yields one object list per frame, in order, with up to `slots` pairs in flight
     on their own HIP streams.  frames: iterable of (im_left_data, im_right_data, im_info, calib, im_shape[, scale]) with device
     tensors, or (img_left_u8, img_right_u8, calib) with uint8 device images (fused preprocessing).  Per pair the results are

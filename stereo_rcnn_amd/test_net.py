@@ -37,7 +37,7 @@ def read_png_rgb(path):
 
 
 def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4,
-              solver='device', slots=3):
+              solver='device', slots=2):
     """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds).
     Frames go through pipeline.detect_3d_stream: PNG decoding runs `prefetch` frames ahead on host threads, the decoded
     uint8 images are copied to the device and everything else -- preprocessing, forward, decode, NMS, borders, 4-DoF solve,
