@@ -136,6 +136,25 @@ typedef struct srcnn_conv_desc {
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
 
+/* Fused tail of a ResNet bottleneck (resnet.py:82-101): y = relu(bn3(conv3(relu(bn2(conv2(x))))) + residual) in one launch
+ * -- conv2 3x3 / stride 1 / pad 1 (C -> C), conv3 1x1 (C -> 4C), frozen BN folded by the caller as for srcnn_conv2d.
+ * f16x3 engine only (precision 1 arithmetic, bit-for-bit the accumulation order of the stand-alone kernel's 8-wave
+ * 32x64-per-wave plans), every activation in SRCNN_FMT_SPLIT16: x (B,H,W,C), residual and y (B,H,W,4C), dense channel
+ * strides.  The C-channel intermediate stays in LDS.  C in {64, 128, 256} (layer1..3). */
+typedef struct srcnn_block_desc {
+    const void *x;
+    const void *w2_hi, *w2_lo;   /* (C, 3, 3, C) _Float16 halves of w2 * 2^k2 */
+    const float *bias2;          /* (C) */
+    float w2_inv_scale;          /* 2^-k2 */
+    const void *w3_hi, *w3_lo;   /* (4C, 1, 1, C) */
+    const float *bias3;          /* (4C) */
+    float w3_inv_scale;
+    const void *residual;
+    void *y;
+    int B, H, W, C;
+} srcnn_block_desc;
+SRCNN_API int srcnn_conv_block(const srcnn_block_desc *d, srcnn_stream_t stream);
+
 /* A0 preprocessing (demo.py:103-129, blob.py:39-64): uint8 RGB (H,W,3) on the device -> BGR, PIXEL_MEANS subtracted
  * (in double, stored float32, as numpy's float32 -= float64), then cv2.resize(img, None, None, fx=scale, fy=scale,
  * INTER_LINEAR) restated operation by operation from OpenCV's float path (oracle/preprocess.py cites it): bit-equal

@@ -234,6 +234,25 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")
 
 
+FUSE_BLOCKS = True      # f16x3 engine: conv2 + conv3 (+ residual) of the identity bottlenecks as one launch (csrc/conv_block.hip)
+
+
+def conv_block(conv2, conv3, x, B, H, W, y, residual):
+    """Fused bottleneck tail (srcnn_conv_block): y = relu(conv3(relu(conv2(x))) + residual), SPLIT16 activations."""
+    assert conv2.kh == 3 and conv2.stride == 1 and conv2.pad == 1 and conv3.kh == 1 and conv3.cout == 4 * conv2.cout
+    conv2.split_f16x3()
+    conv3.split_f16x3()
+    d = _lib.BlockDesc()
+    d.x, d.residual, d.y = x.data_ptr(), residual.data_ptr(), y.data_ptr()
+    d.w2_hi, d.w2_lo, d.bias2, d.w2_inv_scale = conv2.w_hi.data_ptr(), conv2.w_lo.data_ptr(), conv2.bias.data_ptr(), conv2.inv_scale
+    d.w3_hi, d.w3_lo, d.bias3, d.w3_inv_scale = conv3.w_hi.data_ptr(), conv3.w_lo.data_ptr(), conv3.bias.data_ptr(), conv3.inv_scale
+    d.B, d.H, d.W, d.C = B, H, W, conv2.cout
+    if FlopCounter.enabled:
+        FlopCounter.flops += 2.0 * B * H * W * (conv2.cout * conv2.alg_k + conv3.cout * conv3.alg_k)
+        FlopCounter.launches += 1
+    _lib.check(_lib.lib().srcnn_conv_block(ctypes.byref(d), _lib.stream()), "srcnn_conv_block")
+
+
 def preprocess_size(H, W, target_short=600):
     """(OH, OW, im_scale) of the reference's resize: im_scale = target / short side (demo.py:113-114), output size as
     cv2.resize derives it from fx/fy: cvRound(H*s), cvRound(W*s) -- Python's round() is the same ties-to-even."""

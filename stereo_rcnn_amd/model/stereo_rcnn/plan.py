@@ -147,6 +147,7 @@ class Plan(object):
         self.left_prob = e(R, G)
         self.right_prob = e(R, G)
         self.graphs = {}
+        self.fuse_channels = (64, 128, 256)     # bottleneck widths whose conv2 + conv3 run fused (engine.FUSE_BLOCKS)
         self.packed_fmt = -1    # format `packed` currently holds for the inputs of the NEXT run (-1: none, pack in trunk())
         self.fmt = 0            # activation format of the internal buffers for the current/last run
         # independent branches of the forward (FPN laterals, small RPN levels, box head vs keypoint head) are
@@ -175,6 +176,17 @@ class Plan(object):
             cur, nxt = bufs['a'], bufs['b']
             for bi, blk in enumerate(blocks):
                 engine.conv2d(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, x_fmt=f, y_fmt=f)
+                if f and engine.FUSE_BLOCKS and blk['conv2'].cout in self.fuse_channels:
+                    # conv2 + conv3 (+ residual, ReLU) in one launch: the C-channel map stays in LDS (csrc/conv_block.hip)
+                    if blk['down'] is not None:
+                        engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f)
+                        res = nxt
+                    else:
+                        res = x
+                    engine.conv_block(blk['conv2'], blk['conv3'], bufs['m1'], N, h, w_, cur, res)
+                    x, xh, xw = cur, h, w_
+                    cur, nxt = nxt, cur
+                    continue
                 engine.conv2d(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, x_fmt=f, y_fmt=f)
                 if blk['down'] is not None:
                     engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f)
