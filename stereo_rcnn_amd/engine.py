@@ -191,7 +191,7 @@ def _tune(d, key, device):
 
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
-           res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0):
+           res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
     *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h)."""
     L = _lib.lib()
@@ -220,7 +220,9 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
-    if AUTOTUNE:
+    if plan is not None:                   # explicit (tile_mr, tile_nr, waves, stages, splits): tests and tools
+        _set_plan(d, plan)
+    elif AUTOTUNE:
         key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt))
         plan = _TUNED.get(key)
         if plan is None:
