@@ -16,6 +16,7 @@
 // unit of the SPLIT16 format and of the MFMA operand rows: no LDS transpose in either epilogue.
 // 8 wavefronts per workgroup (BM/32 x C/64), per-wave tile 32 pixels x 64 channels.
 #include "conv_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace srcnn {
@@ -34,6 +35,9 @@ struct BlockArgs {
     float os2, os3;                // 2^-k2, 2^-k3
     int H, W, M;                   // M = B * H * W
     int mtiles;
+    int flags;                     // debug: bit 0 count the epilogue stores in the vmcnt budget, bit 1 skip the residual
+                                   // loads, bit 2 skip the stores (timing experiments only; SRCNN_BLK_FLAGS)
+    unsigned long long *stamp;     // debug: 8 x u64 per workgroup (100 MHz chip clock), normally nullptr
 };
 
 __device__ __forceinline__ void blk_dma16(const void *gsrc, _Float16 *lds_wave_base)
@@ -89,7 +93,7 @@ struct BlockCfg {
     static_assert(LDS <= 163840, "LDS budget");
 };
 
-template <int CM>
+template <int CM, bool PB1, bool PB2>
 __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
 {
     using C = BlockCfg<CM>;
@@ -100,6 +104,9 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
     constexpr int NST = 8;                                                       // 16-byte stores per lane per chunk epilogue
 
     const int t = threadIdx.x;
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (p.stamp) ts[0] = __builtin_amdgcn_s_memrealtime();
+    const int count_stores = (p.flags & 1) ? NST : 0;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const int wm = wave / WNG, wn = wave % WNG;
     const int li = lane & 31, lg = lane >> 5;
@@ -244,15 +251,19 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
     // next() = advance the source cursors to the following tile, aptr(tile, stage) = (base, panel distance) of the activation
     // panels of a tile, bofs = offset of the weight panels inside a stage, after(tile) = hook behind a tile's last MFMA
     // (returns true when it issued NST stores).  Schedule (per K tile, all waves in lockstep through one barrier):
-    //   phase A: MFMAs of slice 0, slice 1 fetched from LDS behind the first three, the DMA pieces of tile t + NS - 1 pinned
-    //            one behind each of the others;  wait for tile t + 1 only (counted vmcnt), barrier;
+    //   phase A: MFMAs of slice 0, slice 1 fetched from LDS behind the first three;  wait for tile t + 1 only (counted
+    //            vmcnt), barrier;
     //   phase B: MFMAs of slice 1, slice 0 of tile t + 1 fetched behind them.
-    auto run = [&](auto ns_c, auto lpt_c, int nk, _Float16 *ring, int stage_halves, int bofs, auto &&issue, auto &&next,
+    // The DMA pieces of the tile being prefetched are pinned one behind each MFMA of phase A (PB = false: tile t + NS - 1 into
+    // the stage tile t - 1 left, NS - 1 tiles in flight) or of phase B (PB = true: tile t + NS into the stage tile t has just
+    // left, NS tiles in flight -- what a shallow ring needs).
+    auto run = [&](auto ns_c, auto lpt_c, auto pb_c, int nk, _Float16 *ring, int stage_halves, int bofs, auto &&issue, auto &&next,
                    auto &&aptr, auto &&after) {
         constexpr int NS = decltype(ns_c)::value, LPT = decltype(lpt_c)::value;
+        constexpr bool PB = decltype(pb_c)::value;
         int issued = 0;                       // tiles issued so far
         int store_mark = -1;                  // last tile issued BEFORE the most recent epilogue stores (-1: none pending)
-        const int pre = min(NS - 1, nk);
+        const int pre = min(PB ? NS : NS - 1, nk);
         for (int i = 0; i < pre; ++i) {
 #pragma unroll
             for (int pc = 0; pc < LPT; ++pc) issue(pc, ring + i * stage_halves);
@@ -269,13 +280,14 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
             for (int r = 0; r < 6; ++r) read_piece(f0, ab, ap, ring + bofs, 0, r);
         }
         int cs = 0, ls = NS - 1;
-        for (int tt = 0; tt < nk; ++tt) {
+        int tt = 0;
+        auto tile = [&](auto dma_c, auto next_c) {
+            constexpr bool DMA = decltype(dma_c)::value, NEXT = decltype(next_c)::value;
             const _Float16 *cbase = ring + cs * stage_halves;
-            _Float16 *lbase = ring + ls * stage_halves;
+            _Float16 *lbase = ring + (PB ? cs : ls) * stage_halves;
             const _Float16 *ab;
             int ap;
             aptr(tt, cbase, ab, ap);
-            const bool do_dma = issued < nk;
             mfma_slice(f0, [&](int m) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                         read_piece(f1, ab, ap, cbase + bofs, 1, r);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                if (do_dma) {
+                if (DMA && !PB) {
 #pragma unroll
                     for (int pc = 0; pc < LPT; ++pc)
                         if (1 + pc * 5 / LPT == m) {
@@ -294,16 +306,16 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                         }
                 }
             });
-            if (do_dma) {
+            if (DMA && !PB) {
                 next();
                 ++issued;
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): slice 1 is in registers
             // tile tt + 1 must have landed: everything issued after it may stay in flight
             int allow = 0;
-            if (tt + 1 < nk) {
+            if (NEXT) {
                 allow = (issued - 1 - (tt + 1)) * LPT;
-                if (tt + 1 <= store_mark) allow += NST;           // the epilogue stores were issued after that tile
+                if (tt + 1 <= store_mark) allow += count_stores;  // the epilogue stores were issued after that tile
             }
             blk_wait_barrier(allow);
             ls = (ls + 1 == NS) ? 0 : ls + 1;
@@ -311,11 +323,10 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
             const _Float16 *nbase = ring + cs * stage_halves;
             const _Float16 *nab = nullptr;
             int nap = 0;
-            const bool has_next = tt + 1 < nk;
-            if (has_next) aptr(tt + 1, nbase, nab, nap);
+            if (NEXT) aptr(tt + 1, nbase, nab, nap);
             __builtin_amdgcn_sched_barrier(0);
             mfma_slice(f1, [&](int m) {
-                if (has_next) {
+                if (NEXT) {
 #pragma unroll
                     for (int r = 0; r < 6; ++r)
                         if (r / 2 == m) {
@@ -324,9 +335,26 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                             __builtin_amdgcn_sched_barrier(0);
                         }
                 }
+                if (DMA && PB) {
+#pragma unroll
+                    for (int pc = 0; pc < LPT; ++pc)
+                        if (1 + pc * 5 / LPT == m) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue(pc, lbase);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
             });
+            if (DMA && PB) {
+                next();
+                ++issued;
+            }
             if (after(tt)) store_mark = issued - 1;
-        }
+            ++tt;
+        };
+        while (issued < nk) tile(std::true_type{}, std::true_type{});          // steady state: a tile is prefetched every tile
+        while (tt + 1 < nk) tile(std::false_type{}, std::true_type{});         // drain
+        if (tt < nk) tile(std::false_type{}, std::false_type{});               // last tile: nothing to fetch for
     };
 
     // ------------------------------------------------------------------ epilogue helpers
@@ -357,8 +385,10 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
         auto next = [&]() { advance1(); };
         auto aptr = [&](int, const _Float16 *stage, const _Float16 *&ab, int &ap) { ab = stage; ap = PANEL_A; };
         auto after = [&](int) { return false; };
-        run(std::integral_constant<int, C::NS1>{}, std::integral_constant<int, C::LPT1>{}, K2T, blk_smem, C::STAGE1, 2 * PANEL_A,
-            issue, next, aptr, after);
+        if (p.stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
+        run(std::integral_constant<int, C::NS1>{}, std::integral_constant<int, C::LPT1>{}, std::integral_constant<bool, PB1>{}, K2T,
+            blk_smem, C::STAGE1, 2 * PANEL_A, issue, next, aptr, after);
+        if (p.stamp) ts[2] = __builtin_amdgcn_s_memrealtime();
     }
     // every wave is past the last barrier: nobody reads the ring any more.  Start the weight stream of conv3 (ring behind the
     // resident operand), then turn the accumulators into that operand.
@@ -415,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
             }
         }
         zero_acc();
+        if (p.stamp) ts[3] = __builtin_amdgcn_s_memrealtime();
     }
     // ================================================================== phase 2: conv3 (1x1) + residual + ReLU
     {
@@ -428,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
         auto after = [&](int tile) {
             if (tile % KT2 != KT2 - 1) return false;
             const int nc = tile / KT2;
+            const unsigned long long te0 = p.stamp ? __builtin_amdgcn_s_memrealtime() : 0;
             const int chb = nc * CM + wn * 64;                     // first channel of this wave in the chunk
             // residual groups first (4 x 32 B per lane), then the arithmetic
             uint4 rh[2][2], rl[2][2];
@@ -437,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                 for (int pp = 0; pp < 2; ++pp) {
                     rh[j][pp] = make_uint4(0, 0, 0, 0);
                     rl[j][pp] = make_uint4(0, 0, 0, 0);
-                    if (pix_ok) {
+                    if (pix_ok && !(p.flags & 2)) {
                         const char *q = reinterpret_cast<const char *>(p.res) + row_off + (size_t)(chb + j * 32 + (2 * pp + lg) * 8) * 4;
                         rh[j][pp] = *reinterpret_cast<const uint4 *>(q);
                         rl[j][pp] = *reinterpret_cast<const uint4 *>(q + 16);
@@ -458,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                         hi[e] = (_Float16)x;
                         lo[e] = (_Float16)(x - (float)hi[e]);
                     }
-                    if (pix_ok) {
+                    if (pix_ok && !(p.flags & 4)) {
                         char *q = reinterpret_cast<char *>(p.y) + row_off + (size_t)(chb + j * 32 + (2 * pp + lg) * 8) * 4;
                         *reinterpret_cast<half8 *>(q) = hi;
                         *reinterpret_cast<half8 *>(q + 16) = lo;
@@ -466,24 +498,42 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                 }
             }
             zero_acc();
+            if (p.stamp) ts[5] += __builtin_amdgcn_s_memrealtime() - te0;
             return true;
         };
-        run(std::integral_constant<int, C::NS2>{}, std::integral_constant<int, C::LPT2>{}, 4 * KT2, ring2, C::STAGE2, 0, issue2, next2,
-            aptr, after);
+        run(std::integral_constant<int, C::NS2>{}, std::integral_constant<int, C::LPT2>{}, std::integral_constant<bool, PB2>{}, 4 * KT2,
+            ring2, C::STAGE2, 0, issue2, next2, aptr, after);
+    }
+    if (p.stamp && t == 0) {
+        ts[4] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *o = p.stamp + 8 * (size_t)blockIdx.x;
+        for (int i = 0; i < 6; ++i) o[i] = ts[i];
+        o[6] = 1;
     }
 }
 
-template <int CM>
-static void launch_block(const BlockArgs &a, hipStream_t st)
+template <int CM, bool PB1, bool PB2>
+static void launch_block_v(const BlockArgs &a, hipStream_t st)
 {
     static bool configured = false;
-    auto *k = conv_block_kernel<CM>;
+    auto *k = conv_block_kernel<CM, PB1, PB2>;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)BlockCfg<CM>::LDS);
         configured = true;
     }
     hipLaunchKernelGGL(k, dim3(a.mtiles), dim3(512), BlockCfg<CM>::LDS, st, a);
+}
+
+template <int CM>
+static void launch_block(const BlockArgs &a, int variant, hipStream_t st)
+{
+    switch (variant & 3) {
+    case 0: launch_block_v<CM, false, false>(a, st); break;
+    case 1: launch_block_v<CM, true, false>(a, st); break;
+    case 2: launch_block_v<CM, false, true>(a, st); break;
+    default: launch_block_v<CM, true, true>(a, st); break;
+    }
 }
 
 }  // namespace srcnn
@@ -511,9 +561,14 @@ int srcnn_conv_block(const srcnn_block_desc *d, srcnn_stream_t stream)
     hipStream_t st = as_stream(stream);
     const bool prof = prof_enabled();
     if (prof) prof_begin(st);
-    if (d->C == 64) launch_block<64>(a, st);
-    else if (d->C == 128) launch_block<128>(a, st);
-    else launch_block<256>(a, st);
+    // debug / tuning knobs (read once): SRCNN_BLK_FLAGS = kernel flags, SRCNN_BLK_VARIANT = bit 0 PB schedule in phase 1, bit 1 in phase 2
+    static const int env_flags = getenv("SRCNN_BLK_FLAGS") ? atoi(getenv("SRCNN_BLK_FLAGS")) : 1;
+    static const int env_variant = getenv("SRCNN_BLK_VARIANT") ? atoi(getenv("SRCNN_BLK_VARIANT")) : 2;
+    a.flags = env_flags;
+    a.stamp = debug_stamp_buffer();
+    if (d->C == 64) launch_block<64>(a, env_variant, st);
+    else if (d->C == 128) launch_block<128>(a, env_variant, st);
+    else launch_block<256>(a, env_variant, st);
     if (prof) prof_end(st, 2.0 * (double)a.M * (double)d->C * (9.0 * d->C + 4.0 * d->C));
     return check_launch("srcnn_conv_block");
 }
