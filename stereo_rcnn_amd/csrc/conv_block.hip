@@ -263,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
         constexpr bool PB = decltype(pb_c)::value;
         int issued = 0;                       // tiles issued so far
         int store_mark = -1;                  // last tile issued BEFORE the most recent epilogue stores (-1: none pending)
+        int load_mark = -1;                   // ... before the most recent residual prefetch (8 loads per lane)
         const int pre = min(PB ? NS : NS - 1, nk);
         for (int i = 0; i < pre; ++i) {
 #pragma unroll
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
             if (NEXT) {
                 allow = (issued - 1 - (tt + 1)) * LPT;
                 if (tt + 1 <= store_mark) allow += count_stores;  // the epilogue stores were issued after that tile
+                if (tt + 1 <= load_mark) allow += 8;              // so was the residual prefetch
             }
             blk_wait_barrier(allow);
             ls = (ls + 1 == NS) ? 0 : ls + 1;
@@ -349,7 +351,9 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                 next();
                 ++issued;
             }
-            if (after(tt)) store_mark = issued - 1;
+            const int did = after(tt);            // bit 0: NST stores issued, bit 1: 8 residual loads issued
+            if (did & 1) store_mark = issued - 1;
+            if (did & 2) load_mark = issued - 1;
             ++tt;
         };
         while (issued < nk) tile(std::true_type{}, std::true_type{});          // steady state: a tile is prefetched every tile
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
         auto issue = [&](int pc, _Float16 *sb) { dma1(pc, sb); };
         auto next = [&]() { advance1(); };
         auto aptr = [&](int, const _Float16 *stage, const _Float16 *&ab, int &ap) { ab = stage; ap = PANEL_A; };
-        auto after = [&](int) { return false; };
+        auto after = [&](int) { return 0; };
         if (p.stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
         run(std::integral_constant<int, C::NS1>{}, std::integral_constant<int, C::LPT1>{}, std::integral_constant<bool, PB1>{}, K2T,
             blk_smem, C::STAGE1, 2 * PANEL_A, issue, next, aptr, after);
@@ -456,25 +460,35 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
             ab = blk_smem + (size_t)(tile % KT2) * 2 * PANEL_A;
             ap = PANEL_A;
         };
+        // residual groups of a chunk (4 x 32 B per lane) are requested PF K tiles before the chunk's last MFMA, so that their
+        // latency (L2 / MALL: ~2 us, exposed 4x per workgroup otherwise) runs behind the matrix pipe
+        constexpr int PF = KT2 >= 4 ? 3 : 1;
+        uint4 rh[2][2], rl[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                rh[j][pp] = make_uint4(0, 0, 0, 0);
+                rl[j][pp] = make_uint4(0, 0, 0, 0);
+            }
         auto after = [&](int tile) {
-            if (tile % KT2 != KT2 - 1) return false;
-            const int nc = tile / KT2;
-            const unsigned long long te0 = p.stamp ? __builtin_amdgcn_s_memrealtime() : 0;
-            const int chb = nc * CM + wn * 64;                     // first channel of this wave in the chunk
-            // residual groups first (4 x 32 B per lane), then the arithmetic
-            uint4 rh[2][2], rl[2][2];
+            int did = 0;
+            if (tile % KT2 == KT2 - 1 - PF && !(p.flags & 2)) did = 2;
+            if (did && pix_ok) {
+                const int chp = (tile / KT2) * CM + wn * 64;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {
-                    rh[j][pp] = make_uint4(0, 0, 0, 0);
-                    rl[j][pp] = make_uint4(0, 0, 0, 0);
-                    if (pix_ok && !(p.flags & 2)) {
-                        const char *q = reinterpret_cast<const char *>(p.res) + row_off + (size_t)(chb + j * 32 + (2 * pp + lg) * 8) * 4;
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const char *q = reinterpret_cast<const char *>(p.res) + row_off + (size_t)(chp + j * 32 + (2 * pp + lg) * 8) * 4;
                         rh[j][pp] = *reinterpret_cast<const uint4 *>(q);
                         rl[j][pp] = *reinterpret_cast<const uint4 *>(q + 16);
                     }
-                }
+            }
+            if (tile % KT2 != KT2 - 1) return did;
+            const int nc = tile / KT2;
+            const unsigned long long te0 = p.stamp ? __builtin_amdgcn_s_memrealtime() : 0;
+            const int chb = nc * CM + wn * 64;                     // first channel of this wave in the chunk
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float v[2][8];
@@ -499,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
             }
             zero_acc();
             if (p.stamp) ts[5] += __builtin_amdgcn_s_memrealtime() - te0;
-            return true;
+            return did | 1;
         };
         run(std::integral_constant<int, C::NS2>{}, std::integral_constant<int, C::LPT2>{}, std::integral_constant<bool, PB2>{}, 4 * KT2,
             ring2, C::STAGE2, 0, issue2, next2, aptr, after);
