@@ -22,6 +22,7 @@
 namespace srcnn {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float __attribute__((address_space(4))) cfloat_k;      // constant address space: uniform loads become s_load
 
 struct BlockArgs {
     const void *x;                 // conv2 input, SPLIT16 (B, H, W, C)
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                 next();
                 ++issued;
             }
-            const int did = after(tt);            // bit 0: NST stores issued, bit 1: 8 residual loads issued
+            const int did = after(tt, issued);    // bit 0: NST stores issued, bit 1: 8 residual loads issued
             if (did & 1) store_mark = issued - 1;
             if (did & 2) load_mark = issued - 1;
             ++tt;
@@ -365,13 +366,16 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
     // accumulators of n-subtile j -> scaled, biased (own 16 channels), then lanes l / l+32 exchange so that this lane holds
     // the two whole 8-channel groups g = 2 * pp + lg (pp = 0, 1) of its pixel: v[pp][0..7]
     auto finish_tile = [&](int j, float os, const float *bias, int ch0, float v[2][8]) {
+        // bias through the scalar cache (ch0 is wave-uniform): s_load results count on lgkmcnt, so the epilogue neither waits
+        // for nor drains the vector-memory queue the DMA ring lives in
+        const cfloat_k *cb = reinterpret_cast<const cfloat_k *>(reinterpret_cast<unsigned long long>(bias)) + ch0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b4 = *reinterpret_cast<const float4 *>(bias + ch0 + 8 * q + 4 * lg);
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[j][4 * q + r] = (acc[j][4 * q + r] + accx[j][4 * q + r]) * os + bb[r];
-        }
+            for (int r = 0; r < 4; ++r) {
+                const float b0 = cb[8 * q + r], b1 = cb[8 * q + 4 + r];
+                acc[j][4 * q + r] = (acc[j][4 * q + r] + accx[j][4 * q + r]) * os + (lg ? b1 : b0);
+            }
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
         auto issue = [&](int pc, _Float16 *sb) { dma1(pc, sb); };
         auto next = [&]() { advance1(); };
         auto aptr = [&](int, const _Float16 *stage, const _Float16 *&ab, int &ap) { ab = stage; ap = PANEL_A; };
-        auto after = [&](int) { return 0; };
+        auto after = [&](int, int) { return 0; };
         if (p.stamp) ts[1] = __builtin_amdgcn_s_memrealtime();
         run(std::integral_constant<int, C::NS1>{}, std::integral_constant<int, C::LPT1>{}, std::integral_constant<bool, PB1>{}, K2T,
             blk_smem, C::STAGE1, 2 * PANEL_A, issue, next, aptr, after);
@@ -463,15 +467,17 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
         // residual groups of a chunk (4 x 32 B per lane) are requested PF K tiles before the chunk's last MFMA, so that their
         // latency (L2 / MALL: ~2 us, exposed 4x per workgroup otherwise) runs behind the matrix pipe
         constexpr int PF = KT2 >= 4 ? 3 : 1;
-        uint4 rh[2][2], rl[2][2];
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 rh[2][2], rl[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
-                rh[j][pp] = make_uint4(0, 0, 0, 0);
-                rl[j][pp] = make_uint4(0, 0, 0, 0);
+                rh[j][pp] = u32x4{0, 0, 0, 0};
+                rl[j][pp] = u32x4{0, 0, 0, 0};
             }
-        auto after = [&](int tile) {
+        int res_issued = 0;
+        auto after = [&](int tile, int issued_now) {
             int did = 0;
             if (tile % KT2 == KT2 - 1 - PF && !(p.flags & 2)) did = 2;
             if (did && pix_ok) {
@@ -480,14 +486,30 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp) {
+                        // hidden from the compiler's wait-count bookkeeping (it would drain the whole DMA ring at the first
+                        // use): completion is counted by hand in res_wait() below
                         const char *q = reinterpret_cast<const char *>(p.res) + row_off + (size_t)(chp + j * 32 + (2 * pp + lg) * 8) * 4;
-                        rh[j][pp] = *reinterpret_cast<const uint4 *>(q);
-                        rl[j][pp] = *reinterpret_cast<const uint4 *>(q + 16);
+                        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                                     : "=&v"(rh[j][pp]), "=&v"(rl[j][pp]) : "v"(q) : "memory");
                     }
+                res_issued = issued_now;
             }
             if (tile % KT2 != KT2 - 1) return did;
             const int nc = tile / KT2;
             const unsigned long long te0 = p.stamp ? __builtin_amdgcn_s_memrealtime() : 0;
+            // the residual groups were requested (issued_now - res_issued) K tiles of DMA ago: everything younger may stay
+            // in flight.  The statement names every destination so that no consumer is scheduled above it.
+            {
+                const int younger = (issued_now - res_issued) * C::LPT2;
+#define SRCNN_RW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(rh[0][0]), "+v"(rl[0][0]), "+v"(rh[0][1]), "+v"(rl[0][1]), \
+                                         "+v"(rh[1][0]), "+v"(rl[1][0]), "+v"(rh[1][1]), "+v"(rl[1][1]) :: "memory"); break;
+                switch (younger) {
+                    SRCNN_RW(1) SRCNN_RW(2) SRCNN_RW(3) SRCNN_RW(4) SRCNN_RW(6) SRCNN_RW(8) SRCNN_RW(12)
+                default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(rh[0][0]), "+v"(rl[0][0]), "+v"(rh[0][1]), "+v"(rl[0][1]),
+                                      "+v"(rh[1][0]), "+v"(rl[1][0]), "+v"(rh[1][1]), "+v"(rl[1][1]) :: "memory"); break;
+                }
+#undef SRCNN_RW
+            }
             const int chb = nc * CM + wn * 64;                     // first channel of this wave in the chunk
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -576,7 +598,7 @@ int srcnn_conv_block(const srcnn_block_desc *d, srcnn_stream_t stream)
     const bool prof = prof_enabled();
     if (prof) prof_begin(st);
     // debug / tuning knobs (read once): SRCNN_BLK_FLAGS = kernel flags, SRCNN_BLK_VARIANT = bit 0 PB schedule in phase 1, bit 1 in phase 2
-    static const int env_flags = getenv("SRCNN_BLK_FLAGS") ? atoi(getenv("SRCNN_BLK_FLAGS")) : 1;
+    static const int env_flags = getenv("SRCNN_BLK_FLAGS") ? atoi(getenv("SRCNN_BLK_FLAGS")) : 0;
     static const int env_variant = getenv("SRCNN_BLK_VARIANT") ? atoi(getenv("SRCNN_BLK_VARIANT")) : 2;
     a.flags = env_flags;
     a.stamp = debug_stamp_buffer();
