@@ -476,40 +476,24 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                 rh[j][pp] = u32x4{0, 0, 0, 0};
                 rl[j][pp] = u32x4{0, 0, 0, 0};
             }
-        int res_issued = 0;
-        auto after = [&](int tile, int issued_now) {
+        auto after = [&](int tile, int) {
             int did = 0;
             if (tile % KT2 == KT2 - 1 - PF && !(p.flags & 2)) did = 2;
-            if (did && pix_ok) {
+            if (did) {
                 const int chp = (tile / KT2) * CM + wn * 64;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp) {
-                        // hidden from the compiler's wait-count bookkeeping (it would drain the whole DMA ring at the first
-                        // use): completion is counted by hand in res_wait() below
-                        const char *q = reinterpret_cast<const char *>(p.res) + row_off + (size_t)(chp + j * 32 + (2 * pp + lg) * 8) * 4;
-                        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
-                                     : "=&v"(rh[j][pp]), "=&v"(rl[j][pp]) : "v"(q) : "memory");
+                        // (a pixel past M reads row 0: every wave issues the same 8 loads, which is what the vmcnt budget assumes)
+                        const char *q = reinterpret_cast<const char *>(p.res) + (pix_ok ? row_off : 0) + (size_t)(chp + j * 32 + (2 * pp + lg) * 8) * 4;
+                        rh[j][pp] = *reinterpret_cast<const u32x4 *>(q);
+                        rl[j][pp] = *reinterpret_cast<const u32x4 *>(q + 16);
                     }
-                res_issued = issued_now;
             }
             if (tile % KT2 != KT2 - 1) return did;
             const int nc = tile / KT2;
             const unsigned long long te0 = p.stamp ? __builtin_amdgcn_s_memrealtime() : 0;
-            // the residual groups were requested (issued_now - res_issued) K tiles of DMA ago: everything younger may stay
-            // in flight.  The statement names every destination so that no consumer is scheduled above it.
-            {
-                const int younger = (issued_now - res_issued) * C::LPT2;
-#define SRCNN_RW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(rh[0][0]), "+v"(rl[0][0]), "+v"(rh[0][1]), "+v"(rl[0][1]), \
-                                         "+v"(rh[1][0]), "+v"(rl[1][0]), "+v"(rh[1][1]), "+v"(rl[1][1]) :: "memory"); break;
-                switch (younger) {
-                    SRCNN_RW(1) SRCNN_RW(2) SRCNN_RW(3) SRCNN_RW(4) SRCNN_RW(6) SRCNN_RW(8) SRCNN_RW(12)
-                default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(rh[0][0]), "+v"(rl[0][0]), "+v"(rh[0][1]), "+v"(rl[0][1]),
-                                      "+v"(rh[1][0]), "+v"(rl[1][0]), "+v"(rh[1][1]), "+v"(rl[1][1]) :: "memory"); break;
-                }
-#undef SRCNN_RW
-            }
             const int chb = nc * CM + wn * 64;                     // first channel of this wave in the chunk
 #pragma unroll
             for (int j = 0; j < 2; ++j) {

@@ -236,7 +236,11 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")
 
 
-FUSE_BLOCKS = True      # f16x3 engine: conv2 + conv3 (+ residual) of the identity bottlenecks as one launch (csrc/conv_block.hip)
+# f16x3 engine: conv2 + conv3 (+ residual) of a bottleneck as ONE launch (csrc/conv_block.hip).  Correct (bit-identical to the
+# two stand-alone launches) but measured SLOWER on MI355X in every layer (profiles/fused_block_r02.txt: the per-wave 32x64
+# tiles that a 64-pixel workgroup allows are LDS-bandwidth bound, and the no-LDS epilogue quadruples the cache-line requests
+# of the residual / output traffic), so it is off by default.
+FUSE_BLOCKS = False
 
 
 def conv_block(conv2, conv3, x, B, H, W, y, residual):
