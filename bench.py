@@ -44,6 +44,9 @@ def parse():
                     help='replay the forward as one hipGraph instead of launching eagerly (measured slower on MI355X: the '
                          'replay serialises the side-stream branches; eager launches are not CPU-bound here)')
     ap.add_argument('--no-graph', action='store_true', help='(default) launch eagerly')
+    ap.add_argument('--no-program', action='store_true',
+                    help='walk the Python launch code every forward instead of replaying the native launch list '
+                         '(srcnn_program_run; default: replay -- same launches and streams, ~230 ctypes calls fewer per forward)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f16x3',
                     help="conv engine: f16x3 = fp32-class error-compensated split on the f16 MFMA (default, "
@@ -184,6 +187,7 @@ def main():
     model.eval()
     use_graph = bool(args.graph) and not args.no_graph
     model.use_graph = use_graph
+    model.use_program = not args.no_program and not use_graph
     model.precision = args.precision
     # every rank works on its own synthetic pair (weak scaling: per-GPU work is fixed)
     im_l, im_r, im_info = [t.to(dev) for t in fixture.make_inputs(3 + rank, args.height, args.width)]
@@ -307,6 +311,8 @@ def main():
         if rank == 0:
             L = _lib.lib()
             model.use_graph = False
+            use_program = model.use_program
+            model.use_program = False               # the library's per-launch events are taken on eagerly issued launches
             for pl in model._plans.values():        # one stream: every conv launch is timed alone on the chip
                 pl.overlap = False
             step(gather=False)
@@ -397,6 +403,7 @@ def main():
                                   'frac_headline_mode': round(alg_step / (dt / nf) / 1e12 / PEAKS[other], 4)}
                 model.precision = args.precision
             model.use_graph = use_graph
+            model.use_program = use_program
 
     if rank == 0:
         pairs = args.steps * world
@@ -411,6 +418,7 @@ def main():
                                    '(network input %dx%d), 300 proposals, forward + decode + class NMS, no dense-align'
                                    % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
                        'weights': 'seeded random init, reference state_dict schema', 'hipgraph': use_graph,
+                       'native_launch_program': bool(model.use_program),
                        'host_enqueue_ms_per_step': round(host_enqueue_ms, 3), 'plans_preloaded': plans_loaded,
                        'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single, 'engines': engines,
                        'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},

@@ -299,6 +299,25 @@ SRCNN_API int srcnn_solver_evaluate_host(int im_h, int im_w, double p2_00, doubl
                                const double *box_right4_or_null, const double *kpts5, const double *xyzt, double *cost,
                                double *grad4);
 
+/* ------------------------------------------------------------------ recorded launch programs
+ * The forward is a fixed list of ~230 asynchronous launches over fixed buffers (one list per input size and buffer set).
+ * Between srcnn_program_begin and srcnn_program_end every srcnn_* call made BY THE CALLING THREAD records its kernel
+ * launches / memsets (function, geometry, stream, by-value arguments) into the program instead of launching them;
+ * srcnn_program_run then re-issues the whole list from C on the streams it was recorded with, the main stream replaced by
+ * the one given -- no Python frame, descriptor filling or plan lookup per launch.  Dependencies between streams are
+ * recorded explicitly: record_event (returns an event id >= 0) on the producing stream, wait_event on the consuming one.
+ * The caller keeps every buffer a recorded launch points at alive and unchanged in address (activations, weights,
+ * workspaces).  Unlike a hipGraph the side-stream branches stay real concurrent streams at replay. */
+SRCNN_API void *srcnn_program_create(void);
+SRCNN_API void srcnn_program_destroy(void *prog);
+SRCNN_API int srcnn_program_begin(void *prog, srcnn_stream_t main_stream);
+SRCNN_API int srcnn_program_end(void *prog);
+SRCNN_API int srcnn_program_recording(void);                        /* 1 while the calling thread records */
+SRCNN_API int srcnn_program_record_event(void *prog, srcnn_stream_t stream);
+SRCNN_API int srcnn_program_wait_event(void *prog, srcnn_stream_t stream, int event_id);
+SRCNN_API int srcnn_program_size(void *prog);                       /* recorded nodes */
+SRCNN_API int srcnn_program_run(void *prog, srcnn_stream_t main_stream);
+
 /* ------------------------------------------------------------------ profiling hooks
  * When enabled, every conv-engine launch is bracketed by hipEvents on its stream; the
  * accumulated kernel time / algorithmic flops / launch count are read back with

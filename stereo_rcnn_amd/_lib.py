@@ -97,6 +97,15 @@ _SIGNATURES = {
                                       c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srcnn_solver_evaluate_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srcnn_program_create": (c_void_p, []),
+    "srcnn_program_destroy": (None, [c_void_p]),
+    "srcnn_program_begin": (c_int, [c_void_p, c_void_p]),
+    "srcnn_program_end": (c_int, [c_void_p]),
+    "srcnn_program_recording": (c_int, []),
+    "srcnn_program_record_event": (c_int, [c_void_p, c_void_p]),
+    "srcnn_program_wait_event": (c_int, [c_void_p, c_void_p, c_int]),
+    "srcnn_program_size": (c_int, [c_void_p]),
+    "srcnn_program_run": (c_int, [c_void_p, c_void_p]),
     "srcnn_prof_enable": (c_int, [c_int]),
     "srcnn_prof_read": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_double),
                                 ctypes.POINTER(ctypes.c_longlong)]),
@@ -160,6 +169,7 @@ class Workspace(object):
 
 
 _workspaces = {}
+_recording_refs = None      # while a launch program records: every workspace handed out (the program keeps them alive)
 
 
 def workspace(nbytes, device, key="default"):
@@ -167,4 +177,7 @@ def workspace(nbytes, device, key="default"):
     k = (str(device), key, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     if k not in _workspaces:
         _workspaces[k] = Workspace()
-    return _workspaces[k].get(nbytes, device)
+    buf = _workspaces[k].get(nbytes, device)
+    if _recording_refs is not None:
+        _recording_refs.append(buf)
+    return buf

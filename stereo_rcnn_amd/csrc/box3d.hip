@@ -171,7 +171,7 @@ int srcnn_infer_boundary(float *rec, int n, int rec_cols, int im_w, void *worksp
     using namespace srcnn;
     SRCNN_REQUIRE(rec && n > 0 && rec_cols >= SRCNN_REC_COLS && im_w > 0, "bad args (rec_cols >= SRCNN_REC_COLS)");
     SRCNN_REQUIRE(workspace && workspace_bytes >= srcnn_box3d_workspace_bytes(n, im_w), "workspace too small");
-    hipLaunchKernelGGL(infer_boundary_kernel, dim3(1), dim3(1024), 0, as_stream(stream), rec, n, rec_cols, im_w,
+    SRCNN_LAUNCH(infer_boundary_kernel, dim3(1), dim3(1024), 0, as_stream(stream), rec, n, rec_cols, im_w,
                        static_cast<double *>(workspace));
     return check_launch("srcnn_infer_boundary");
 }
@@ -181,7 +181,7 @@ int srcnn_solve_4dof(float *rec, int n, int rec_cols, int im_h, int im_w, double
 {
     using namespace srcnn;
     SRCNN_REQUIRE(rec && state4 && n > 0 && rec_cols >= SRCNN_REC_COLS, "bad args (rec_cols >= SRCNN_REC_COLS)");
-    hipLaunchKernelGGL(solve4_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols,
+    SRCNN_LAUNCH(solve4_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols,
                        make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03), eval_thresh, state4);
     return check_launch("srcnn_solve_4dof");
 }
@@ -191,7 +191,7 @@ int srcnn_align_inputs(const float *rec, int n, int rec_cols, float *boxes, floa
 {
     using namespace srcnn;
     SRCNN_REQUIRE(rec && boxes && borders && poses && valid && n > 0 && rec_cols >= SRCNN_REC_COLS, "bad args");
-    hipLaunchKernelGGL(align_inputs_kernel, dim3(cdiv(n, 64)), dim3(64), 0, as_stream(stream), rec, n, rec_cols, boxes,
+    SRCNN_LAUNCH(align_inputs_kernel, dim3(cdiv(n, 64)), dim3(64), 0, as_stream(stream), rec, n, rec_cols, boxes,
                        borders, poses, valid);
     return check_launch("srcnn_align_inputs");
 }
@@ -203,7 +203,7 @@ int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im_w, double
     using namespace srcnn;
     SRCNN_REQUIRE(rec && state && n > 0 && rec_cols >= SRCNN_REC_COLS, "bad args (rec_cols >= SRCNN_REC_COLS)");
     SRCNN_REQUIRE((align_status == nullptr) == (best_dis == nullptr), "align_status and best_dis come together");
-    hipLaunchKernelGGL(solve3_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols,
+    SRCNN_LAUNCH(solve3_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols,
                        make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03), align_status, best_dis, state);
     return check_launch("srcnn_solve_3dof");
 }

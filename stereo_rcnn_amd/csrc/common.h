@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 #include "../../include/srcnn_hip.h"
 
 namespace srcnn {
@@ -54,6 +57,52 @@ struct Carver {
         return r;
     }
 };
+
+// ---- launch recording (core.hip): every kernel launch and async memset of the library goes through launch_kernel() /
+// memset_async().  Normally they launch; while a srcnn_program is recording on the calling thread they append a node
+// (function, geometry, stream, a private copy of the by-value arguments) to it instead, and srcnn_program_run() replays
+// the whole list from C -- the forward's ~230 launches without a Python frame or a ctypes call in between.
+struct Program;
+Program *recording_program();
+void program_add_kernel(Program *p, const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t st, void *blob,
+                        void (*destroy)(void *), void **argv, int argc);
+void program_add_memset(Program *p, void *dst, int value, size_t bytes, hipStream_t st);
+
+template <typename Tup, size_t... I>
+inline void tuple_arg_pointers(Tup &t, void **argv, std::index_sequence<I...>)
+{
+    ((argv[I] = const_cast<void *>(static_cast<const void *>(&std::get<I>(t)))), ...);
+}
+
+template <typename... P, typename... A>
+inline void launch_kernel(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, A &&...a)
+{
+    static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+    using Tup = std::tuple<std::remove_cv_t<std::remove_reference_t<P>>...>;
+    constexpr int N = (int)sizeof...(P);
+    void *argv[N > 0 ? N : 1];
+    Program *prog = recording_program();
+    if (!prog) {
+        Tup t(static_cast<std::remove_cv_t<std::remove_reference_t<P>>>(a)...);
+        tuple_arg_pointers(t, argv, std::index_sequence_for<P...>{});
+        (void)hipLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, argv, lds, st);
+        return;
+    }
+    Tup *t = new Tup(static_cast<std::remove_cv_t<std::remove_reference_t<P>>>(a)...);
+    tuple_arg_pointers(*t, argv, std::index_sequence_for<P...>{});
+    program_add_kernel(prog, reinterpret_cast<const void *>(kernel), grid, block, lds, st, t,
+                       [](void *q) { delete static_cast<Tup *>(q); }, argv, N);
+}
+
+inline hipError_t memset_async(void *dst, int value, size_t bytes, hipStream_t st)
+{
+    Program *prog = recording_program();
+    if (!prog) return hipMemsetAsync(dst, value, bytes, st);
+    program_add_memset(prog, dst, value, bytes, st);
+    return hipSuccess;
+}
+
+#define SRCNN_LAUNCH(kernel, grid, block, lds, st, ...) ::srcnn::launch_kernel(kernel, dim3(grid), dim3(block), lds, st, __VA_ARGS__)
 
 // nms.hip: batched NMS where problems (2b, 2b+1) are scanned in lockstep and stop once the intersection of their
 // keep lists has `stop_after` entries (keep lists are then complete only up to that point).  Used by the proposal layer.

@@ -542,7 +542,7 @@ static void launch_block_v(const BlockArgs &a, hipStream_t st)
                                   (int)BlockCfg<CM>::LDS);
         configured = true;
     }
-    hipLaunchKernelGGL(k, dim3(a.mtiles), dim3(512), BlockCfg<CM>::LDS, st, a);
+    SRCNN_LAUNCH(k, dim3(a.mtiles), dim3(512), BlockCfg<CM>::LDS, st, a);
 }
 
 template <int CM>

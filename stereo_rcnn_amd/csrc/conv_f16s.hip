@@ -541,8 +541,8 @@ static void launch(const ConvArgs &a, int splits, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    if (a.y_fmt == 1) hipLaunchKernelGGL(k1, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);
-    else hipLaunchKernelGGL(k0, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);
+    if (a.y_fmt == 1) SRCNN_LAUNCH(k1, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);
+    else SRCNN_LAUNCH(k0, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);
 }
 
 // Plan -> instantiation.  Workgroup tile (64*mr) x (64*nr); waves 4 or 8; stages = LDS ring depth.

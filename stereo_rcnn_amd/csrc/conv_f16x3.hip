@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs p)
 template <int MR, int NR>
 static void launch(const ConvArgs &a, int splits, hipStream_t st)
 {
-    hipLaunchKernelGGL((conv_f16x3_kernel<MR, NR>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
+    SRCNN_LAUNCH((conv_f16x3_kernel<MR, NR>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
 }
 
 void launch_conv_f16x3(const ConvArgs &a, const Plan &pl, hipStream_t st)

@@ -345,7 +345,7 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
 template <int MR, int NR>
 static void launch(const ConvArgs &a, int splits, hipStream_t st)
 {
-    hipLaunchKernelGGL((conv_mfma_kernel<MR, NR>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
+    SRCNN_LAUNCH((conv_mfma_kernel<MR, NR>), dim3(a.mtiles * a.ntiles, splits), dim3(256), 0, st, a);
 }
 
 }  // namespace srcnn
@@ -392,7 +392,7 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     if (pl.splits > 1) {
         const size_t total = (size_t)a.M * a.Cout;
         const int blocks = (int)min((size_t)2048, (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a, pl.splits);
+        SRCNN_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a, pl.splits);
     }
     if (prof) prof_end(st, 2.0 * (double)a.M * (double)a.Cout * (double)a.K);
     return check_launch("srcnn_conv2d");

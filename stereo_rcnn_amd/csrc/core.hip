@@ -62,6 +62,73 @@ const void *zero_page()
     return page;
 }
 
+// ------------------------------------------------------------------ recorded launch programs
+struct ProgNode {
+    enum Kind { KERNEL, MEMSET, RECORD, WAIT } kind;
+    const void *fn = nullptr;
+    dim3 grid, block;
+    size_t lds = 0;
+    int stream = 0;                 // index into Program::streams (0 = the main stream, substituted at run time)
+    std::vector<void *> argv;       // pointers into `blob`
+    void *blob = nullptr;
+    void (*destroy)(void *) = nullptr;
+    void *dst = nullptr;            // MEMSET
+    int value = 0;
+    size_t bytes = 0;
+    int event = -1;                 // RECORD / WAIT
+};
+
+struct Program {
+    std::vector<ProgNode> nodes;
+    std::vector<hipStream_t> streams;      // as recorded; [0] = main
+    std::vector<hipEvent_t> events;
+    bool recording = false;
+    ~Program()
+    {
+        for (auto &n : nodes)
+            if (n.blob && n.destroy) n.destroy(n.blob);
+        for (auto e : events) (void)hipEventDestroy(e);
+    }
+    int stream_index(hipStream_t s)
+    {
+        for (size_t i = 0; i < streams.size(); ++i)
+            if (streams[i] == s) return (int)i;
+        streams.push_back(s);
+        return (int)streams.size() - 1;
+    }
+};
+
+static thread_local Program *t_recording = nullptr;
+
+Program *recording_program() { return t_recording; }
+
+void program_add_kernel(Program *p, const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t st, void *blob,
+                        void (*destroy)(void *), void **argv, int argc)
+{
+    ProgNode n;
+    n.kind = ProgNode::KERNEL;
+    n.fn = fn;
+    n.grid = grid;
+    n.block = block;
+    n.lds = lds;
+    n.stream = p->stream_index(st);
+    n.argv.assign(argv, argv + argc);
+    n.blob = blob;
+    n.destroy = destroy;
+    p->nodes.push_back(std::move(n));
+}
+
+void program_add_memset(Program *p, void *dst, int value, size_t bytes, hipStream_t st)
+{
+    ProgNode n;
+    n.kind = ProgNode::MEMSET;
+    n.stream = p->stream_index(st);
+    n.dst = dst;
+    n.value = value;
+    n.bytes = bytes;
+    p->nodes.push_back(std::move(n));
+}
+
 static unsigned long long *g_stamp = nullptr;
 unsigned long long *debug_stamp_buffer() { return g_stamp; }
 
@@ -72,7 +139,97 @@ extern "C" {
 // debug hook (not part of include/srcnn_hip.h): device buffer of 16 x u64 per workgroup, or NULL to switch off
 SRCNN_API void srcnn_debug_set_stamp_buffer(void *buf) { srcnn::g_stamp = static_cast<unsigned long long *>(buf); }
 
-int srcnn_version(void) { return 100; }
+int srcnn_version(void) { return 200; }
+
+// ---- launch programs (include/srcnn_hip.h)
+void *srcnn_program_create(void) { return new srcnn::Program(); }
+
+void srcnn_program_destroy(void *prog) { delete static_cast<srcnn::Program *>(prog); }
+
+int srcnn_program_begin(void *prog, srcnn_stream_t main_stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(prog && !t_recording, "null program, or another program is recording on this thread");
+    Program *p = static_cast<Program *>(prog);
+    SRCNN_REQUIRE(p->nodes.empty(), "program already holds a recording");
+    p->streams.assign(1, as_stream(main_stream));
+    p->recording = true;
+    t_recording = p;
+    return SRCNN_OK;
+}
+
+int srcnn_program_end(void *prog)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(prog && t_recording == prog, "this program is not recording on this thread");
+    t_recording = nullptr;
+    static_cast<Program *>(prog)->recording = false;
+    return SRCNN_OK;
+}
+
+int srcnn_program_recording(void) { return srcnn::t_recording != nullptr; }
+
+int srcnn_program_record_event(void *prog, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    if (!prog || t_recording != prog) {
+        set_error("srcnn_program_record_event: this program is not recording on this thread");
+        return SRCNN_ERR_ARG;
+    }
+    Program *p = static_cast<Program *>(prog);
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        set_error("srcnn_program_record_event: hipEventCreate failed");
+        return SRCNN_ERR_HIP;
+    }
+    p->events.push_back(e);
+    ProgNode n;
+    n.kind = ProgNode::RECORD;
+    n.stream = p->stream_index(as_stream(stream));
+    n.event = (int)p->events.size() - 1;
+    p->nodes.push_back(std::move(n));
+    return (int)p->events.size() - 1;
+}
+
+int srcnn_program_wait_event(void *prog, srcnn_stream_t stream, int event_id)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(prog && t_recording == prog, "this program is not recording on this thread");
+    Program *p = static_cast<Program *>(prog);
+    SRCNN_REQUIRE(event_id >= 0 && event_id < (int)p->events.size(), "unknown event");
+    ProgNode n;
+    n.kind = ProgNode::WAIT;
+    n.stream = p->stream_index(as_stream(stream));
+    n.event = event_id;
+    p->nodes.push_back(std::move(n));
+    return SRCNN_OK;
+}
+
+int srcnn_program_size(void *prog) { return prog ? (int)static_cast<srcnn::Program *>(prog)->nodes.size() : 0; }
+
+int srcnn_program_run(void *prog, srcnn_stream_t main_stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(prog, "null program");
+    Program *p = static_cast<Program *>(prog);
+    SRCNN_REQUIRE(!p->recording && !p->nodes.empty(), "program is empty or still recording");
+    hipStream_t main_s = as_stream(main_stream);
+    for (auto &n : p->nodes) {
+        hipStream_t st = n.stream == 0 ? main_s : p->streams[n.stream];
+        hipError_t e = hipSuccess;
+        switch (n.kind) {
+        case ProgNode::KERNEL: e = hipLaunchKernel(n.fn, n.grid, n.block, n.argv.data(), n.lds, st); break;
+        case ProgNode::MEMSET: e = hipMemsetAsync(n.dst, n.value, n.bytes, st); break;
+        case ProgNode::RECORD: e = hipEventRecord(p->events[n.event], st); break;
+        case ProgNode::WAIT: e = hipStreamWaitEvent(st, p->events[n.event], 0); break;
+        }
+        if (e != hipSuccess) {
+            set_error("srcnn_program_run: node failed: %s", hipGetErrorString(e));
+            return SRCNN_ERR_HIP;
+        }
+    }
+    return SRCNN_OK;
+}
 
 const char *srcnn_last_error(void) { return srcnn::g_err; }
 

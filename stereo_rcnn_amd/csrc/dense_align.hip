@@ -370,19 +370,19 @@ int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W,
     float *depth_enum = reinterpret_cast<float *>(ws + L.depth_enum), *cost = reinterpret_cast<float *>(ws + L.cost);
     float *best = reinterpret_cast<float *>(ws + L.best);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(4096, 1, 2), dim3(256), 0, st, im_left, im_right, H, W, up_l, up_r);
-    hipLaunchKernelGGL(sample_kernel, dim3(R), dim3(256), 0, st, boxes, borders, poses, valid, cal, max_pixels, uvz, cnt);
-    hipLaunchKernelGGL(left_sample_kernel, dim3(cdiv(max_pixels, 256), R), dim3(256), 0, st, up_l, uvz, cnt, max_pixels,
+    SRCNN_LAUNCH(upsample2x_kernel, dim3(4096, 1, 2), dim3(256), 0, st, im_left, im_right, H, W, up_l, up_r);
+    SRCNN_LAUNCH(sample_kernel, dim3(R), dim3(256), 0, st, boxes, borders, poses, valid, cal, max_pixels, uvz, cnt);
+    SRCNN_LAUNCH(left_sample_kernel, dim3(cdiv(max_pixels, 256), R), dim3(256), 0, st, up_l, uvz, cnt, max_pixels,
                        cal, left_val);
     for (int stage = 0; stage < 2; ++stage) {
         const int iters = stage == 0 ? 50 : 20;                  // dense_align.py:280,290
-        hipLaunchKernelGGL(make_enum_kernel, dim3(cdiv(R * iters, 256)), dim3(256), 0, st, poses, best, cal, R, iters,
+        SRCNN_LAUNCH(make_enum_kernel, dim3(cdiv(R * iters, 256)), dim3(256), 0, st, poses, best, cal, R, iters,
                            stage, depth_enum);
-        hipLaunchKernelGGL(cost_kernel, dim3(iters, R), dim3(256), 0, st, up_r, uvz, cnt, left_val, depth_enum,
+        SRCNN_LAUNCH(cost_kernel, dim3(iters, R), dim3(256), 0, st, up_r, uvz, cnt, left_val, depth_enum,
                            max_pixels, R, cal, cost);
-        hipLaunchKernelGGL(argmin_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, cost, depth_enum, R, iters, best);
+        SRCNN_LAUNCH(argmin_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, cost, depth_enum, R, iters, best);
     }
-    hipLaunchKernelGGL(finish_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, poses, best, cnt, R, cal, status, best_dis);
+    SRCNN_LAUNCH(finish_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, poses, best, cnt, R, cal, status, best_dis);
     return check_launch("srcnn_dense_align");
 }
 

@@ -250,7 +250,7 @@ int srcnn_softmax_rows(const float *x, int rows, int cols, int x_stride, float *
     using namespace srcnn;
     SRCNN_REQUIRE(x && y && rows >= 0 && cols > 0 && x_stride >= cols, "bad args");
     if (rows == 0) return SRCNN_OK;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, as_stream(stream), x, rows, cols,
+    SRCNN_LAUNCH(softmax_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, as_stream(stream), x, rows, cols,
                        x_stride, y);
     return check_launch("srcnn_softmax_rows");
 }
@@ -261,7 +261,7 @@ int srcnn_kpts_tail(const float *logits, int n, int G, float *kpts_prob, float *
     using namespace srcnn;
     SRCNN_REQUIRE(logits && kpts_prob && left_prob && right_prob && G > 0 && G <= 32, "bad args");
     if (n == 0) return SRCNN_OK;
-    hipLaunchKernelGGL(kpts_tail_kernel, dim3(n), dim3(256), 0, as_stream(stream), logits, G, kpts_prob, left_prob,
+    SRCNN_LAUNCH(kpts_tail_kernel, dim3(n), dim3(256), 0, as_stream(stream), logits, G, kpts_prob, left_prob,
                        right_prob);
     return check_launch("srcnn_kpts_tail");
 }
@@ -276,7 +276,7 @@ int srcnn_decode_detections(const float *rois_left, const float *rois_right, con
     SRCNN_REQUIRE(rois_left && rois_right && bbox_pred && dim_orien_pred && kpts_prob && left_prob && right_prob &&
                       im_info && boxes_left && boxes_right && dim_orien && kpts, "null pointer");
     if (n == 0) return SRCNN_OK;
-    hipLaunchKernelGGL(decode_detections_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), rois_left,
+    SRCNN_LAUNCH(decode_detections_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), rois_left,
                        rois_right, bbox_pred, dim_orien_pred, kpts_prob, left_prob, right_prob, im_info, n, n_cls, G,
                        boxes_left, boxes_right, dim_orien, kpts);
     return check_launch("srcnn_decode_detections");
@@ -289,7 +289,7 @@ int srcnn_pack_detections(const float *scores, const float *boxes_left, const fl
     using namespace srcnn;
     SRCNN_REQUIRE(scores && boxes_left && boxes_right && dim_orien && kpts && keep_idx && num_keep && rec, "null pointer");
     SRCNN_REQUIRE(rec_cols >= 20 && n > 0 && j >= 0 && j < n_cls, "bad sizes (rec_cols >= 20)");
-    hipLaunchKernelGGL(pack_detections_kernel, dim3(cdiv(n + 1, 128)), dim3(128), 0, as_stream(stream), scores,
+    SRCNN_LAUNCH(pack_detections_kernel, dim3(cdiv(n + 1, 128)), dim3(128), 0, as_stream(stream), scores,
                        boxes_left, boxes_right, dim_orien, kpts, keep_idx, num_keep, n, n_cls, j, rec_cols, rec);
     return check_launch("srcnn_pack_detections");
 }
@@ -315,13 +315,13 @@ int srcnn_class_nms(const float *scores, int n, int n_cls, int j, const float *b
     int *num = reinterpret_cast<int *>(ws + L.num);
     int *count = reinterpret_cast<int *>(ws + L.count);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(class_select_sort_kernel, dim3(1), dim3(1024), 0, st, scores, n, n_cls, j, boxes_left,
+    SRCNN_LAUNCH(class_select_sort_kernel, dim3(1), dim3(1024), 0, st, scores, n, n_cls, j, boxes_left,
                        score_thresh, sorted_idx, dets, count);
     int rc = check_launch("class_nms: select");
     if (rc != SRCNN_OK) return rc;
     rc = srcnn_nms_batched(keep, dets, num, count, 1, n, 5, nms_thresh, ws + L.nms, workspace_bytes - L.nms, stream);
     if (rc != SRCNN_OK) return rc;
-    hipLaunchKernelGGL(map_keep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, keep, num, sorted_idx, n, keep_idx,
+    SRCNN_LAUNCH(map_keep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, keep, num, sorted_idx, n, keep_idx,
                        num_keep);
     return check_launch("class_nms: map");
 }

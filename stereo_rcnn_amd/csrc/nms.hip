@@ -291,7 +291,7 @@ static void launch_scan(const u64 *mask, const u64 *zero_word, int nb, int n, in
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = lds;
     }
-    hipLaunchKernelGGL(k, dim3(nb / PAIR), dim3(SCAN_T * PAIR), lds, st, mask, zero_word, n, cb, n_valid, keep_out,
+    SRCNN_LAUNCH(k, dim3(nb / PAIR), dim3(SCAN_T * PAIR), lds, st, mask, zero_word, n, cb, n_valid, keep_out,
                        num_out, stop_after);
 }
 
@@ -305,7 +305,7 @@ static int launch_nms(int *keep_out, const float *dets, int *num_out, const int 
     SRCNN_REQUIRE(!paired || nb % 2 == 0, "paired NMS needs an even number of problems");
     if (nb == 0) return SRCNN_OK;
     if (n == 0) {
-        SRCNN_HIP_TRY(hipMemsetAsync(num_out, 0, sizeof(int) * nb, st));
+        SRCNN_HIP_TRY(memset_async(num_out, 0, sizeof(int) * nb, st));
         return SRCNN_OK;
     }
     const int cb = cdiv(n, 64);
@@ -317,7 +317,7 @@ static int launch_nms(int *keep_out, const float *dets, int *num_out, const int 
     }
     SRCNN_REQUIRE((size_t)(paired ? 2 : 1) * (SCAN_RING + (size_t)n) * 4 + 128 <= 160 * 1024, "n too large for the LDS kept list");
     auto *mask = static_cast<unsigned long long *>(ws);
-    hipLaunchKernelGGL(pair_mask_kernel, dim3(cb, cb, nb), dim3(64), 0, st, dets, n, dim, thresh, mask, cb, mask + words);
+    SRCNN_LAUNCH(pair_mask_kernel, dim3(cb, cb, nb), dim3(64), 0, st, dets, n, dim, thresh, mask, cb, mask + words);
     if (paired) launch_scan<2>(mask, mask + words, nb, n, cb, n_valid, keep_out, num_out, stop_after, st);
     else launch_scan<1>(mask, mask + words, nb, n, cb, n_valid, keep_out, num_out, 0, st);
     return check_launch("nms");

@@ -307,12 +307,12 @@ int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, int o
     SRCNN_REQUIRE((unsigned)out_format <= 1, "bad format");
     if (out_format == 1) {
         const size_t groups = (size_t)B * (H + 6) * ((W + 8) / 2);
-        hipLaunchKernelGGL(stem_pack_split16_kernel, dim3(grid_for(groups, 256)), dim3(256), 0, as_stream(stream), im_nchw, B,
+        SRCNN_LAUNCH(stem_pack_split16_kernel, dim3(grid_for(groups, 256)), dim3(256), 0, as_stream(stream), im_nchw, B,
                            H, W, reinterpret_cast<char *>(out));
         return check_launch("srcnn_stem_pack");
     }
     const size_t total = (size_t)B * (H + 6) * (W + 8);
-    hipLaunchKernelGGL(stem_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), im_nchw, B, H, W,
+    SRCNN_LAUNCH(stem_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), im_nchw, B, H, W,
                        reinterpret_cast<float4 *>(out));
     return check_launch("srcnn_stem_pack");
 }
@@ -325,7 +325,7 @@ int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y
     SRCNN_REQUIRE((OH - 1) * 2 < H && (OW - 1) * 2 < W, "output too large for input");
     SRCNN_REQUIRE((unsigned)y_format <= 1, "bad format");
     const size_t total = (size_t)B * OH * OW * (C / 8);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, B, H, W, C,
+    SRCNN_LAUNCH(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, B, H, W, C,
                        y, OH, OW, y_format);
     return check_launch("srcnn_maxpool3x3s2_ceil");
 }
@@ -337,7 +337,7 @@ int srcnn_upsample_add(const float *top, int TH, int TW, const float *lateral, i
     SRCNN_REQUIRE(C % 8 == 0, "C must be a multiple of 8");
     SRCNN_REQUIRE((unsigned)top_format <= 1 && (unsigned)y_format <= 1, "bad format");
     SRCNN_REQUIRE((long long)B * H <= 65535 && (long long)W * (C / 8) < (1LL << 31), "map too large");
-    hipLaunchKernelGGL(upsample_add_kernel, dim3((W * (C / 8) + 255) / 256, B * H), dim3(256), 0, as_stream(stream), top, TH, TW,
+    SRCNN_LAUNCH(upsample_add_kernel, dim3((W * (C / 8) + 255) / 256, B * H), dim3(256), 0, as_stream(stream), top, TH, TW,
                        lateral, B, H, W, C, y, top_format, y_format);
     return check_launch("srcnn_upsample_add");
 }
@@ -350,7 +350,7 @@ int srcnn_act_convert(const void *x, int x_format, void *y, int y_format, long l
     SRCNN_REQUIRE((unsigned)x_format <= 1 && (unsigned)y_format <= 1, "bad format");
     if (pixels == 0) return SRCNN_OK;
     const size_t total = (size_t)pixels * (C / 8);
-    hipLaunchKernelGGL(act_convert_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, x_format, y,
+    SRCNN_LAUNCH(act_convert_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, x_format, y,
                        y_format, (size_t)pixels, C);
     return check_launch("srcnn_act_convert");
 }
@@ -365,7 +365,7 @@ int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, double scale, f
     SRCNN_REQUIRE(OH == (int)nearbyint((double)H * scale) && OW == (int)nearbyint((double)W * scale),
                   "OH/OW must be cvRound(H*scale), cvRound(W*scale)");
     const size_t total = (size_t)(OH + 6) * ((OW + 8 + 1) / 2);
-    hipLaunchKernelGGL(preprocess_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), img_rgb, H, W,
+    SRCNN_LAUNCH(preprocess_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), img_rgb, H, W,
                        1.0 / scale, OH, OW, out_nchw, reinterpret_cast<char *>(packed), packed_format);
     return check_launch("srcnn_preprocess");
 }
@@ -376,7 +376,7 @@ int srcnn_subsample2(const float *x, int B, int H, int W, int C, float *y, int O
     SRCNN_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
     SRCNN_REQUIRE((OH - 1) * 2 < H && (OW - 1) * 2 < W, "output too large for input");
     const size_t total = (size_t)B * OH * OW * (C / 4);
-    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream),
+    SRCNN_LAUNCH(subsample2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4 *>(x), B, H, W, C / 4, reinterpret_cast<float4 *>(y), OH, OW);
     return check_launch("srcnn_subsample2");
 }
@@ -386,7 +386,7 @@ int srcnn_nhwc_to_nchw(const float *x, int B, int H, int W, int C, float *y, src
     using namespace srcnn;
     const int R = H * W, S = C;   // (B, HW, C) -> (B, C, HW)
     SRCNN_REQUIRE(B <= 65535, "batch too large");
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(S, 32), cdiv(R, 32), B), dim3(32, 8), 0, as_stream(stream), x, R, S, y);
+    SRCNN_LAUNCH(transpose_kernel, dim3(cdiv(S, 32), cdiv(R, 32), B), dim3(32, 8), 0, as_stream(stream), x, R, S, y);
     return check_launch("srcnn_nhwc_to_nchw");
 }
 
@@ -395,7 +395,7 @@ int srcnn_nchw_to_nhwc(const float *x, int B, int C, int H, int W, float *y, src
     using namespace srcnn;
     const int R = C, S = H * W;   // (B, C, HW) -> (B, HW, C)
     SRCNN_REQUIRE(B <= 65535, "batch too large");
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(S, 32), cdiv(R, 32), B), dim3(32, 8), 0, as_stream(stream), x, R, S, y);
+    SRCNN_LAUNCH(transpose_kernel, dim3(cdiv(S, 32), cdiv(R, 32), B), dim3(32, 8), 0, as_stream(stream), x, R, S, y);
     return check_launch("srcnn_nchw_to_nhwc");
 }
 

@@ -220,7 +220,7 @@ int roi_align_forward_cuda(int aligned_height, int aligned_width, float spatial_
     }
     const int threads = 256;
     const int blocks = (int)((total + threads - 1) / threads);
-    hipLaunchKernelGGL(roi_align_nchw_kernel, dim3(blocks), dim3(threads), 0, as_stream(stream), (int)total,
+    SRCNN_LAUNCH(roi_align_nchw_kernel, dim3(blocks), dim3(threads), 0, as_stream(stream), (int)total,
                        features, spatial_scale, height, width, channels, aligned_height, aligned_width, rois,
                        output);
     return check_launch("roi_align_forward_cuda") == SRCNN_OK ? 1 : 0;
@@ -248,19 +248,19 @@ int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, c
         const int G = channels / 8, rows = G <= 32 ? 64 / G : 1;   // one or two wavefronts per block: thousands of small blocks
         dim3 grid8((A + rows - 1) / rows, num_rois), block8(G, rows);
         if (A == 7)
-            hipLaunchKernelGGL(pyramid_roi_align8_kernel<7>, grid8, block8, 0, as_stream(stream), pa, channels, rois, out,
+            SRCNN_LAUNCH(pyramid_roi_align8_kernel<7>, grid8, block8, 0, as_stream(stream), pa, channels, rois, out,
                                out_cstride, out_coffset, maps_format, out_format);
         else
-            hipLaunchKernelGGL(pyramid_roi_align8_kernel<14>, grid8, block8, 0, as_stream(stream), pa, channels, rois, out,
+            SRCNN_LAUNCH(pyramid_roi_align8_kernel<14>, grid8, block8, 0, as_stream(stream), pa, channels, rois, out,
                                out_cstride, out_coffset, maps_format, out_format);
         return check_launch("srcnn_pyramid_roi_align");
     }
     dim3 grid(A, num_rois), block(channels);
     if (A == 7)
-        hipLaunchKernelGGL(pyramid_roi_align_kernel<7>, grid, block, 0, as_stream(stream), pa, channels, rois, out,
+        SRCNN_LAUNCH(pyramid_roi_align_kernel<7>, grid, block, 0, as_stream(stream), pa, channels, rois, out,
                            out_cstride, out_coffset, maps_format, out_format);
     else
-        hipLaunchKernelGGL(pyramid_roi_align_kernel<14>, grid, block, 0, as_stream(stream), pa, channels, rois,
+        SRCNN_LAUNCH(pyramid_roi_align_kernel<14>, grid, block, 0, as_stream(stream), pa, channels, rois,
                            out, out_cstride, out_coffset, maps_format, out_format);
     return check_launch("srcnn_pyramid_roi_align");
 }

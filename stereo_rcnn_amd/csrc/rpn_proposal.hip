@@ -355,7 +355,7 @@ int srcnn_rpn_score(const float *head, int B, int hw, int head_cstride, float *p
     using namespace srcnn;
     SRCNN_REQUIRE(head && probs && deltas && B > 0 && hw > 0 && head_cstride >= 24, "bad args");
     const int total = B * hw;
-    hipLaunchKernelGGL(rpn_score_kernel, dim3(std::min(cdiv(total, 256), 4096)), dim3(256), 0, as_stream(stream), head,
+    SRCNN_LAUNCH(rpn_score_kernel, dim3(std::min(cdiv(total, 256), 4096)), dim3(256), 0, as_stream(stream), head,
                        B, hw, head_cstride, probs, deltas, level_offset, num_anchors_total);
     return check_launch("srcnn_rpn_score");
 }
@@ -412,30 +412,30 @@ int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num
         TkState *state = reinterpret_cast<TkState *>(ws + L.state);
         unsigned *hist = reinterpret_cast<unsigned *>(ws + L.hist);
         unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + L.cand);
-        SRCNN_HIP_TRY(hipMemsetAsync(ws + L.state, 0, L.cand - L.state, st));
+        SRCNN_HIP_TRY(memset_async(ws + L.state, 0, L.cand - L.state, st));
         const int ksel = n;
         const int G = 256;
         static const int sshift[3] = {21, 10, 0}, swidth[3] = {11, 11, 10};
         static const unsigned smask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
-        hipLaunchKernelGGL(tk_set_remaining_kernel, dim3(1), dim3(64), 0, st, state, B, (unsigned)ksel);
+        SRCNN_LAUNCH(tk_set_remaining_kernel, dim3(1), dim3(64), 0, st, state, B, (unsigned)ksel);
         for (int p = 0; p < 3; ++p) {
-            hipLaunchKernelGGL(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, 0,
+            SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, 0,
                                sshift[p], swidth[p], smask[p]);
-            hipLaunchKernelGGL(tk_pick_kernel, dim3(B), dim3(64), 0, st, state, hist, 0, sshift[p], p == 2, ksel,
+            SRCNN_LAUNCH(tk_pick_kernel, dim3(B), dim3(64), 0, st, state, hist, 0, sshift[p], p == 2, ksel,
                                num_anchors);
         }
         static const int ishift[2] = {11, 0};
         static const unsigned imask[2] = {0u, 0xFFFFF800u};
         for (int p = 0; p < 2; ++p) {
-            hipLaunchKernelGGL(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, 1,
+            SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, 1,
                                ishift[p], 11, imask[p]);
-            hipLaunchKernelGGL(tk_pick_kernel, dim3(B), dim3(64), 0, st, state, hist, 1, ishift[p], p == 1, ksel,
+            SRCNN_LAUNCH(tk_pick_kernel, dim3(B), dim3(64), 0, st, state, hist, 1, ishift[p], p == 1, ksel,
                                num_anchors);
         }
-        hipLaunchKernelGGL(tk_compact_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, cand, TK_MAXK);
-        hipLaunchKernelGGL(tk_rank_kernel, dim3(cdiv(ksel, 64), B), dim3(1024), 0, st, cand, TK_MAXK, ksel, n, order);
+        SRCNN_LAUNCH(tk_compact_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, cand, TK_MAXK);
+        SRCNN_LAUNCH(tk_rank_kernel, dim3(cdiv(ksel, 64), B), dim3(1024), 0, st, cand, TK_MAXK, ksel, n, order);
     }
-    hipLaunchKernelGGL(gather_decode_kernel, dim3(cdiv(B * n, 256)), dim3(256), 0, st, probs, deltas, num_anchors, B,
+    SRCNN_LAUNCH(gather_decode_kernel, dim3(cdiv(B * n, 256)), dim3(256), 0, st, probs, deltas, num_anchors, B,
                        n, n, order, lt, im_info, dets);
     int rc = check_launch("proposal: select/decode");
     if (rc != SRCNN_OK) return rc;
@@ -443,7 +443,7 @@ int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num
     rc = nms_pairs_until(keep, dets, num, nullptr, 2 * B, n, 5, nms_thresh, ws + L.nms, workspace_bytes - L.nms,
                          post_nms, st);
     if (rc != SRCNN_OK) return rc;
-    hipLaunchKernelGGL(intersect_pad_kernel, dim3(B), dim3(1024), 0, st, keep, num, dets, n, post_nms, rois_left,
+    SRCNN_LAUNCH(intersect_pad_kernel, dim3(B), dim3(1024), 0, st, keep, num, dets, n, post_nms, rois_left,
                        rois_right, num_valid);
     return check_launch("proposal: intersect");
 }

@@ -226,8 +226,8 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt))
         plan = _TUNED.get(key)
         if plan is None:
-            if torch.cuda.is_current_stream_capturing():
-                plan = (0, 0, 0, 0, 0)    # never time inside a graph capture; warm-up runs tune first
+            if torch.cuda.is_current_stream_capturing() or _lib.lib().srcnn_program_recording():
+                plan = (0, 0, 0, 0, 0)    # never time inside a graph capture / program recording; warm-up runs tune first
             else:
                 plan = _tune(d, key, x.device)
         _set_plan(d, plan)

@@ -147,6 +147,8 @@ class Plan(object):
         self.left_prob = e(R, G)
         self.right_prob = e(R, G)
         self.graphs = {}
+        self.programs = {}      # precision -> (native launch program handle, buffers it keeps alive); run(use_program=True)
+        self._rec = None        # program being recorded right now
         self.fuse_channels = (64, 128, 256)     # bottleneck widths whose conv2 + conv3 run fused (engine.FUSE_BLOCKS)
         self.packed_fmt = -1    # format `packed` currently holds for the inputs of the NEXT run (-1: none, pack in trunk())
         self.fmt = 0            # activation format of the internal buffers for the current/last run
@@ -199,12 +201,30 @@ class Plan(object):
                 cur, nxt = nxt, cur
             self.c[li] = x
 
-    # ---- fork / join helpers (all capturable: event record + stream wait)
+    # ---- fork / join helpers: event record + stream wait, eagerly (torch; also what a hipGraph capture sees) or, while a
+    # launch program records (run(use_program=True)), as nodes of that program
+    def _signal(self, stream):
+        """Marks the current end of `stream`; returns a token for _wait()."""
+        if self._rec is not None:
+            ev = _lib.lib().srcnn_program_record_event(self._rec, stream.cuda_stream)
+            if ev < 0:
+                _lib.check(ev, "srcnn_program_record_event")
+            return ev
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def _wait(self, stream, token):
+        if self._rec is not None:
+            _lib.check(_lib.lib().srcnn_program_wait_event(self._rec, stream.cuda_stream, token), "srcnn_program_wait_event")
+        else:
+            stream.wait_event(token)
+
     def _fork(self, side):
-        side.wait_stream(torch.cuda.current_stream())
+        self._wait(side, self._signal(torch.cuda.current_stream()))
 
     def _join(self, side):
-        torch.cuda.current_stream().wait_stream(side)
+        self._wait(torch.cuda.current_stream(), self._signal(side))
 
     def _rpn_level(self, l):
         """RPN_Conv on left and right maps of level l into [left 512 | right 512], fused 1x1 heads, scoring."""
@@ -235,9 +255,7 @@ class Plan(object):
             with torch.cuda.stream(s_lat):
                 for i, (cin, (h, w_)) in enumerate(((c4, (h4, w4)), (c3, (h3, w3)), (c2, (h2, w2)))):
                     engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)     # lateral stays F32
-                    ev = torch.cuda.Event()
-                    ev.record(s_lat)
-                    lat_done.append(ev)
+                    lat_done.append(self._signal(s_lat))
         engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, x_fmt=f, y_fmt=f)
         h6, w6 = self.rpn_shapes[4]
         engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                              # stereo_rcnn.py:168
@@ -254,7 +272,7 @@ class Plan(object):
                                                  (c2, (h2, w2), self.p2))):
             top, th, tw = tops[i]
             if par:
-                torch.cuda.current_stream().wait_event(lat_done[i])
+                self._wait(torch.cuda.current_stream(), lat_done[i])
             else:
                 engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)
             engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i], top_fmt=f, y_fmt=f)   # stereo_rcnn.py:91-108
@@ -383,14 +401,42 @@ class Plan(object):
         self.packed_fmt = fmt
         return scale
 
-    def run(self, use_graph=False, precision='f32'):
-        """precision: 'f32' (exact fp32 MFMA engine) or 'f16x3' (3-term split on the f16 MFMA)."""
+    def _record_program(self, precision):
+        """One pass through launch_all() with the library in record mode: nothing is launched, every kernel launch / memset /
+        stream dependency lands in a native list that srcnn_program_run re-issues (include/srcnn_hip.h)."""
+        L = _lib.lib()
+        self.launch_all()                     # warm-up: tunes the plans, sizes every workspace, splits the weights
+        torch.cuda.synchronize()
+        prog = L.srcnn_program_create()
+        refs = []
+        _lib._recording_refs = refs
+        _lib.check(L.srcnn_program_begin(prog, torch.cuda.current_stream().cuda_stream), "srcnn_program_begin")
+        self._rec = prog
+        try:
+            self.launch_all()
+        finally:
+            self._rec = None
+            _lib._recording_refs = None
+            _lib.check(L.srcnn_program_end(prog), "srcnn_program_end")
+        self.programs[precision] = (prog, refs)
+        return prog
+
+    def run(self, use_graph=False, precision='f32', use_program=False):
+        """precision: 'f32' (exact fp32 MFMA engine) or 'f16x3' (3-term split on the f16 MFMA).
+        use_program: replay the forward from the native launch list (recorded on first use) instead of walking the Python
+        launch code -- same launches, same streams, same results."""
         prev = engine.PRECISION
         engine.PRECISION = precision
         # the f16x3 engine keeps activations in the SPLIT16 format between convolutions so that
         # both GEMM operands are DMA'd into LDS (csrc/conv_f16s.hip); the fp32 engine uses F32
         self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
         try:
+            if use_program and not use_graph:
+                self.packed_fmt = -1                  # the recorded list always contains the stem_pack launches
+                ent = self.programs.get(precision)
+                prog = ent[0] if ent else self._record_program(precision)
+                _lib.check(_lib.lib().srcnn_program_run(prog, torch.cuda.current_stream().cuda_stream), "srcnn_program_run")
+                return
             if not use_graph:
                 self.launch_all()
                 return
@@ -418,7 +464,7 @@ class Plan(object):
         fc = self.fc.view(B, self.post, -1)
         bbox_pred = fc[:, :, :w.n_bbox].contiguous()
         dim_orien = fc[:, :, w.n_bbox:w.n_bbox + w.n_dim].contiguous()
-        if self.graphs:
+        if self.graphs or self.programs:
             return {
                 'rois_left': self.rois_left.clone(), 'rois_right': self.rois_right.clone(),
                 'cls_prob': self.cls_prob.view(B, self.post, -1).clone(),

@@ -36,6 +36,7 @@ class _StereoRCNN(nn.Module):
         self.RCNN_roi_align = RoIAlignAvg(cfg.POOLING_SIZE, cfg.POOLING_SIZE, 1.0 / 16.0)
         self.RCNN_roi_kpts_align = RoIAlignAvg(cfg.POOLING_SIZE * 2, cfg.POOLING_SIZE * 2, 1.0 / 16.0)
         self.use_graph = False            # replay the forward as one hipGraph (see plan.py)
+        self.use_program = False          # replay the forward from the native launch list (srcnn_program_run; see plan.py)
         # conv engine: 'f16x3' (default: error-compensated 3-term split on the f16 MFMA, fp32-class results, same parity
         # tolerances) or 'f32' (exact fp32 MFMA, ~2.4x slower)
         self.precision = 'f16x3'
@@ -160,7 +161,7 @@ class _StereoRCNN(nn.Module):
         return self._run(plan), plan.im_left, plan.im_right, plan.im_info
 
     def _run(self, plan):
-        plan.run(self.use_graph, self.precision)
+        plan.run(self.use_graph, self.precision, getattr(self, 'use_program', False))
         o = plan.outputs()
         self.RCNN_loss_cls = 0
         self.RCNN_loss_bbox = 0

@@ -168,6 +168,35 @@ def test_graph_replay_matches_eager(small, dev):
         assert torch.equal(a, b) and torch.equal(a, c)      # deterministic kernels: bitwise repeatable
 
 
+@pytest.mark.parametrize("precision", ['f16x3', 'f32'])
+def test_native_launch_program_replay_matches_eager(dev, precision):
+    """srcnn_program_*: the forward recorded once into a native launch list and re-issued from C (side streams and their
+    event dependencies included) gives bit-for-bit the eager forward, repeatedly, also on another stream and with other
+    inputs in the same buffers."""
+    from stereo_rcnn_amd import _lib
+    m, _ = _build_model(dev)
+    m.precision = precision
+    a = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
+    b = [t.to(dev) for t in fixture.make_inputs(5, 120, 400, target_short=192)]
+    with torch.no_grad():
+        ea = [t.clone() for t in m(*a)[:8]]
+        eb = [t.clone() for t in m(*b)[:8]]
+        m.use_program = True
+        pa1 = [t.clone() for t in m(*a)[:8]]
+        pb = [t.clone() for t in m(*b)[:8]]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            pa2 = [t.clone() for t in m(*a)[:8]]
+        torch.cuda.synchronize()
+    plan = m._get_plan(1, a[0].shape[2], a[0].shape[3])
+    prog = plan.programs[precision][0]
+    n = _lib.lib().srcnn_program_size(prog)
+    assert n > 150, n                       # ~230 kernel launches + the fork / join nodes
+    for x, y, z, w_, v in zip(ea, pa1, pa2, eb, pb):
+        assert torch.equal(x, y) and torch.equal(x, z) and torch.equal(w_, v)
+
+
 def test_full_size_vs_golden(dev):
     """BASELINE configs[1]: 375x1242 pair -> 600x1987, ResNet-101 FPN, 300 proposals."""
     from stereo_rcnn_amd import fixture
