@@ -278,6 +278,16 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el[0])
 
+        # host cost of enqueueing ONE step on an idle GPU (queues empty: no back-pressure from the runtime in the number)
+        enq = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            step(0, gather=False)
+            enq.append((time.perf_counter() - te) * 1e3)
+        torch.cuda.synchronize()
+        host_enqueue_idle_ms = sorted(enq)[len(enq) // 2]
+
         # the same K steps strictly one pair at a time (reported next to the headline when S > 1)
         single = None
         if S > 1:
@@ -419,7 +429,8 @@ def main():
                                    % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
                        'weights': 'seeded random init, reference state_dict schema', 'hipgraph': use_graph,
                        'native_launch_program': bool(model.use_program),
-                       'host_enqueue_ms_per_step': round(host_enqueue_ms, 3), 'plans_preloaded': plans_loaded,
+                       'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
+                       'host_enqueue_ms_per_step_idle_gpu': round(host_enqueue_idle_ms, 3), 'plans_preloaded': plans_loaded,
                        'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single, 'engines': engines,
                        'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},
             'roofline': roofline,

@@ -173,7 +173,7 @@ def test_native_launch_program_replay_matches_eager(dev, precision):
     """srcnn_program_*: the forward recorded once into a native launch list and re-issued from C (side streams and their
     event dependencies included) gives bit-for-bit the eager forward, repeatedly, also on another stream and with other
     inputs in the same buffers."""
-    from stereo_rcnn_amd import _lib
+    from stereo_rcnn_amd import _lib, fixture
     m, _ = _build_model(dev)
     m.precision = precision
     a = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
