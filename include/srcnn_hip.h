@@ -132,6 +132,7 @@ typedef struct srcnn_conv_desc {
      * operands are DMA'd straight into LDS (global_load_lds).  fp32 engine: all formats must be F32. */
     int x_format, y_format, res_format;
     int tile_waves, tile_stages;
+    int layer_tag;         /* caller's id of this layer (> 0) for srcnn_range_flag_read; 0 = untagged */
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
@@ -152,8 +153,19 @@ typedef struct srcnn_block_desc {
     const void *residual;
     void *y;
     int B, H, W, C;
+    int layer_tag;
 } srcnn_block_desc;
 SRCNN_API int srcnn_conv_block(const srcnn_block_desc *d, srcnn_stream_t stream);
+
+/* SPLIT16 range guard.  The format stores hi = f16(v) unscaled: an activation beyond +-65504 (or a NaN) becomes inf and
+ * poisons what it touches, where the fp32 engine would carry on.  Every kernel that writes SPLIT16 from fresh arithmetic
+ * records it: a library-owned device word keeps max(layer_tag + 1) over the launches that produced such a value since
+ * the last reset (0 = every SPLIT16 tensor was in range; 9001 = srcnn_upsample_add).  srcnn_range_flag_read copies the word
+ * to the host (it SYNCHRONISES the device) and optionally clears it; srcnn_pack_detections also drops it into
+ * rec[0][1], so that the 3-D flow sees it without an extra copy.  A caller that finds it set re-runs the pair with
+ * desc.precision = 0 (exact fp32 engine, F32 activations): stereo_rcnn_amd/pipeline.py does. */
+SRCNN_API int srcnn_range_flag_read(int reset);
+SRCNN_API const void *srcnn_range_flag_device_word(void);
 
 /* A0 preprocessing (demo.py:103-129, blob.py:39-64): uint8 RGB (H,W,3) on the device -> BGR, PIXEL_MEANS subtracted
  * (in double, stored float32, as numpy's float32 -= float64), then cv2.resize(img, None, None, fx=scale, fy=scale,

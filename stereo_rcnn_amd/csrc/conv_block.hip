@@ -39,6 +39,8 @@ struct BlockArgs {
     int flags;                     // debug: bit 0 count the epilogue stores in the vmcnt budget, bit 1 skip the residual
                                    // loads, bit 2 skip the stores (timing experiments only; SRCNN_BLK_FLAGS)
     unsigned long long *stamp;     // debug: 8 x u64 per workgroup (100 MHz chip clock), normally nullptr
+    unsigned *range_flag;          // SPLIT16 range guard (conv_common.h)
+    int tag;
 };
 
 __device__ __forceinline__ void blk_dma16(const void *gsrc, _Float16 *lds_wave_base)
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float x = fmaxf(v[pp][e], 0.f);                     // ReLU of conv2 (resnet.py:89)
+                    if (!(x <= 65504.f)) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
                     hi[e] = (_Float16)x;
                     lo[e] = (_Float16)(x - (float)hi[e]);
                 }
@@ -507,6 +510,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockArgs p)
                     for (int e = 0; e < 8; ++e) {
                         float x = v[pp][e] + ((float)h[e] + (float)l[e]);
                         x = fmaxf(x, 0.f);
+                        if (!(x <= 65504.f)) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
                         hi[e] = (_Float16)x;
                         lo[e] = (_Float16)(x - (float)hi[e]);
                     }
@@ -586,6 +590,9 @@ int srcnn_conv_block(const srcnn_block_desc *d, srcnn_stream_t stream)
     static const int env_variant = getenv("SRCNN_BLK_VARIANT") ? atoi(getenv("SRCNN_BLK_VARIANT")) : 2;
     a.flags = env_flags;
     a.stamp = debug_stamp_buffer();
+    a.range_flag = range_flag_word();
+    a.tag = d->layer_tag > 0 ? d->layer_tag : 0;
+    SRCNN_REQUIRE(a.range_flag != nullptr, "range flag allocation failed");
     if (d->C == 64) launch_block<64>(a, env_variant, st);
     else if (d->C == 128) launch_block<128>(a, env_variant, st);
     else launch_block<256>(a, env_variant, st);

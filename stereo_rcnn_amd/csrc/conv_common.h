@@ -26,6 +26,8 @@ struct ConvArgs {
     int kt_per_split; // K tiles per grid.y slice
     int mtiles, ntiles;
     unsigned long long *stamp;   // debug: per-workgroup phase timestamps (conv_f16s only), normally nullptr
+    unsigned *range_flag;        // SPLIT16 range guard (see split16_guard); never null for SPLIT16 outputs
+    int tag;                     // caller's layer tag (>= 0): the flag keeps the largest tag + 1 that tripped
 };
 
 
@@ -97,6 +99,24 @@ __device__ __forceinline__ void act_store8(void *base, int fmt, size_t pixel, in
         *reinterpret_cast<h8 *>(p + 16) = lo;
     }
 }
+
+// SPLIT16 range guard.  hi = f16(v) has no scaling: |v| > 65504 (or a NaN) turns into inf and poisons every product it
+// enters, where the fp32 engine would carry on.  Every kernel that WRITES the format from fresh arithmetic (the conv
+// epilogues, upsample_add) calls this on the 8 values of a group; one atomicMax per offending group leaves (layer tag + 1) in a
+// library-owned device word (srcnn_range_flag_read), so that the host can re-run the forward on the exact fp32 engine
+// instead of returning garbage.  In range -- the normal case -- it costs 8 max + 1 compare per group and no memory access.
+__device__ __forceinline__ void split16_guard(const float8 &r, unsigned *flag, int tag)
+{
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(r.v[e]));
+    bool bad = !(m <= 65504.f);                 // also true for NaN
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bad = bad || (r.v[e] != r.v[e]);
+    if (bad) atomicMax(flag, (unsigned)(tag + 1));
+}
+
+unsigned *range_flag_word();   // core.hip: library-owned, zero-initialised device word
 
 struct Plan {
     int mr, nr, splits, kt_per_split;   // workgroup tile (64*mr) x (64*nr); K slices

@@ -476,6 +476,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                         const int oh = rem / p.OW, ow = rem - oh * p.OW;
                         opix = ((size_t)bb * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
                     }
+                    if (OUT_SPLIT) split16_guard(v, p.range_flag, p.tag);
                     act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + co) >> 3, v);
                 }
             }
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                 if (p.mode == 0) {
                     if (p.res) v += act_load(p.res, p.res_fmt, (size_t)row, p.rcs, col);
                     if (p.relu) v = fmaxf(v, 0.f);
+                    if (OUT_SPLIT && !(fabsf(v) <= 65504.f)) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
                     act_store(p.y, OUT_SPLIT ? 1 : 0, (size_t)row, p.ycs, p.yco + col, v);
                 } else {
                     const int cq = p.Cout >> 2;
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                     const int oh = rem / p.OW, ow = rem - oh * p.OW;
                     const size_t opix = ((size_t)b * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
                     if (p.relu) v = fmaxf(v, 0.f);
+                    if (OUT_SPLIT && !(fabsf(v) <= 65504.f)) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
                     act_store(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, p.yco + co, v);
                 }
             }

@@ -325,6 +325,12 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     if (d->precision == 1 && a.x_fmt == 0) SRCNN_REQUIRE(a.y_fmt == 0 && a.res_fmt == 0, "f16x3 with F32 input writes F32");
     a.zero_page = nullptr;
     a.stamp = debug_stamp_buffer();
+    a.range_flag = nullptr;
+    a.tag = d->layer_tag > 0 ? d->layer_tag : 0;
+    if (a.y_fmt == 1) {
+        a.range_flag = range_flag_word();
+        SRCNN_REQUIRE(a.range_flag != nullptr, "range flag allocation failed");
+    }
     if (d->precision == 1 && a.x_fmt == 1) {
         a.zero_page = zero_page();
         SRCNN_REQUIRE(a.zero_page != nullptr, "zero page allocation failed");

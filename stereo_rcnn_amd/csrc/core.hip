@@ -129,6 +129,18 @@ void program_add_memset(Program *p, void *dst, int value, size_t bytes, hipStrea
     p->nodes.push_back(std::move(n));
 }
 
+unsigned *range_flag_word()
+{
+    static unsigned *word = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!word) {
+        if (hipMalloc(reinterpret_cast<void **>(&word), 256) != hipSuccess) return nullptr;
+        (void)hipMemset(word, 0, 256);
+    }
+    return word;
+}
+
 static unsigned long long *g_stamp = nullptr;
 unsigned long long *debug_stamp_buffer() { return g_stamp; }
 
@@ -140,6 +152,18 @@ extern "C" {
 SRCNN_API void srcnn_debug_set_stamp_buffer(void *buf) { srcnn::g_stamp = static_cast<unsigned long long *>(buf); }
 
 int srcnn_version(void) { return 200; }
+
+int srcnn_range_flag_read(int reset)
+{
+    unsigned *w = srcnn::range_flag_word();
+    if (!w) return SRCNN_ERR_HIP;
+    unsigned v = 0;
+    if (hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return SRCNN_ERR_HIP;
+    if (reset && v) (void)hipMemset(w, 0, sizeof(v));
+    return (int)v;
+}
+
+const void *srcnn_range_flag_device_word(void) { return srcnn::range_flag_word(); }
 
 // ---- launch programs (include/srcnn_hip.h)
 void *srcnn_program_create(void) { return new srcnn::Program(); }

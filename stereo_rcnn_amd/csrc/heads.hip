@@ -200,14 +200,18 @@ __global__ void pack_detections_kernel(const float *__restrict__ scores, const f
                                        const float *__restrict__ boxes_r, const float *__restrict__ dim_orien,
                                        const float *__restrict__ kpts, const int *__restrict__ keep_idx,
                                        const int *__restrict__ num, int n, int ncls, int j, int cols,
-                                       float *__restrict__ rec)
+                                       float *__restrict__ rec, const unsigned *__restrict__ range_flag)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;     // record row, 0..n
     if (r > n) return;
     float *o = rec + (size_t)r * cols;
     for (int c = 0; c < cols; ++c) o[c] = 0.f;
     const int k = *num;
-    if (r == 0) { o[0] = (float)k; return; }
+    if (r == 0) {
+        o[0] = (float)k;
+        o[1] = (float)*range_flag;           // SPLIT16 range guard of the forward that produced these detections (0 = clean)
+        return;
+    }
     if (r - 1 >= k) return;
     const int i = keep_idx[r - 1];
     o[0] = scores[(size_t)i * ncls + j];
@@ -290,7 +294,8 @@ int srcnn_pack_detections(const float *scores, const float *boxes_left, const fl
     SRCNN_REQUIRE(scores && boxes_left && boxes_right && dim_orien && kpts && keep_idx && num_keep && rec, "null pointer");
     SRCNN_REQUIRE(rec_cols >= 20 && n > 0 && j >= 0 && j < n_cls, "bad sizes (rec_cols >= 20)");
     SRCNN_LAUNCH(pack_detections_kernel, dim3(cdiv(n + 1, 128)), dim3(128), 0, as_stream(stream), scores,
-                       boxes_left, boxes_right, dim_orien, kpts, keep_idx, num_keep, n, n_cls, j, rec_cols, rec);
+                       boxes_left, boxes_right, dim_orien, kpts, keep_idx, num_keep, n, n_cls, j, rec_cols, rec,
+                       static_cast<const unsigned *>(srcnn_range_flag_device_word()));
     return check_launch("srcnn_pack_detections");
 }
 

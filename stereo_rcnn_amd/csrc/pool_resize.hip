@@ -109,7 +109,8 @@ __global__ void maxpool3x3s2_kernel(const float *__restrict__ x, int B, int H, i
 // grid (ceil(W * C/8 / 256), B * H): one output row per blockIdx.y, so the row geometry (source rows, vertical weights) is
 // wave-uniform and the per-thread index arithmetic is one division by the group count.
 __global__ void upsample_add_kernel(const float *__restrict__ top, int TH, int TW, const float *__restrict__ lat,
-                                    int B, int H, int W, int C, float *__restrict__ y, int top_fmt, int yfmt)
+                                    int B, int H, int W, int C, float *__restrict__ y, int top_fmt, int yfmt,
+                                    unsigned *__restrict__ range_flag)
 {
     (void)B;
     const float rh = H > 1 ? (float)(TH - 1) / (float)(H - 1) : 0.f;
@@ -137,6 +138,7 @@ __global__ void upsample_add_kernel(const float *__restrict__ top, int TH, int T
 #pragma unroll
     for (int e = 0; e < 8; ++e)
         o.v[e] = (h0l * (w0l * a.v[e] + w1l * bb.v[e]) + h1l * (w0l * cc.v[e] + w1l * d.v[e])) + l.v[e];
+    if (yfmt == 1) split16_guard(o, range_flag, 9000);        // a sum of two in-range maps can leave the f16 range
     act_store8(y, yfmt, pix, C, g, o);
 }
 
@@ -338,7 +340,7 @@ int srcnn_upsample_add(const float *top, int TH, int TW, const float *lateral, i
     SRCNN_REQUIRE((unsigned)top_format <= 1 && (unsigned)y_format <= 1, "bad format");
     SRCNN_REQUIRE((long long)B * H <= 65535 && (long long)W * (C / 8) < (1LL << 31), "map too large");
     SRCNN_LAUNCH(upsample_add_kernel, dim3((W * (C / 8) + 255) / 256, B * H), dim3(256), 0, as_stream(stream), top, TH, TW,
-                       lateral, B, H, W, C, y, top_format, y_format);
+                       lateral, B, H, W, C, y, top_format, y_format, range_flag_word());
     return check_launch("srcnn_upsample_add");
 }
 

@@ -94,6 +94,35 @@ class FlopCounter(object):
     launches = 0
 
 
+# ---- SPLIT16 range guard (include/srcnn_hip.h: srcnn_range_flag_read): layers are tagged by name so that a tripped flag
+# can be reported as the layer that produced the out-of-range activation
+TAG_NAMES = {9001: 'upsample_add'}
+_TAG_IDS = {}
+
+
+def layer_tag(name):
+    if name is None:
+        return 0
+    t = _TAG_IDS.get(name)
+    if t is None:
+        t = _TAG_IDS[name] = len(_TAG_IDS) + 1
+        TAG_NAMES[t + 1] = name                 # the flag holds tag + 1
+    return t
+
+
+class Split16RangeError(RuntimeError):
+    """An activation left the range the SPLIT16 format can hold (|v| > 65504 or NaN): the f16x3 results of that forward are
+    not valid; re-run it with precision 'f32'."""
+
+
+def range_flag(reset=True):
+    """(flag, layer name): flag 0 = every SPLIT16 tensor written since the last reset was in range.  Synchronises the device."""
+    v = _lib.lib().srcnn_range_flag_read(1 if reset else 0)
+    if v < 0:
+        _lib.check(v, "srcnn_range_flag_read")
+    return v, (TAG_NAMES.get(v, 'layer tag %d' % (v - 1)) if v else None)
+
+
 PRECISION = 'f32'     # default engine: 'f32' (exact fp32 MFMA) or 'f16x3' (3-term split on the f16 MFMA)
 
 # ---- per-shape launch-plan autotuning ("measure, don't guess"): every distinct conv shape is timed
@@ -191,7 +220,7 @@ def _tune(d, key, device):
 
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
-           res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None):
+           res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
     *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h)."""
     L = _lib.lib()
@@ -217,6 +246,7 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     d.relu = cw.relu if relu is None else int(relu)
     d.mode = cw.mode
     d.x_format, d.y_format, d.res_format = x_fmt, y_fmt, res_fmt
+    d.layer_tag = layer_tag(name)
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
@@ -243,7 +273,7 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
 FUSE_BLOCKS = False
 
 
-def conv_block(conv2, conv3, x, B, H, W, y, residual):
+def conv_block(conv2, conv3, x, B, H, W, y, residual, name=None):
     """Fused bottleneck tail (srcnn_conv_block): y = relu(conv3(relu(conv2(x))) + residual), SPLIT16 activations."""
     assert conv2.kh == 3 and conv2.stride == 1 and conv2.pad == 1 and conv3.kh == 1 and conv3.cout == 4 * conv2.cout
     conv2.split_f16x3()
@@ -253,6 +283,7 @@ def conv_block(conv2, conv3, x, B, H, W, y, residual):
     d.w2_hi, d.w2_lo, d.bias2, d.w2_inv_scale = conv2.w_hi.data_ptr(), conv2.w_lo.data_ptr(), conv2.bias.data_ptr(), conv2.inv_scale
     d.w3_hi, d.w3_lo, d.bias3, d.w3_inv_scale = conv3.w_hi.data_ptr(), conv3.w_lo.data_ptr(), conv3.bias.data_ptr(), conv3.inv_scale
     d.B, d.H, d.W, d.C = B, H, W, conv2.cout
+    d.layer_tag = layer_tag(name)
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * H * W * (conv2.cout * conv2.alg_k + conv3.cout * conv3.alg_k)
         FlopCounter.launches += 1

@@ -168,7 +168,7 @@ class Plan(object):
             engine.stem_pack(self.im_right, self.packed, self.B, out_fmt=f)
         self.packed_fmt = -1                          # consumed: the next forward packs again unless set_images() ran
         sh, sw = self.stem_hw
-        engine.conv2d(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, x_cstride=4, x_fmt=f)
+        engine.conv2d(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, x_cstride=4, x_fmt=f, name='stem')
         ph, pw = self.c1_hw
         engine.maxpool3x3s2_ceil(self.stem_out, N, sh, sw, 64, self.c1, ph, pw, y_fmt=f)
         x, xh, xw = self.c1, ph, pw
@@ -177,26 +177,27 @@ class Plan(object):
             bufs = self.layer_bufs[li]
             cur, nxt = bufs['a'], bufs['b']
             for bi, blk in enumerate(blocks):
-                engine.conv2d(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, x_fmt=f, y_fmt=f)
+                nm = 'layer%d.%d.' % (li + 1, bi)
+                engine.conv2d(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, x_fmt=f, y_fmt=f, name=nm + 'conv1')
                 if f and engine.FUSE_BLOCKS and blk['conv2'].cout in self.fuse_channels:
                     # conv2 + conv3 (+ residual, ReLU) in one launch: the C-channel map stays in LDS (csrc/conv_block.hip)
                     if blk['down'] is not None:
-                        engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f)
+                        engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f, name=nm + 'downsample')
                         res = nxt
                     else:
                         res = x
-                    engine.conv_block(blk['conv2'], blk['conv3'], bufs['m1'], N, h, w_, cur, res)
+                    engine.conv_block(blk['conv2'], blk['conv3'], bufs['m1'], N, h, w_, cur, res, name=nm + 'conv2+conv3')
                     x, xh, xw = cur, h, w_
                     cur, nxt = nxt, cur
                     continue
-                engine.conv2d(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, x_fmt=f, y_fmt=f)
+                engine.conv2d(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, x_fmt=f, y_fmt=f, name=nm + 'conv2')
                 if blk['down'] is not None:
-                    engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f)
+                    engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f, name=nm + 'downsample')
                     res = nxt
                 else:
                     res = x
                 engine.conv2d(blk['conv3'], bufs['m2'], N, h, w_, cur, h, w_, residual=res, x_fmt=f, y_fmt=f,
-                              res_fmt=f)
+                              res_fmt=f, name=nm + 'conv3')
                 x, xh, xw = cur, h, w_
                 cur, nxt = nxt, cur
             self.c[li] = x
@@ -233,9 +234,9 @@ class Plan(object):
         h, w_ = self.rpn_shapes[l]
         cat, hd = self.rpn_cat[l], self.rpn_hd[l]
         off = sum(3 * a * b for a, b in self.rpn_shapes[:l])
-        engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f)
+        engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
         engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
-                      x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f)
+                      x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
         engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_, x_fmt=f)
         _lib.check(_lib.lib().srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(),
                                               self.deltas.data_ptr(), off, self.A, _lib.stream()), "srcnn_rpn_score")
@@ -256,7 +257,7 @@ class Plan(object):
                 for i, (cin, (h, w_)) in enumerate(((c4, (h4, w4)), (c3, (h3, w3)), (c2, (h2, w2)))):
                     engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)     # lateral stays F32
                     lat_done.append(self._signal(s_lat))
-        engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, x_fmt=f, y_fmt=f)
+        engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, x_fmt=f, y_fmt=f, name='fpn.toplayer')
         h6, w6 = self.rpn_shapes[4]
         engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                              # stereo_rcnn.py:168
         if par:
@@ -276,7 +277,7 @@ class Plan(object):
             else:
                 engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)
             engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i], top_fmt=f, y_fmt=f)   # stereo_rcnn.py:91-108
-            engine.conv2d(w.smooth[i], self.summed[i], N, h, w_, out, h, w_, x_fmt=f, y_fmt=f)
+            engine.conv2d(w.smooth[i], self.summed[i], N, h, w_, out, h, w_, x_fmt=f, y_fmt=f, name='fpn.smooth%d' % (i + 1))
             if i + 1 < 3:
                 tops[i + 1] = (out, h, w_)
             level = 2 - i                        # p4 -> RPN level 2, p3 -> 1, p2 -> 0
@@ -332,8 +333,8 @@ class Plan(object):
         P = cfg.POOLING_SIZE
         self._pyramid(False, self.rois_left, P, self.sem, 512, 0)        # stereo_rcnn.py:248-249
         self._pyramid(True, self.rois_right, P, self.sem, 512, 256)
-        engine.conv2d(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, x_fmt=f, y_fmt=f)   # 7x7/7 conv == GEMM (resnet.py:257)
-        engine.conv2d(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, x_fmt=f, y_fmt=f)
+        engine.conv2d(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, x_fmt=f, y_fmt=f, name='box.top0')   # 7x7/7 conv == GEMM (resnet.py:257)
+        engine.conv2d(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, x_fmt=f, y_fmt=f, name='box.top3')
         engine.conv2d(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, x_fmt=f)
         _lib.check(_lib.lib().srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, w.fc.cout,
                                                  self.cls_prob.data_ptr(), _lib.stream()), "srcnn_softmax_rows")
@@ -346,9 +347,9 @@ class Plan(object):
         s = 2 * P
         for i, cw in enumerate(w.kpts):
             y = self.kp_a if i % 2 == 0 else self.kp_b
-            engine.conv2d(cw, x, R, s, s, y, s, s, x_fmt=f, y_fmt=f)
+            engine.conv2d(cw, x, R, s, s, y, s, s, x_fmt=f, y_fmt=f, name='kpts.%d' % (2 * i))
             x = y
-        engine.conv2d(w.kpts_up, x, R, s, s, self.kp_up, s, s, x_fmt=f, y_fmt=f)
+        engine.conv2d(w.kpts_up, x, R, s, s, self.kp_up, s, s, x_fmt=f, y_fmt=f, name='kpts.deconv')
         G = cfg.KPTS_GRID
         engine.conv2d(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, x_fmt=f)
         _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, self.kpts_prob.data_ptr(),

@@ -160,6 +160,14 @@ class _StereoRCNN(nn.Module):
         plan.set_images(img_left_u8, img_right_u8, self.precision, short)
         return self._run(plan), plan.im_left, plan.im_right, plan.im_info
 
+    def check_range(self, reset=True):
+        """SPLIT16 range guard of the f16x3 engine (engine.range_flag): raises engine.Split16RangeError naming the layer if an
+        activation of a forward since the last reset left the f16 range (the results are then invalid: re-run with precision
+        'f32').  Synchronises the device.  The 3-D pipeline checks the same flag through the detection record instead."""
+        flag, name = engine.range_flag(reset)
+        if flag:
+            raise engine.Split16RangeError('SPLIT16 range exceeded in %s' % name)
+
     def _run(self, plan):
         plan.run(self.use_graph, self.precision, getattr(self, 'use_program', False))
         o = plan.outputs()

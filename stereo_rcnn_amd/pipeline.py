@@ -189,6 +189,10 @@ def collect_3d(st):
     """Wait for a launch_3d() handle and turn its record into the object list detect_3d returns."""
     st.event.synchronize()
     rec, state = st.rec_host.numpy(), st.state_host.numpy()
+    if rec[0, 1] > 0:           # SPLIT16 range guard tripped during this (or a concurrently running) forward
+        from . import engine
+        flag, name = engine.range_flag(reset=True)
+        raise engine.Split16RangeError('SPLIT16 range exceeded in %s' % (name or engine.TAG_NAMES.get(int(rec[0, 1]), '?')))
     k = int(rec[0, 0])
     objs = []
     for i in range(k):
@@ -278,11 +282,23 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
     if solver in ('scipy', 'host'):
         return _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
                                 dense_align, pool if solver == 'scipy' else None, native=(solver == 'host'))
+    from . import engine
     with torch.no_grad():
         out = model(im_left_data, im_right_data, im_info, slot=slot)
         st = launch_3d(out, im_left_data, im_right_data, im_info, _scale32(im_info), calib, im_shape, eval_thresh,
                        class_index, dense_align, slot)
-    return collect_3d(st)
+    try:
+        return collect_3d(st)
+    except engine.Split16RangeError:
+        if model.precision == 'f32':
+            raise
+        # an activation left the f16 range: this pair again on the exact fp32 engine (F32 activations), never garbage
+        prev, model.precision = model.precision, 'f32'
+        try:
+            return detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
+                             dense_align, pool, solver, slot)
+        finally:
+            model.precision = prev
 
 
 def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, class_index=1, dense_align=True, slot=0,
@@ -307,12 +323,31 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
         for objs in _detect_3d_stream_scipy(model, frames, pool, eval_thresh, class_index, dense_align, min(slots, 2)):
             yield objs
         return
+    from . import engine
     streams = [torch.cuda.Stream() for _ in range(max(1, slots))]
     inflight = collections.deque()
+
+    def finish(entry):
+        st, frame = entry
+        try:
+            return collect_3d(st)
+        except engine.Split16RangeError:
+            if model.precision == 'f32':
+                raise
+            torch.cuda.synchronize()                           # the SPLIT16 range guard tripped: this pair again, exact fp32 engine
+            prev, model.precision = model.precision, 'f32'
+            try:
+                if len(frame) == 3:
+                    return detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align, 0)
+                return detect_3d(model, frame[0], frame[1], frame[2], frame[3], frame[4], eval_thresh, class_index, dense_align)
+            finally:
+                model.precision = prev
+                engine.range_flag(reset=True)
+
     for k, frame in enumerate(frames):
         slot = k % len(streams)
         if len(inflight) == len(streams):                      # the slot's buffers are still in use by the oldest pair
-            yield collect_3d(inflight.popleft())
+            yield finish(inflight.popleft())
         s = streams[slot]
         s.wait_stream(torch.cuda.current_stream())
         with torch.no_grad(), torch.cuda.stream(s):
@@ -323,9 +358,9 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
                 scale = float(np.float32(frame[5])) if len(frame) > 5 else _scale32(info)
                 out = model(l, r, info, slot=slot)
                 st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot)
-        inflight.append(st)
+        inflight.append((st, frame))
     while inflight:
-        yield collect_3d(inflight.popleft())
+        yield finish(inflight.popleft())
 
 
 class _Pair(object):

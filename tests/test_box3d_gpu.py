@@ -223,3 +223,32 @@ def test_streaming_equals_serial_and_images_entry(dev):
         for x, y in zip(want, got):
             assert np.array_equal(x['box_left'], y['box_left']) and x['aligned'] == y['aligned']
             assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta']
+
+
+def test_pipeline_falls_back_to_fp32_when_the_split16_range_is_exceeded(dev):
+    """An input whose activations leave the f16 range (image scaled x2000): the default engine's forward trips the range guard,
+    detect_3d notices it in the detection record and redoes the pair on the exact fp32 engine -- same objects as asking for
+    precision 'f32' directly, never inf / NaN garbage."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import engine, fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    l, r, info = fixture.make_inputs(3, 120, 400, target_short=192)
+    l, r = (l * 2000.0).to(dev), (r * 2000.0).to(dev)
+    args = (mdl, l, r, info.to(dev), calib, (120, 400, 3))
+    engine.range_flag(reset=True)
+    with torch.no_grad():
+        mdl(l, r, info.to(dev))
+    flag, name = engine.range_flag(reset=True)
+    assert flag > 0 and name is not None, (flag, name)
+    print('range guard tripped in', name)
+    with pytest.raises(engine.Split16RangeError):
+        with torch.no_grad():
+            mdl(l, r, info.to(dev))
+        mdl.check_range()
+    got = pipeline.detect_3d(*args)                       # default engine -> guard -> fp32 re-run
+    assert mdl.precision == 'f16x3' and engine.range_flag()[0] == 0
+    mdl.precision = 'f32'
+    want = pipeline.detect_3d(*args)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert np.array_equal(a['box_left'], b['box_left']) and np.array_equal(a['xyz'], b['xyz'])

@@ -412,3 +412,62 @@ def test_fused_bottleneck_tail_equals_the_two_convolutions(dev, C, B, H, W):
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), c2.weight.permute(0, 3, 1, 2), c2.bias, padding=1).relu()
     ref = (torch.nn.functional.conv2d(ref, c3.weight.permute(0, 3, 1, 2), c3.bias) + res.permute(0, 3, 1, 2)).relu()
     assert float((a.permute(0, 3, 1, 2) - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+def _conv_ref64(x_nhwc, cw):
+    w = cw.weight.double().permute(0, 3, 1, 2)
+    y = torch.nn.functional.conv2d(x_nhwc.double().permute(0, 3, 1, 2), w, cw.bias.double(), stride=cw.stride, padding=cw.pad)
+    return (y.relu() if cw.relu else y).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 1e3])
+@pytest.mark.parametrize("k", [1, 3])
+def test_split16_dynamic_range_trained_like_weights(dev, scale, k):
+    """the f16x3 / SPLIT16 engine with activations scaled x1e-3 and x1e3 and a trained-like weight
+    distribution (frozen-BN per-channel gains spanning 1e-2 .. 16 folded into the weights) against float64 convolution,
+    through two chained layers so that the re-split SPLIT16 intermediate is exercised.  The range guard stays clear."""
+    from stereo_rcnn_amd import _lib, engine
+    g = torch.Generator().manual_seed(int(k * 10 + abs(torch.log10(torch.tensor(scale)).item())))
+    C = 128
+    mk = lambda cout, cin, kk: torch.randn(cout, cin, kk, kk, generator=g) * (2.0 / (cin * kk * kk)) ** 0.5
+    gain = lambda c: 10.0 ** (torch.rand(c, generator=g) * 3.2 - 2.0)
+    bn = lambda c: {'weight': gain(c), 'bias': torch.randn(c, generator=g) * 0.1 * scale,
+                    'running_mean': torch.randn(c, generator=g) * 0.1 * scale, 'running_var': torch.ones(c)}
+    c1 = engine.prep_conv(mk(C, C, k), None, 1, k // 2, True, bn(C), dev)
+    c2 = engine.prep_conv(mk(C, C, 1), None, 1, 0, False, bn(C), dev)
+    B, H, W = 1, 24, 40
+    x = (torch.randn(B, H, W, C, generator=g) * scale).to(dev)
+    S = _lib.FMT_SPLIT16
+    engine.range_flag(reset=True)
+    xs = engine.act_convert(x, 0, S)
+    mid, out = torch.empty_like(xs), torch.empty_like(xs)
+    engine.conv2d(c1, xs, B, H, W, mid, H, W, precision='f16x3', x_fmt=S, y_fmt=S, name='range.c1')
+    engine.conv2d(c2, mid, B, H, W, out, H, W, precision='f16x3', x_fmt=S, y_fmt=S, name='range.c2')
+    got = engine.act_convert(out, S, 0).double()
+    ref = _conv_ref64(_conv_ref64(x, c1).float(), c2)
+    flag, name = engine.range_flag(reset=True)
+    assert flag == 0, name
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print('scale %g k=%d: max |err| / max |ref| = %.2e (max |ref| %.3g)' % (scale, k, err, float(ref.abs().max())))
+    assert err < (2e-6 if scale >= 1.0 else 1e-4), err       # below ~6e-5 the f16 halves are subnormal: absolute floor 3e-8
+
+
+def test_split16_range_guard_trips_and_names_the_layer(dev):
+    """An activation beyond +-65504 cannot be held by SPLIT16 (hi = f16(v) = inf): the guard records the layer that produced it."""
+    from stereo_rcnn_amd import _lib, engine
+    g = torch.Generator().manual_seed(1)
+    C = 64
+    cw = engine.prep_conv(torch.randn(C, C, 1, 1, generator=g), torch.zeros(C), 1, 0, False, None, dev)
+    S = _lib.FMT_SPLIT16
+    x = torch.randn(1, 8, 8, C, generator=g).to(dev)
+    y = torch.empty_like(x)
+    engine.range_flag(reset=True)
+    engine.conv2d(cw, engine.act_convert(x * 100.0, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=S, name='guard.fine')
+    assert engine.range_flag(reset=True) == (0, None)
+    engine.conv2d(cw, engine.act_convert(x * 2.0e4, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=S, name='guard.hot')
+    flag, name = engine.range_flag(reset=False)
+    assert flag > 0 and name == 'guard.hot'
+    assert engine.range_flag(reset=True)[0] == flag and engine.range_flag()[0] == 0        # sticky until reset
+    # F32 output of the same layer is not subject to the format's range
+    engine.conv2d(cw, engine.act_convert(x * 2.0e4, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=0, name='guard.f32out')
+    assert engine.range_flag()[0] == 0 and torch.isfinite(y).all()
