@@ -160,7 +160,8 @@ SRCNN_API int srcnn_conv_block(const srcnn_block_desc *d, srcnn_stream_t stream)
 /* SPLIT16 range guard.  The format stores hi = f16(v) unscaled: an activation beyond +-65504 (or a NaN) becomes inf and
  * poisons what it touches, where the fp32 engine would carry on.  Every kernel that writes SPLIT16 from fresh arithmetic
  * records it: a library-owned device word keeps max(layer_tag + 1) over the launches that produced such a value since
- * the last reset (0 = every SPLIT16 tensor was in range; 9001 = srcnn_upsample_add).  srcnn_range_flag_read copies the word
+ * the last reset (0 = every SPLIT16 tensor was in range; 9001 = srcnn_upsample_add, 9002 = an input converted by
+ * srcnn_stem_pack / srcnn_act_convert; a NaN is looked for BEFORE a ReLU, which would turn it into 0).  srcnn_range_flag_read copies the word
  * to the host (it SYNCHRONISES the device) and optionally clears it; srcnn_pack_detections also drops it into
  * rec[0][1], so that the 3-D flow sees it without an extra copy.  A caller that finds it set re-runs the pair with
  * desc.precision = 0 (exact fp32 engine, F32 activations): stereo_rcnn_amd/pipeline.py does. */

@@ -465,10 +465,16 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
                             for (int e = 0; e < 8; ++e) v.v[e] += (float)hi[e] + (float)lo[e];
                         }
                     }
+                    bool nan_pre = false;                        // fmaxf(NaN, 0) = 0: look before the ReLU launders an inf - inf
+                    if (OUT_SPLIT) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) nan_pre = nan_pre || (v.v[e] != v.v[e]);
+                    }
                     if (p.relu) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
                     }
+                    if (OUT_SPLIT && nan_pre) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
                     size_t opix = (size_t)row;
                     if (p.mode == 1) {                           // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j)
                         const int ohw = p.OH * p.OW;

@@ -36,7 +36,8 @@ __global__ void stem_pack_kernel(const float *__restrict__ im, int B, int H, int
 // start of each ROW (the row pitch, (W+8)*16 B, need not be a multiple of 32 B): every 8-pixel tap run of the stride-2
 // stem starts on an even pixel, i.e. on a group boundary.  An odd last pixel of a row is never read by the stem and
 // is not written.
-__global__ void stem_pack_split16_kernel(const float *__restrict__ im, int B, int H, int W, char *__restrict__ out)
+__global__ void stem_pack_split16_kernel(const float *__restrict__ im, int B, int H, int W, char *__restrict__ out,
+                                        unsigned *__restrict__ range_flag)
 {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const int HP = H + 6, WP = W + 8, GP = WP / 2;
@@ -63,11 +64,14 @@ __global__ void stem_pack_split16_kernel(const float *__restrict__ im, int B, in
             }
         }
         h8 hi, lo;
+        float8 chk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+            chk.v[e] = v[e];
             hi[e] = (_Float16)v[e];
             lo[e] = (_Float16)(v[e] - (float)hi[e]);
         }
+        split16_guard(chk, range_flag, 9001);            // an input image beyond the f16 range: flag 9002 = input conversion
         char *dst = out + ((size_t)b * HP + yp) * WP * 16 + (size_t)gp * 32;
         *reinterpret_cast<h8 *>(dst) = hi;
         *reinterpret_cast<h8 *>(dst + 16) = lo;
@@ -144,7 +148,7 @@ __global__ void upsample_add_kernel(const float *__restrict__ top, int TH, int T
 
 // NHWC activation format conversion on 8-channel groups
 __global__ void act_convert_kernel(const void *__restrict__ x, int xfmt, void *__restrict__ y, int yfmt, size_t pixels,
-                                   int C)
+                                   int C, unsigned *__restrict__ range_flag)
 {
     const int G = C / 8;
     const size_t total = pixels * G;
@@ -152,7 +156,9 @@ __global__ void act_convert_kernel(const void *__restrict__ x, int xfmt, void *_
          idx += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = idx / G;
         const int g = (int)(idx - pix * G);
-        act_store8(y, yfmt, pix, C, g, act_load8(x, xfmt, pix, C, g));
+        const float8 v = act_load8(x, xfmt, pix, C, g);
+        if (yfmt == 1 && xfmt == 0) split16_guard(v, range_flag, 9001);
+        act_store8(y, yfmt, pix, C, g, v);
     }
 }
 
@@ -310,7 +316,7 @@ int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, int o
     if (out_format == 1) {
         const size_t groups = (size_t)B * (H + 6) * ((W + 8) / 2);
         SRCNN_LAUNCH(stem_pack_split16_kernel, dim3(grid_for(groups, 256)), dim3(256), 0, as_stream(stream), im_nchw, B,
-                           H, W, reinterpret_cast<char *>(out));
+                           H, W, reinterpret_cast<char *>(out), range_flag_word());
         return check_launch("srcnn_stem_pack");
     }
     const size_t total = (size_t)B * (H + 6) * (W + 8);
@@ -353,7 +359,7 @@ int srcnn_act_convert(const void *x, int x_format, void *y, int y_format, long l
     if (pixels == 0) return SRCNN_OK;
     const size_t total = (size_t)pixels * (C / 8);
     SRCNN_LAUNCH(act_convert_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, x_format, y,
-                       y_format, (size_t)pixels, C);
+                       y_format, (size_t)pixels, C, range_flag_word());
     return check_launch("srcnn_act_convert");
 }
 

@@ -96,7 +96,7 @@ class FlopCounter(object):
 
 # ---- SPLIT16 range guard (include/srcnn_hip.h: srcnn_range_flag_read): layers are tagged by name so that a tripped flag
 # can be reported as the layer that produced the out-of-range activation
-TAG_NAMES = {9001: 'upsample_add'}
+TAG_NAMES = {9001: 'upsample_add', 9002: 'input conversion to SPLIT16 (stem_pack / act_convert)'}
 _TAG_IDS = {}
 
 

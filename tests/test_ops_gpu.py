@@ -430,7 +430,8 @@ def test_split16_dynamic_range_trained_like_weights(dev, scale, k):
     g = torch.Generator().manual_seed(int(k * 10 + abs(torch.log10(torch.tensor(scale)).item())))
     C = 128
     mk = lambda cout, cin, kk: torch.randn(cout, cin, kk, kk, generator=g) * (2.0 / (cin * kk * kk)) ** 0.5
-    gain = lambda c: 10.0 ** (torch.rand(c, generator=g) * 3.2 - 2.0)
+    # gains 1e-2 .. 16 (1e-2 .. 2 at x1e3, where two layers of gain 16 would legitimately leave the f16 range: see the guard test)
+    gain = lambda c: 10.0 ** (torch.rand(c, generator=g) * (2.3 if scale > 1 else 3.2) - 2.0)
     bn = lambda c: {'weight': gain(c), 'bias': torch.randn(c, generator=g) * 0.1 * scale,
                     'running_mean': torch.randn(c, generator=g) * 0.1 * scale, 'running_var': torch.ones(c)}
     c1 = engine.prep_conv(mk(C, C, k), None, 1, k // 2, True, bn(C), dev)
@@ -464,10 +465,16 @@ def test_split16_range_guard_trips_and_names_the_layer(dev):
     engine.range_flag(reset=True)
     engine.conv2d(cw, engine.act_convert(x * 100.0, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=S, name='guard.fine')
     assert engine.range_flag(reset=True) == (0, None)
-    engine.conv2d(cw, engine.act_convert(x * 2.0e4, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=S, name='guard.hot')
+    hot = engine.act_convert(x * 3.0e3, 0, S)              # inputs up to ~1.2e4 (fine), outputs ~8 x that (not)
+    assert engine.range_flag()[0] == 0
+    engine.conv2d(cw, hot, 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=S, name='guard.hot')
     flag, name = engine.range_flag(reset=False)
     assert flag > 0 and name == 'guard.hot'
     assert engine.range_flag(reset=True)[0] == flag and engine.range_flag()[0] == 0        # sticky until reset
     # F32 output of the same layer is not subject to the format's range
-    engine.conv2d(cw, engine.act_convert(x * 2.0e4, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=0, name='guard.f32out')
-    assert engine.range_flag()[0] == 0 and torch.isfinite(y).all()
+    engine.conv2d(cw, hot, 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=0, name='guard.f32out')
+    assert engine.range_flag()[0] == 0 and torch.isfinite(y).all() and float(y.abs().max()) > 65504
+    # an input that cannot be represented is caught at the conversion
+    engine.act_convert(x * 1.0e5, 0, S)
+    flag, name = engine.range_flag()
+    assert flag == 9002 and 'input conversion' in name
