@@ -94,3 +94,48 @@ def gather_detections(rec, async_op=False):
     work = dist.all_gather_into_tensor(out.view(-1), rec.contiguous().view(-1), async_op=async_op) \
         if rec.is_cuda else dist.all_gather(list(out.unbind(0)), rec.contiguous(), async_op=async_op)
     return out, work
+
+
+def objects_to_record(objs, max_det=300):
+    """Host-side list of final 3-D objects (pipeline.detect_3d) -> the same fixed (max_det + 1, REC_COLS) float32 record the
+    device 3-D stage fills (include/srcnn_hip.h lists the columns): what a rank contributes to the gather of a split."""
+    import numpy as np
+    rec = np.zeros((max_det + 1, REC_COLS), np.float32)
+    k = min(len(objs), max_det)
+    rec[0, 0] = k
+    for i, o in enumerate(objs[:k]):
+        r = rec[1 + i]
+        r[0] = o['score']
+        r[1:5], r[5:9] = o['box_left'], o['box_right']
+        r[9:12] = o['dim']
+        r[12], r[13] = np.sin(o['alpha']), np.cos(o['alpha'])
+        r[14:19] = o['kpts']
+        r[19] = o.get('roi_index', -1)
+        r[20] = 1.0
+        r[21:24], r[24] = o['xyz_init'], o.get('theta_init', 0.0)
+        r[25] = 1.0 if o['aligned'] else 0.0
+        r[26] = o.get('disparity', 0.0)
+        r[27:30], r[30] = o['xyz'], o['theta']
+        r[31] = o['alpha']
+    return torch.from_numpy(rec)
+
+
+def gather_split_records(records, num_frames_total, rank, world):
+    """records: this rank's per-frame records in shard order (frame i of the split lives on rank i % world).  Returns, on every
+    rank, the (num_frames_total, max_det + 1, REC_COLS) tensor of the whole split in frame order: ONE all_gather of the padded
+    per-rank stacks (ranks own ceil or floor(N / world) frames; short stacks are zero-padded)."""
+    per = -(-num_frames_total // world)
+    shape = tuple(records[0].shape) if records else (301, REC_COLS)
+    dev = records[0].device if records else torch.device('cpu')
+    stack = torch.zeros((per,) + shape, dtype=torch.float32, device=dev)
+    for i, r in enumerate(records):
+        stack[i] = r
+    out, work = gather_detections(stack)
+    if work is not None:
+        work.wait()
+    full = torch.zeros((num_frames_total,) + shape, dtype=torch.float32, device=dev)
+    for r in range(out.shape[0]):
+        idx = shard_indices(num_frames_total, r, world if dist.is_initialized() else 1)
+        for j, frame in enumerate(idx):
+            full[frame] = out[r, j]
+    return full

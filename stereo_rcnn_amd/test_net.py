@@ -37,8 +37,11 @@ def read_png_rgb(path):
 
 
 def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4,
-              solver='device', slots=2):
+              solver='device', slots=2, detect_stream=None, records=None):
     """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds).
+    `detect_stream(frames)`: replaces the detector (a generator of object lists, one per frame) -- the CPU tests drive the
+    sharding / writer / gather logic with it; `records`: a list that receives one detection record per frame
+    (distributed.objects_to_record) for the gather of the split.
     Frames go through pipeline.detect_3d_stream: PNG decoding runs `prefetch` frames ahead on host threads, the decoded
     uint8 images are copied to the device and everything else -- preprocessing, forward, decode, NMS, borders, 4-DoF solve,
     dense alignment, 3-DoF rectification -- is device work with `slots` pairs in flight (solver='device').
@@ -70,6 +73,8 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
     def to_device(loaded):
         left, right, calib = loaded
         calibs.append(calib)
+        if detect_stream is not None:
+            return (left, right, calib)                         # injected detector: frames stay on the host
         lu, ru = torch.from_numpy(left).to(device, non_blocking=True), torch.from_numpy(right).to(device, non_blocking=True)
         if solver == 'device':
             return (lu, ru, calib)                              # preprocessing is fused in front of the forward
@@ -79,7 +84,10 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
         return (l, r, info, calib, left.shape, float(scale))
 
     def results():
-        if solver == 'device' or pool is not None:
+        if detect_stream is not None:
+            for objs in detect_stream(frames()):
+                yield objs
+        elif solver == 'device' or pool is not None:
             for objs in pipeline.detect_3d_stream(model, frames(), pool, solver=solver, slots=slots):
                 yield objs
         else:
@@ -91,9 +99,13 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
         open(os.path.join(result_dir, 'data', frame + '.txt'), 'w').close()      # a frame without detections still gets a file
         pipeline.write_kitti_results(result_dir, frame, calib, [o for o in objs if o['aligned']])   # test_net.py:322-330
         n_obj += sum(o['aligned'] for o in objs)
+        if records is not None:
+            from .distributed import objects_to_record
+            records.append(objects_to_record(objs))
         if log and (k + 1) % 50 == 0:
             log('%d/%d frames, %.1f frames/s' % (k + 1, len(ids), (k + 1) / (time.time() - t0)))
-    torch.cuda.synchronize(device)
+    if device is not None and torch.device(device).type == 'cuda':
+        torch.cuda.synchronize(device)
     return len(ids), n_obj, time.time() - t0
 
 
@@ -107,6 +119,9 @@ def main(argv=None):
                     help="3-D stage: 'device' = native Newton-CG kernels (default), 'scipy' = the reference's host arrangement")
     ap.add_argument('--solver-workers', type=int, default=0, help='scipy path: worker processes (0 = cpu_count / ranks, <= 32)')
     ap.add_argument('--precision', choices=['f16x3', 'f32'], default='f16x3')
+    ap.add_argument('--gather', action='store_true',
+                    help='after the split, all_gather the per-frame detection records (2-D + 3-D fields) over RCCL and let rank 0 '
+                         'write <result-dir>/records.pt (the per-frame KITTI files are written by the owning rank either way)')
     args = ap.parse_args(argv)
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     use_dist = 'RANK' in os.environ and world > 1
@@ -126,12 +141,19 @@ def main(argv=None):
     ids = read_split(args.split)
     mine = [ids[i] for i in shard_indices(len(ids), rank, world)]
     log = lambda s: print('[rank %d] %s' % (rank, s), flush=True)
+    records = [] if args.gather else None
     if args.solver == 'scipy':
         with pipeline.SolverPool(args.solver_workers or None) as pool:
-            frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, pool, log=log, solver='scipy')
+            frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, pool, log=log, solver='scipy',
+                                         records=records)
     else:
-        frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, log=log)
+        frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, log=log, records=records)
     print('[rank %d] %d frames, %d objects, %.1f s (%.1f frames/s)' % (rank, frames, objs, dt, frames / max(dt, 1e-9)), flush=True)
+    if args.gather:
+        from .distributed import gather_split_records
+        full = gather_split_records([r.to(device) for r in records], len(ids), rank, world)
+        if rank == 0:
+            torch.save({'ids': ids, 'records': full.cpu()}, os.path.join(args.result_dir, 'records.pt'))
     if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

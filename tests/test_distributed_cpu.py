@@ -119,3 +119,84 @@ def test_bench_self_launches_n_ranks_dry_run():
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--dry-run'], cwd=root,
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])['n_gpus'] == 1
+
+
+def _fake_objects(frame_left):
+    """Deterministic fake detections from the frame's pixels (stands in for the GPU detector in the CPU tests)."""
+    import numpy as np
+    seed = int(frame_left[0, 0, 0]) + 1
+    rng = np.random.default_rng(seed)
+    objs = []
+    for i in range(seed % 4 + 1):
+        x1, y1 = rng.uniform(0, 300), rng.uniform(20, 80)
+        objs.append({'score': float(rng.uniform(0.1, 1)), 'box_left': np.array([x1, y1, x1 + 40, y1 + 30], np.float32),
+                     'box_right': np.array([x1 - 8, y1, x1 + 32, y1 + 30], np.float32), 'dim': np.array([1.6, 1.5, 4.0]),
+                     'alpha': 0.3 * i, 'kpts': np.array([x1 + 5, 1, 0.9, x1, x1 + 40], np.float32),
+                     'xyz_init': rng.uniform(-5, 30, 3), 'theta_init': 0.1, 'xyz': rng.uniform(-5, 30, 3), 'theta': 0.2 + i,
+                     'aligned': i % 2 == 0, 'disparity': float(rng.uniform(5, 60)), 'roi_index': i})
+    return objs
+
+
+def _split_worker(rank, world, port, root, result_dir, q):
+    import numpy as np
+    from stereo_rcnn_amd import test_net
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ids = test_net.read_split(os.path.join(root, 'val.txt'))
+    mine = [ids[i] for i in sdist.shard_indices(len(ids), rank, world)]
+    records = []
+    detect = lambda frames: (_fake_objects(f[0]) for f in frames)
+    n_frames, n_obj, _ = test_net.run_split(None, root, mine, result_dir, None, detect_stream=detect, records=records)
+    full = sdist.gather_split_records(records, len(ids), rank, world)
+    q.put((rank, mine, n_obj, full.numpy() if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_kitti_split_driver_world_size_2_gloo(tmp_path):
+    """test_net.py's loop on two ranks (gloo, CPU): frames sharded i mod 2, every frame's KITTI file written by its owner, the
+    per-frame records -- 2-D detection AND the 3-D fields (x, y, z, theta, disparity, status: SURVEY 8(e)) -- gathered by one
+    all_gather so that every rank holds the whole split in frame order."""
+    import numpy as np
+    from PIL import Image
+    root = tmp_path / 'training'
+    for d in ('image_2', 'image_3', 'calib'):
+        (root / d).mkdir(parents=True)
+    ids = ['%06d' % i for i in range(5)]
+    p2 = np.array([721.5377, 0, 609.5593, 44.85728, 0, 721.5377, 172.854, 0.2163791, 0, 0, 1, 0.002745884]).reshape(3, 4)
+    p3 = p2.copy(); p3[0, 3] = -339.5242
+    row = lambda name, mat: name + ': ' + ' '.join('%.12e' % v for v in np.ravel(mat))
+    for k, frame in enumerate(ids):
+        img = np.full((40, 60, 3), k, np.uint8)
+        Image.fromarray(img).save(str(root / 'image_2' / (frame + '.png')))
+        Image.fromarray(img).save(str(root / 'image_3' / (frame + '.png')))
+        (root / 'calib' / (frame + '.txt')).write_text('\n'.join([row('P0', p2), row('P1', p2), row('P2', p2), row('P3', p3),
+                                                                 row('R0_rect', np.eye(3)), row('Tr_velo_to_cam', np.eye(3, 4))]) + '\n')
+    (root / 'val.txt').write_text('\n'.join(ids) + '\n')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, str(root), str(tmp_path / 'res'), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][1] == ['000000', '000002', '000004'] and got[1][1] == ['000001', '000003']
+    assert sorted(os.listdir(str(tmp_path / 'res' / 'data'))) == [f + '.txt' for f in ids]
+    full = got[0][3]
+    assert full.shape == (5, 301, sdist.REC_COLS)
+    total_aligned = 0
+    for k, frame in enumerate(ids):
+        objs = _fake_objects(np.full((40, 60, 3), k, np.uint8))
+        want = sdist.objects_to_record(objs).numpy()
+        assert np.array_equal(full[k], want)
+        u = sdist.unpack_records(torch.from_numpy(full[k]))
+        assert np.allclose(u['pose'][:, :3].numpy(), np.array([o['xyz'] for o in objs], np.float32))
+        lines = (tmp_path / 'res' / 'data' / (frame + '.txt')).read_text().splitlines()
+        assert len(lines) == sum(o['aligned'] for o in objs)
+        total_aligned += len(lines)
+    assert total_aligned == got[0][2] + got[1][2]
