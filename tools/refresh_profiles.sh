@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every measured artefact of a round on the GPU box into gpurun_out/<tag>/ (copy what is to be judged to profiles/).
 #   usage (inside gpurun): bash tools/refresh_profiles.sh r01
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=/root/repo
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -9,8 +9,11 @@ cd $R
 python -m oracle.build > /dev/null 2>&1
 rm -f /tmp/plans_${TAG}.json
 python bench.py --plans /tmp/plans_${TAG}.json > $O/bench_${TAG}_f16x3.json 2> $O/bench_err.log
-python bench.py --precision f32 --no-cpu-baseline > $O/bench_${TAG}_f32.json 2>> $O/bench_err.log
-python bench.py --streams 1 --no-cpu-baseline > $O/bench_${TAG}_f16x3_1inflight.json 2>> $O/bench_err.log
+python bench.py --precision f32 --no-cpu-baseline --no-f32-leg > $O/bench_${TAG}_f32.json 2>> $O/bench_err.log
+python bench.py --streams 1 --no-cpu-baseline --no-f32-leg > $O/bench_${TAG}_f16x3_1inflight.json 2>> $O/bench_err.log
+python tools/demo_pipeline.py > $O/full_pipeline_${TAG}.txt 2>&1
+python tools/enqueue_probe.py > $O/host_enqueue_${TAG}.txt 2>&1
+python tools/block_bench.py > $O/block_bench_${TAG}.txt 2>&1
 python tools/time_forward.py f16x3 > $O/stage_times_${TAG}_f16x3.txt 2>&1
 SWEEP=1 python tools/conv_bench.py f16s > $O/conv_microbench_${TAG}_f16x3_split16.txt 2>&1
 python tools/conv_bench.py f32 > $O/conv_microbench_${TAG}_f32.txt 2>&1
@@ -18,7 +21,7 @@ python tools/bench_configs.py > $O/configs_3_5_${TAG}.txt 2>&1
 python tools/nms_bench.py > $O/nms_microbench_${TAG}.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 # one pair at a time and pre-tuned plans: every conv launch in this trace is a steady-state launch, alone on the chip
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --streams 1 --plans /tmp/plans_${TAG}.json > $O/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-leg --streams 1 --plans /tmp/plans_${TAG}.json > $O/prof_bench.log 2>&1
 cp $O/prof/*kernel_stats.csv $O/${TAG}_f16x3_bench_kernel_stats.csv 2>/dev/null || find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_f16x3_bench_kernel_stats.csv \;
 python $R/tools/stats_avg.py $O/${TAG}_f16x3_bench_kernel_stats.csv > $O/${TAG}_f16x3_bench_conv_avg.txt 2>&1
 grep -o '"avg_launch_ms": [0-9.]*' $O/prof_bench.log >> $O/${TAG}_f16x3_bench_conv_avg.txt
@@ -27,7 +30,7 @@ rm -rf $O/prof
 mkdir -p $O/pmc
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   D=$O/pmc/$(echo $C | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --streams 1 --plans /tmp/plans_${TAG}.json > $D.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --streams 1 --plans /tmp/plans_${TAG}.json > $D.log 2>&1
 done
 python $R/tools/pmc_sum.py $O/pmc 5 $O/pmc_${TAG}_traffic.json > $O/pmc_${TAG}_f16x3_bench_sums.txt 2>&1
 rm -rf $O/pmc
