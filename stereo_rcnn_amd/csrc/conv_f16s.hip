@@ -77,7 +77,7 @@ extern __shared__ __attribute__((aligned(1024))) _Float16 smem[];
 // MR/NR: per-WAVE tile in 32x32 MFMA tiles; WM x 2 waves per workgroup -> workgroup tile (32*MR*WM) x (64*NR).
 // WM = 2: 4 waves (256 threads).  WM = 4: 8 waves (512 threads).  NS: LDS ring stages (NS-1 K tiles in flight).
 template <int MR, int NR, bool OUT_SPLIT, int WM, int NS>
-__global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p)
+__global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_kernel(const ConvArgs p)
 {
     constexpr int NWAVES = 2 * WM, NTHREADS = 64 * NWAVES;
     constexpr int BM = 32 * MR * WM, BN = 64 * NR;
@@ -87,7 +87,6 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     constexpr int STAGE = 2 * PANEL_A + 2 * PANEL_B;
     constexpr int LPT = 2 * (AG + BG);                        // DMA instructions per wave per K tile
     static_assert(NS >= 2 && NS <= 4 && (NS - 2) * LPT < 64, "ring depth");
-    static_assert(NS * STAGE * 2 >= BM * BN * 4, "epilogue tile must fit in the operand ring");
 
     const int t = threadIdx.x;
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;     // debug stamps (only when p.stamp is set)
@@ -388,13 +387,18 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
     // residual read and result written with 16-byte accesses (2 per group instead of 16 two-byte ones).
     const int cq = p.mode == 1 ? (p.Cout >> 2) : p.Cout;     // channels per output pixel (deconv: Cout = 4 taps x cq)
     if ((cq & 7) == 0 && (p.ycs & 7) == 0 && (p.yco & 7) == 0 && (!p.res || (p.rcs & 7) == 0)) {
-        float *tile = reinterpret_cast<float *>(smem);       // [BM][BN] floats <= the two operand stages
+        // The accumulator tile goes through the operand LDS in PASSES row blocks of RPP rows (1 pass for every tile up to
+        // 256x128; the 256x256 tile of the 4-wave / 512-register configuration does not fit at once and takes 2).
+        constexpr int PASSES = (BM * BN * 4 + NS * STAGE * 2 - 1) / (NS * STAGE * 2);
+        constexpr int RPP = BM / PASSES;
+        static_assert(BM % PASSES == 0 && RPP % (32 * MR) == 0 || PASSES == 1, "a pass is a whole number of per-wave row blocks");
+        float *tile = reinterpret_cast<float *>(smem);       // [RPP][BN] floats <= the operand ring
         // thread -> (8-channel group g, rows r0 + it * RSTEP): the group is the same in every iteration, so bias and column
         // tests are loop invariants, and the NG residual groups of the thread are independent 32-byte loads that are all
         // put in flight BEFORE the accumulators go through the LDS (one memory latency per workgroup instead of one per
         // iteration: the conv3 + residual layers of the trunk are epilogue-bound, profiles/stamp_conv_r01.txt)
-        constexpr int GROUPS = BN / 8, NG = BM * GROUPS / NTHREADS, RSTEP = NTHREADS / GROUPS;
-        static_assert(BM * GROUPS % NTHREADS == 0 && NTHREADS % GROUPS == 0, "epilogue mapping");
+        constexpr int GROUPS = BN / 8, NG = RPP * GROUPS / NTHREADS, RSTEP = NTHREADS / GROUPS;
+        static_assert(RPP * GROUPS % NTHREADS == 0 && NTHREADS % GROUPS == 0, "epilogue mapping");
         const int g = t % GROUPS, r0 = t / GROUPS;
         const int col = n0 + g * 8;
         const bool col_ok = col < p.Cout;
@@ -402,18 +406,6 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
         const int ij = p.mode == 1 ? col / cq : 0;
         const int co = col - ij * cq;
         const bool use_res = p.res && !split && col_ok;
-        uint4 res_a[NG], res_b[NG];
-#pragma unroll
-        for (int it = 0; it < NG; ++it) {
-            const int row = m0 + r0 + it * RSTEP;
-            res_a[it] = make_uint4(0, 0, 0, 0);
-            res_b[it] = make_uint4(0, 0, 0, 0);
-            if (use_res && row < p.M) {
-                const char *q = reinterpret_cast<const char *>(p.res) + ((size_t)row * p.rcs + (size_t)col) * 4;
-                res_a[it] = *reinterpret_cast<const uint4 *>(q);
-                res_b[it] = *reinterpret_cast<const uint4 *>(q + 16);
-            }
-        }
         float bias8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -424,66 +416,86 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_f16s_kernel(const ConvArgs p
             bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
         }
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int mp = m0 + ps * RPP;                    // first output row of this pass
+            uint4 res_a[NG], res_b[NG];
 #pragma unroll
-            for (int j = 0; j < NR; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int r = (wm * MR + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
-                    tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
+            for (int it = 0; it < NG; ++it) {
+                const int row = mp + r0 + it * RSTEP;
+                res_a[it] = make_uint4(0, 0, 0, 0);
+                res_b[it] = make_uint4(0, 0, 0, 0);
+                if (use_res && row < p.M) {
+                    const char *q = reinterpret_cast<const char *>(p.res) + ((size_t)row * p.rcs + (size_t)col) * 4;
+                    res_a[it] = *reinterpret_cast<const uint4 *>(q);
+                    res_b[it] = *reinterpret_cast<const uint4 *>(q + 16);
                 }
-        __syncthreads();
-        if (p.stamp) st4 = __builtin_readcyclecounter();
+            }
+            if (ps > 0) __syncthreads();                     // the previous pass has been read out of the tile
 #pragma unroll
-        for (int it = 0; it < NG; ++it) {
-            const int r = r0 + it * RSTEP;
-            const int row = m0 + r;
-            if (row < p.M && col_ok) {
-                float8 v;
-                const float4 a = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8);
-                const float4 b = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8 + 4);
-                v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
-                v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
-                if (split) {
-                    float *dst = p.partial + ((size_t)blockIdx.y * p.M + row) * p.Cout + col;
-                    *reinterpret_cast<float4 *>(dst) = a;
-                    *reinterpret_cast<float4 *>(dst + 4) = b;
-                } else {
-                    if (p.bias) {
+            for (int i = 0; i < MR; ++i) {
+                const int rb = (wm * MR + i) * 32 - ps * RPP;     // this 32-row block inside the pass (wave-uniform)
+                if (rb < 0 || rb >= RPP) continue;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v.v[e] += bias8[e];
+                for (int j = 0; j < NR; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int r = rb + (e & 3) + 8 * (e >> 2) + 4 * lg;
+                        tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
                     }
-                    if (p.res) {
-                        if (p.res_fmt == 0) {
-                            v.v[0] += __uint_as_float(res_a[it].x); v.v[1] += __uint_as_float(res_a[it].y);
-                            v.v[2] += __uint_as_float(res_a[it].z); v.v[3] += __uint_as_float(res_a[it].w);
-                            v.v[4] += __uint_as_float(res_b[it].x); v.v[5] += __uint_as_float(res_b[it].y);
-                            v.v[6] += __uint_as_float(res_b[it].z); v.v[7] += __uint_as_float(res_b[it].w);
-                        } else {                                  // SPLIT16 group: [8 x f16 hi][8 x f16 lo]
-                            const half8 hi = __builtin_bit_cast(half8, res_a[it]), lo = __builtin_bit_cast(half8, res_b[it]);
+            }
+            __syncthreads();
+            if (p.stamp && ps == 0) st4 = __builtin_readcyclecounter();
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v.v[e] += (float)hi[e] + (float)lo[e];
+            for (int it = 0; it < NG; ++it) {
+                const int r = r0 + it * RSTEP;
+                const int row = mp + r;
+                if (row < p.M && col_ok) {
+                    float8 v;
+                    const float4 a = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8);
+                    const float4 b = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8 + 4);
+                    v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
+                    v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+                    if (split) {
+                        float *dst = p.partial + ((size_t)blockIdx.y * p.M + row) * p.Cout + col;
+                        *reinterpret_cast<float4 *>(dst) = a;
+                        *reinterpret_cast<float4 *>(dst + 4) = b;
+                    } else {
+                        if (p.bias) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v.v[e] += bias8[e];
                         }
-                    }
-                    bool nan_pre = false;                        // fmaxf(NaN, 0) = 0: look before the ReLU launders an inf - inf
-                    if (OUT_SPLIT) {
+                        if (p.res) {
+                            if (p.res_fmt == 0) {
+                                v.v[0] += __uint_as_float(res_a[it].x); v.v[1] += __uint_as_float(res_a[it].y);
+                                v.v[2] += __uint_as_float(res_a[it].z); v.v[3] += __uint_as_float(res_a[it].w);
+                                v.v[4] += __uint_as_float(res_b[it].x); v.v[5] += __uint_as_float(res_b[it].y);
+                                v.v[6] += __uint_as_float(res_b[it].z); v.v[7] += __uint_as_float(res_b[it].w);
+                            } else {                                  // SPLIT16 group: [8 x f16 hi][8 x f16 lo]
+                                const half8 hi = __builtin_bit_cast(half8, res_a[it]), lo = __builtin_bit_cast(half8, res_b[it]);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) nan_pre = nan_pre || (v.v[e] != v.v[e]);
-                    }
-                    if (p.relu) {
+                                for (int e = 0; e < 8; ++e) v.v[e] += (float)hi[e] + (float)lo[e];
+                            }
+                        }
+                        bool nan_pre = false;                        // fmaxf(NaN, 0) = 0: look before the ReLU launders an inf - inf
+                        if (OUT_SPLIT) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+                            for (int e = 0; e < 8; ++e) nan_pre = nan_pre || (v.v[e] != v.v[e]);
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+                        }
+                        if (OUT_SPLIT && nan_pre) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
+                        size_t opix = (size_t)row;
+                        if (p.mode == 1) {                           // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j)
+                            const int ohw = p.OH * p.OW;
+                            const int bb = row / ohw, rem = row - bb * ohw;
+                            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                            opix = ((size_t)bb * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
+                        }
+                        if (OUT_SPLIT) split16_guard(v, p.range_flag, p.tag);
+                        act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + co) >> 3, v);
                     }
-                    if (OUT_SPLIT && nan_pre) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
-                    size_t opix = (size_t)row;
-                    if (p.mode == 1) {                           // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j)
-                        const int ohw = p.OH * p.OW;
-                        const int bb = row / ohw, rem = row - bb * ohw;
-                        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                        opix = ((size_t)bb * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
-                    }
-                    if (OUT_SPLIT) split16_guard(v, p.range_flag, p.tag);
-                    act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + co) >> 3, v);
                 }
             }
         }
@@ -564,6 +576,7 @@ bool conv_f16s_plan_ok(const Plan &pl)
     case 224: return pl.stages == 2;
     case 228: return pl.stages == 2 || pl.stages == 4;
     case 428: return pl.stages == 3;
+    case 444: return pl.stages == 2;          // 256x256 on 4 waves of 128x128: one wave per SIMD, 512 registers
     default: return false;
     }
 }
@@ -582,6 +595,7 @@ void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st)
     case 2282: launch<1, 2, 4, 2>(a, pl.splits, st); break;   // 128x128 on 8 waves of 32x64
     case 2284: launch<1, 2, 4, 4>(a, pl.splits, st); break;
     case 4283: launch<2, 2, 4, 3>(a, pl.splits, st); break;   // 256x128 on 8 waves of 64x64
+    case 4442: launch<4, 4, 2, 2>(a, pl.splits, st); break;   // 256x256 on 4 waves of 128x128
     default: launch<1, 1, 2, 2>(a, pl.splits, st); break;     // unreachable: plan_for() validates with conv_f16s_plan_ok
     }
 }

@@ -133,7 +133,7 @@ _TUNE_LOG = {}       # key -> [(plan, ms)] of the last tuning run (dev tools pri
 # (tile_mr, tile_nr, waves, stages): workgroup tile (64*mr) x (64*nr), wavefronts, LDS ring depth
 _CANDIDATES = [(2, 2, 4, 2), (2, 1, 4, 2), (1, 2, 4, 2), (1, 1, 4, 2)]
 # extra variants of the SPLIT16 engine (csrc/conv_f16s.hip): 8-wave tiles and deeper DMA rings
-_CANDIDATES_F16S = [(4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
+_CANDIDATES_F16S = [(4, 4, 4, 2), (4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
 
 
 def save_plans(path):
@@ -172,6 +172,8 @@ def _tune(d, key, device):
         tiles = _CANDIDATES_F16S + tiles
     for mr, nr, waves, stages in tiles:
         if nr == 2 and d.Cout <= 64:
+            continue
+        if nr == 4 and (d.Cout <= 128 or M < 256 * 64):       # the 256x256 tile: only where it still fills the chip
             continue
         if mr >= 2 and M <= 64 * (mr // 2):
             continue

@@ -196,6 +196,7 @@ def test_conv_engine_vs_torch_cpu(dev, case, precision):
     # (tile_mr, tile_nr, waves, stages, splits): every SPLIT16 kernel instantiation, with and without split-K
     (1, 1, 4, 2, 1), (1, 1, 4, 4, 1), (1, 1, 4, 4, 3), (2, 1, 4, 2, 1), (2, 1, 4, 3, 2), (1, 2, 4, 2, 1), (1, 2, 4, 3, 1),
     (2, 2, 4, 2, 2), (2, 2, 8, 2, 1), (2, 2, 8, 4, 1), (2, 2, 8, 4, 9), (4, 2, 8, 3, 1), (4, 2, 8, 3, 4),
+    (4, 4, 4, 2, 1), (4, 4, 4, 2, 3),       # 256x256 on 4 waves (one per SIMD, 512 registers), two-pass epilogue
 ])
 @pytest.mark.parametrize("case", [
     (2, 23, 37, 96, 200, 3, 1, 1, True, True, True),      # ragged M (1702) and N (200) tails, image-border taps
