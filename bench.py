@@ -435,7 +435,7 @@ def main():
                        'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},
             'roofline': roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU path timed beside it: rank 0 at N = 1 only
             res['cpu_baseline'] = cpu_baseline(3, args.height, args.width)
         print(json.dumps(res), flush=True)
     if args.plans and not plans_loaded and rank == 0:

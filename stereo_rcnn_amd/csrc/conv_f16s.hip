@@ -391,7 +391,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         // 256x128; the 256x256 tile of the 4-wave / 512-register configuration does not fit at once and takes 2).
         constexpr int PASSES = (BM * BN * 4 + NS * STAGE * 2 - 1) / (NS * STAGE * 2);
         constexpr int RPP = BM / PASSES;
-        static_assert(BM % PASSES == 0 && RPP % (32 * MR) == 0 || PASSES == 1, "a pass is a whole number of per-wave row blocks");
+        static_assert((BM % PASSES == 0 && RPP % (32 * MR) == 0) || PASSES == 1, "a pass is a whole number of per-wave row blocks");
         float *tile = reinterpret_cast<float *>(smem);       // [RPP][BN] floats <= the operand ring
         // thread -> (8-channel group g, rows r0 + it * RSTEP): the group is the same in every iteration, so bias and column
         // tests are loop invariants, and the NG residual groups of the thread are independent 32-byte loads that are all

@@ -133,7 +133,9 @@ _TUNE_LOG = {}       # key -> [(plan, ms)] of the last tuning run (dev tools pri
 # (tile_mr, tile_nr, waves, stages): workgroup tile (64*mr) x (64*nr), wavefronts, LDS ring depth
 _CANDIDATES = [(2, 2, 4, 2), (2, 1, 4, 2), (1, 2, 4, 2), (1, 1, 4, 2)]
 # extra variants of the SPLIT16 engine (csrc/conv_f16s.hip): 8-wave tiles and deeper DMA rings
-_CANDIDATES_F16S = [(4, 4, 4, 2), (4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
+# ((4, 4, 4, 2) = the 256x256 tile on 4 waves / 512 registers exists and is tested, but measured 10-25 % slower than
+# (4, 2, 8, 3) on every big layer -- profiles/conv_microbench_r02_f16x3_split16.txt -- so the tuner does not try it)
+_CANDIDATES_F16S = [(4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
 
 
 def save_plans(path):
