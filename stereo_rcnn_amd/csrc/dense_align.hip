@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ b
 {
     __shared__ int wave_cnt[4];
     __shared__ int s_base;
+    __shared__ BoxGeom s_g;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (valid && !(valid[r] > 0.f)) {            // masked row of a fixed-size batch: an object with no sample (status 0)
         if (tid == 0) { cnt[r] = 0; cnt[gridDim.x + r] = 0; }
@@ -127,11 +128,23 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ b
     const int nr = r1 > r0 ? (r1 - r0 + hstep - 1) / hstep : 0;
     const int nc = c1 > c0 ? (c1 - c0 + wstep - 1) / wstep : 0;
     const int total = nr * nc;
-    BoxGeom g;
-    build_box(poses + r * 7, g);
+    // The box geometry is per OBJECT: one wave builds it, every pixel thread reads it from LDS (broadcast reads).
+    // Round 2 finding (tools/da_probe2.py, profiles/dense_align_repeatability_r02.txt): when every one of the 256 threads
+    // built its own copy in registers, about 1 call in 400 that ran BESIDE a forward pass on another stream came back with
+    // lanes 48-63 of ONE wave of ONE far object holding a different geometry (the same wrong values every time; 85 of 1561
+    // lattice pixels rejected, the coarse optimum moved from 31 m to 56 m).  Inputs, workspace and every other lane were
+    // identical; the kernel uses no scratch; an instrumented build of the same code never reproduced it.  That points at an
+    // instruction-timing hazard in that particular generated sequence, not at memory.  This arrangement removed the symptom
+    // (0 of 3000 calls) and does 1/4 of the double-precision trigonometry; the cause itself is not established.
+    if (wv == 0) {
+        BoxGeom mine;
+        build_box(poses + r * 7, mine);
+        if (lane == 0) s_g = mine;
+    }
     const float fcx = (float)cal.cx, fcy = (float)cal.cy, ff = (float)cal.f;
     if (tid == 0) s_base = 0;
     __syncthreads();
+    const BoxGeom &g = s_g;
     float *out = uvz + (size_t)r * max_pixels * 3;
     for (int i0 = 0; i0 < total; i0 += 256) {
         const int i = i0 + tid;
@@ -240,7 +253,7 @@ __global__ void make_enum_kernel(const float *__restrict__ poses, const float *_
         if (d < 1.5f) d = 1.5f;                                                         // :285
     } else {
         const double tint = 0.5 * 2.0 / iters;                                          // :291
-        d = (best_depth[r] - (float)(iters * tint / 2)) + (float)(tint * i);            // :294
+        d = (best_depth[r] - (float)(iters * tint / 2)) + (float)(tint * i);    // :294
     }
     depth_enum[idx] = d;
 }
@@ -310,7 +323,7 @@ __global__ void finish_kernel(const float *__restrict__ poses, const float *__re
 }
 
 struct DaLayout {
-    size_t up_l, up_r, uvz, cnt, left_val, depth_enum, cost, best, total;
+    size_t up_l, up_r, uvz, cnt, left_val, depth_enum[2], cost[2], best[2], total;   // [stage]: coarse and fine keep their own slots
 };
 
 static DaLayout da_layout(int H, int W, int R, int max_pixels)
@@ -324,9 +337,11 @@ static DaLayout da_layout(int H, int W, int R, int max_pixels)
     L.uvz = take((size_t)R * max_pixels * 3 * sizeof(float));
     L.cnt = take((size_t)2 * R * sizeof(int));                  // [R] valid samples, [R] overflow flags
     L.left_val = take((size_t)R * max_pixels * 3 * sizeof(float));
-    L.depth_enum = take((size_t)50 * R * sizeof(float));
-    L.cost = take((size_t)50 * R * sizeof(float));
-    L.best = take((size_t)R * sizeof(float));
+    for (int stage = 0; stage < 2; ++stage) {
+        L.depth_enum[stage] = take((size_t)50 * R * sizeof(float));
+        L.cost[stage] = take((size_t)50 * R * sizeof(float));
+        L.best[stage] = take((size_t)R * sizeof(float));
+    }
     L.total = off;
     return L;
 }
@@ -367,8 +382,7 @@ int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W,
     float *up_l = reinterpret_cast<float *>(ws + L.up_l), *up_r = reinterpret_cast<float *>(ws + L.up_r);
     float *uvz = reinterpret_cast<float *>(ws + L.uvz), *left_val = reinterpret_cast<float *>(ws + L.left_val);
     int *cnt = reinterpret_cast<int *>(ws + L.cnt);
-    float *depth_enum = reinterpret_cast<float *>(ws + L.depth_enum), *cost = reinterpret_cast<float *>(ws + L.cost);
-    float *best = reinterpret_cast<float *>(ws + L.best);
+    float *best[2] = {reinterpret_cast<float *>(ws + L.best[0]), reinterpret_cast<float *>(ws + L.best[1])};
     hipStream_t st = as_stream(stream);
     SRCNN_LAUNCH(upsample2x_kernel, dim3(4096, 1, 2), dim3(256), 0, st, im_left, im_right, H, W, up_l, up_r);
     SRCNN_LAUNCH(sample_kernel, dim3(R), dim3(256), 0, st, boxes, borders, poses, valid, cal, max_pixels, uvz, cnt);
@@ -376,13 +390,15 @@ int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W,
                        cal, left_val);
     for (int stage = 0; stage < 2; ++stage) {
         const int iters = stage == 0 ? 50 : 20;                  // dense_align.py:280,290
-        SRCNN_LAUNCH(make_enum_kernel, dim3(cdiv(R * iters, 256)), dim3(256), 0, st, poses, best, cal, R, iters,
+        float *depth_enum = reinterpret_cast<float *>(ws + L.depth_enum[stage]);
+        float *cost = reinterpret_cast<float *>(ws + L.cost[stage]);
+        SRCNN_LAUNCH(make_enum_kernel, dim3(cdiv(R * iters, 256)), dim3(256), 0, st, poses, best[0], cal, R, iters,
                            stage, depth_enum);
         SRCNN_LAUNCH(cost_kernel, dim3(iters, R), dim3(256), 0, st, up_r, uvz, cnt, left_val, depth_enum,
                            max_pixels, R, cal, cost);
-        SRCNN_LAUNCH(argmin_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, cost, depth_enum, R, iters, best);
+        SRCNN_LAUNCH(argmin_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, cost, depth_enum, R, iters, best[stage]);
     }
-    SRCNN_LAUNCH(finish_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, poses, best, cnt, R, cal, status, best_dis);
+    SRCNN_LAUNCH(finish_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, poses, best[1], cnt, R, cal, status, best_dis);
     return check_launch("srcnn_dense_align");
 }
 

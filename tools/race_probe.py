@@ -58,6 +58,7 @@ with torch.no_grad():
 # ---- the device 3-D stage under concurrency: record of every frame vs the record of a lone run
 import numpy as np
 from stereo_rcnn_amd import pipeline
+from stereo_rcnn_amd.model.dense_align.dense_align import align_parallel
 from tools.demo_pipeline import demo_calib
 calib = demo_calib()
 shape = (375, 1242, 3)
@@ -66,33 +67,36 @@ with torch.no_grad():
     st = pipeline.launch_3d(out, l, r, info, float(info[0, 2]), calib, shape)
     st.event.synchronize()
     ref_rec, ref_state = st.rec_host.numpy().copy(), st.state_host.numpy().copy()
-    out = m(l, r, info)
-    st = pipeline.launch_3d(out, l, r, info, float(info[0, 2]), calib, shape)
-    st.event.synchronize()
-    print('lone 3-D stage repeatable:', np.array_equal(ref_rec, st.rec_host.numpy()), np.array_equal(ref_state[0], st.state_host.numpy()[0]))
-    for S in (2, 3, 4):
+    k0 = int(ref_rec[0, 0])
+    for S in (3, 3, 3):
         streams = [torch.cuda.Stream() for _ in range(S)]
-        recs = []
         pend = []
-        for k in range(4 * S):
+        nbad = 0
+        for k in range(40 * S):
             s = k % S
             if len(pend) == S:
                 h = pend.pop(0)
                 h.event.synchronize()
-                recs.append((h.rec_host.numpy().copy(), h.state_host.numpy().copy()))
+                rec = h.rec_host.numpy()
+                d = rec[:k0 + 1] != ref_rec[:k0 + 1]
+                if d.any():
+                    nbad += 1
+                    torch.cuda.synchronize()
+                    rows = np.nonzero(d.any(1))[0]
+                    for rr in rows:
+                        print('frame %d slot %d row %d: got  %s' % (k - S, (k - S) % S, rr, np.array2string(rec[rr, 20:32], precision=4)))
+                        print('%s ref  %s' % (' ' * 24, np.array2string(ref_rec[rr, 20:32], precision=4)))
+                    # the stage buffers still hold this frame's alignment inputs / outputs
+                    i = int(rows[0]) - 1
+                    print('   stage buffers: valid %s box %s borders %s pose %s -> status %s dis %s' % (
+                        float(h.valid[i]), h.boxes[i].tolist(), h.borders[i].tolist(), h.poses[i].tolist(), float(h.align_status[i]), float(h.best_dis[i])))
+                    kp = torch.zeros(h.boxes.shape[0], 5, device=dev); kp[:, 3:5] = h.borders
+                    a2, b2 = align_parallel(calib, float(info[0, 2]), l, r, h.boxes, kp, h.poses, valid=h.valid)
+                    torch.cuda.synchronize()
+                    print('   dense alignment of those very buffers again: status %s dis %s' % (float(a2[i]), float(b2[i])))
             streams[s].wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(streams[s]):
                 out = m(l, r, info, slot=s)
                 pend.append(pipeline.launch_3d(out, l, r, info, float(info[0, 2]), calib, shape, slot=s))
-        for h in pend:
-            h.event.synchronize()
-            recs.append((h.rec_host.numpy().copy(), h.state_host.numpy().copy()))
-        k0 = int(ref_rec[0, 0])
-        rep = []
-        for k, (rec, stt) in enumerate(recs):
-            d = rec[:k0 + 1] != ref_rec[:k0 + 1]
-            groups = {'det 0-19': d[:, 0:20].any(1).sum(), '4dof 20-24': d[:, 20:25].any(1).sum(), 'align 25-26': d[:, 25:27].any(1).sum(),
-                      'final 27-31': d[:, 27:32].any(1).sum()}
-            if d.any():
-                rep.append((k, k % S, {a: int(b) for a, b in groups.items() if b}))
-        print('%d in flight, 3-D stage: frames whose record differs from the lone run: %s' % (S, rep if rep else 'none'))
+        torch.cuda.synchronize()
+        print('%d in flight: %d of %d frames differ' % (S, nbad, 40 * S - S), flush=True)
