@@ -293,6 +293,14 @@ SRCNN_API int srcnn_align_inputs(const float *rec, int n, int rec_cols, float *b
 SRCNN_API int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
                      double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
                      srcnn_stream_t stream);
+/* Record forms on HOST memory (pinned copies of `rec` / `state`): row for row the function the two kernels above run, built
+ * for the host and using the host's libm, i.e. bit-identical to the reference's scipy path (scipy Newton-CG, numpy scalar
+ * `**2` = pow, glibc cos / sin / atan2).  Rows are spread over `threads` host threads (<= 0: one per 8 rows, at most 16). */
+SRCNN_API int srcnn_solve_4dof_records_host(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02,
+                                  double p2_12, double p2_03_minus_p3_03, float eval_thresh, double *state4, int threads);
+SRCNN_API int srcnn_solve_3dof_records_host(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02,
+                                  double p2_12, double p2_03_minus_p3_03, const float *align_status, const float *best_dis,
+                                  double *state, int threads);
 /* the same solver code compiled for the host (HOST pointers, no GPU needed): the reference's
  * solve_x_y_z_theta_from_kpt(im_shape, calib, alpha, dim, box_left, box_right, kpts) -> (status, state) and
  * solve_x_y_theta_from_kpt(im_shape, calib, alpha, dim, box_left, disparity, kpts) -> (state, z), flattened.

@@ -94,6 +94,10 @@ _SIGNATURES = {
     "srcnn_align_inputs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srcnn_solve_3dof": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
+    "srcnn_solve_4dof_records_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double,
+                                              c_float, c_void_p, c_int]),
+    "srcnn_solve_3dof_records_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double,
+                                              c_void_p, c_void_p, c_void_p, c_int]),
     "srcnn_solve_4dof_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "srcnn_solve_3dof_host": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p,

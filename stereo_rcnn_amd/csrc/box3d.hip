@@ -8,6 +8,9 @@
 // inside one wavefront.
 #include "common.h"
 #include "box_solver.h"
+#include <atomic>
+#include <thread>
+#include <vector>
 
 namespace srcnn {
 
@@ -60,17 +63,16 @@ struct Calib {
     int im_h, im_w;
 };
 
-__device__ __forceinline__ void load5(const float *p, double *o)
+SRCNN_HD inline void load5(const float *p, double *o)
 {
     for (int i = 0; i < 5; ++i) o[i] = (double)p[i];
 }
 
-// demo.py:282-302: every detection above the threshold -> (status, x, y, z, theta), poses kept in float32 as `poses_all`
-__global__ void solve4_kernel(float *__restrict__ rec, int n, int cols, Calib c, float eval_thresh, double *__restrict__ state4)
+// demo.py:282-302 for detection i of a record: (status, x, y, z, theta), poses kept in float32 as `poses_all`.
+// Host and device run this same function (the host build through srcnn_solve_4dof_records_host).
+SRCNN_HD inline void solve4_row(float *rec, int n, int cols, const Calib &c, float eval_thresh, double *state4, int i)
 {
-    if (threadIdx.x != 0) return;
-    const int i = blockIdx.x;
-    const int k = min((int)rec[0], n);
+    const int k = (int)rec[0] < n ? (int)rec[0] : n;
     float *row = rec + (size_t)(1 + i) * cols;
     double *out = state4 + (size_t)i * 4;
     out[0] = out[1] = out[2] = out[3] = 0.0;
@@ -91,6 +93,11 @@ __global__ void solve4_kernel(float *__restrict__ rec, int n, int cols, Calib c,
     for (int q = 0; q < 4; ++q) row[C_POSE4 + q] = (float)st[q];                  // poses[0..2], poses[6]
     for (int q = 0; q < 4; ++q) row[C_POSE + q] = (float)st[q];
     row[C_ALPHA] = (float)alpha;                                                  // poses[7]
+}
+
+__global__ void solve4_kernel(float *__restrict__ rec, int n, int cols, Calib c, float eval_thresh, double *__restrict__ state4)
+{
+    if (threadIdx.x == 0) solve4_row(rec, n, cols, c, eval_thresh, state4, blockIdx.x);
 }
 
 // gather of what align_parallel takes (demo.py:306-308): boxes (n,4), borders (n,2), poses (n,7), valid (n)
@@ -116,12 +123,10 @@ __global__ void align_inputs_kernel(const float *__restrict__ rec, int n, int co
 }
 
 // demo.py:311-319: objects the alignment succeeded on are re-solved with z fixed by the aligned disparity
-__global__ void solve3_kernel(float *__restrict__ rec, int n, int cols, Calib c, const float *__restrict__ align_status,
-                              const float *__restrict__ best_dis, double *__restrict__ state)
+SRCNN_HD inline void solve3_row(float *rec, int n, int cols, const Calib &c, const float *align_status, const float *best_dis,
+                                double *state, int i)
 {
-    if (threadIdx.x != 0) return;
-    const int i = blockIdx.x;
-    const int k = min((int)rec[0], n);
+    const int k = (int)rec[0] < n ? (int)rec[0] : n;
     if (i >= k) return;
     float *row = rec + (size_t)(1 + i) * cols;
     double *out = state + (size_t)i * 4;
@@ -140,6 +145,32 @@ __global__ void solve3_kernel(float *__restrict__ rec, int n, int cols, Calib c,
                                 st, nullptr);
     out[0] = st[0]; out[1] = st[1]; out[2] = z; out[3] = st[2];
     for (int q = 0; q < 4; ++q) row[C_POSE + q] = (float)out[q];
+}
+
+__global__ void solve3_kernel(float *__restrict__ rec, int n, int cols, Calib c, const float *__restrict__ align_status,
+                              const float *__restrict__ best_dis, double *__restrict__ state)
+{
+    if (threadIdx.x == 0) solve3_row(rec, n, cols, c, align_status, best_dis, state, blockIdx.x);
+}
+
+// rows [0, n) of a host record over `threads` host threads (<= 0: one per 8 rows, at most 16)
+template <typename F>
+static void host_rows(int n, int threads, F &&row_fn)
+{
+    if (threads <= 0) threads = n / 8;
+    threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    if (threads > n) threads = n > 0 ? n : 1;
+    if (threads == 1) {
+        for (int i = 0; i < n; ++i) row_fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    std::atomic<int> next{0};
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&]() {
+            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) row_fn(i);   // rows are independent
+        });
+    for (auto &th : pool) th.join();
 }
 
 static Calib make_calib(int im_h, int im_w, double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03)
@@ -229,6 +260,34 @@ int srcnn_solve_3dof_host(int im_h, int im_w, double p2_00, double p2_02, double
     const Calib c = make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03);
     *z = boxsolve::solve_3dof(im_h, im_w, c.f, c.cx, c.cy, c.base, alpha, dim3, box_left4, disparity, kpts5, state3,
                               newton_status);
+    return SRCNN_OK;
+}
+
+// The record forms of the two solves on HOST memory: what srcnn_solve_4dof / srcnn_solve_3dof do, row for row (same
+// function), with the host's libm -- i.e. bit-identical to the reference's scipy path (tests/test_solvers_cpu.py).  The
+// "reference-exact" 3-D flow copies the record down, runs these, and copies it back for the dense alignment.
+int srcnn_solve_4dof_records_host(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                                  double p2_03_minus_p3_03, float eval_thresh, double *state4, int threads)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(rec && state4 && n > 0 && rec_cols >= SRCNN_REC_COLS, "bad args (rec_cols >= SRCNN_REC_COLS)");
+    const Calib c = make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03);
+    const int k = (int)rec[0] < n ? (int)rec[0] : n;
+    for (int i = k > 0 ? k : 0; i < n; ++i) state4[(size_t)i * 4] = state4[(size_t)i * 4 + 1] = state4[(size_t)i * 4 + 2] = state4[(size_t)i * 4 + 3] = 0.0;
+    host_rows(k, threads, [&](int i) { solve4_row(rec, n, rec_cols, c, eval_thresh, state4, i); });
+    return SRCNN_OK;
+}
+
+int srcnn_solve_3dof_records_host(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                                  double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
+                                  int threads)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(rec && state && n > 0 && rec_cols >= SRCNN_REC_COLS, "bad args (rec_cols >= SRCNN_REC_COLS)");
+    SRCNN_REQUIRE((align_status == nullptr) == (best_dis == nullptr), "align_status and best_dis come together");
+    const Calib c = make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03);
+    const int k = (int)rec[0] < n ? (int)rec[0] : n;
+    host_rows(k, threads, [&](int i) { solve3_row(rec, n, rec_cols, c, align_status, best_dis, state, i); });
     return SRCNN_OK;
 }
 

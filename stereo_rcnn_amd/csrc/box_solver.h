@@ -130,6 +130,20 @@ SRCNN_HD void setup(Problem &t, int im_h, int im_w, double f, double cx, double 
     t.z_fixed = 0;
 }
 
+// `v ** 2` of the reference (numpy float64 scalars) is libm's pow(v, 2.0), which is NOT always the correctly rounded v * v
+// (glibc: last bit differs in ~0.06 % of the calls) -- and one last bit moves a chaotic Newton-CG end point.  The host build
+// therefore calls the same pow (through a volatile exponent: the compiler would fold pow(v, 2.0) into v * v); the device has
+// no glibc and squares exactly, which is one of the two reasons its end points differ from the host's (the other: ocml cos/sin).
+SRCNN_HD inline double sq(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return v * v;
+#else
+    volatile double two = 2.0;
+    return pow(v, two);
+#endif
+}
+
 // Cost (sum of squares, box_estimator.py:253-276 / :463-480) and the REFERENCE's gradient (:278-372 / :482-538) at
 // (x, y, z, theta).  g has 4 entries (x, y, z, theta).
 SRCNN_HD double evaluate(const Problem &t, double x, double y, double z, double theta, bool want_grad, double *g)
@@ -146,40 +160,40 @@ SRCNN_HD double evaluate(const Problem &t, double x, double y, double z, double 
         const double num = x - shift + ct * vw + st * vl;
         const double den = z - st * vw + ct * vl;
         const double res = scale * (num / den - t.obs[k]);
-        cost += res * res;
+        cost += sq(res);
         if (want_grad) {
             g[0] += 2.0 * res / den;
-            g[2] += -2.0 * res * num / (den * den);
-            g[3] += 2.0 * res * ((vl * ct - vw * st) / den + (vw * ct + vl * st) * num / (den * den));
+            g[2] += -2.0 * res * num / sq(den);
+            g[3] += 2.0 * res * ((vl * ct - vw * st) / den + (vw * ct + vl * st) * num / sq(den));
         }
     }
     const double bw = t.vw[3], bl_ = t.vl[3];
     if (t.act[5]) {
         const double den = z - st * bw + ct * bl_;
         const double res = y / den - t.obs[5];
-        cost += res * res;
+        cost += sq(res);
         if (want_grad) {
             g[1] += 2.0 * res / den;
-            g[2] += -2.0 * res * y / (den * den);
-            g[3] += 2.0 * res * (y * (bw * ct + bl_ * st)) / (den * den);
+            g[2] += -2.0 * res * y / sq(den);
+            g[3] += 2.0 * res * (y * (bw * ct + bl_ * st)) / sq(den);
         }
     }
     if (t.act[6]) {
         const double den = z + st * bw - ct * bl_;
         const double res = (y - t.h) / den - t.obs[6];
-        cost += res * res;
+        cost += sq(res);
         if (want_grad) {
             g[1] += 2.0 * res / den;
-            g[2] += 2.0 * res * (t.h - y) / (den * den);
-            g[3] += 2.0 * res * ((t.h - y) * (bw * ct + bl_ * st)) / (den * den);
+            g[2] += 2.0 * res * (t.h - y) / sq(den);
+            g[3] += 2.0 * res * ((t.h - y) * (bw * ct + bl_ * st)) / sq(den);
         }
     }
     if (t.act[7]) {
         const double res = theta - kPi / 2 + atan2(-x, z) - t.alpha;
-        cost += res * res;
+        cost += sq(res);
         if (want_grad) {
             const double r = -x / z;
-            const double q = 1.0 + r * r;
+            const double q = 1.0 + sq(r);
             g[0] += 2.0 * res / q * (-1.0 / z);
             g[2] += 2.0 * res / q * (x / (z * z));
             g[3] += 2.0 * res;

@@ -2,14 +2,19 @@
 (= test_net.py:131-331): network forward, decode, per-class NMS, border inference, 4-DoF box solve,
 dense alignment, 3-DoF rectification.
 
-Default (`solver='device'`): EVERY stage is a launch into the HIP library on one stream, working in place on
-the image's fixed-size detection record (include/srcnn_hip.h: SRCNN_REC_COLS) -- class NMS -> pack ->
-srcnn_infer_boundary -> srcnn_solve_4dof -> srcnn_dense_align (masked, fixed batch) -> srcnn_solve_3dof -- and
-ONE device-to-host copy at the end: no host round trip between the detector and the final 3-D boxes, nothing per
-object in Python.  The solvers are scipy's Newton-CG restated in double precision (csrc/box_solver.h).
-
-`solver='scipy'` keeps the reference's own arrangement (host numpy `infer_boundary`, scipy solves, optionally fanned
-out to a process pool) as the comparison path: model/utils/box_estimator.py, model/utils/kitti_utils.py."""
+Every stage works in place on the image's fixed-size detection record (include/srcnn_hip.h: SRCNN_REC_COLS) through
+launches into the HIP library on one stream -- class NMS -> pack -> srcnn_infer_boundary -> 4-DoF solve ->
+srcnn_dense_align (masked, fixed batch) -> 3-DoF solve -- nothing per object in Python.  The solvers are scipy's
+Newton-CG restated in double precision (csrc/box_solver.h), one source built for the device and for the host:
+  solver='host' (default)  the two solves run on the HOST build between the device stages (record down, solve in C
+                           threads, record up): results bit-identical to the reference's scipy path, because the host
+                           build calls the same libm (pow, cos, sin, atan2) numpy does.  Streamed, the solves of one pair
+                           hide behind the forward of the next: same throughput as 'device'.
+  solver='device'          the solves are kernels (one detection per workgroup): no host round trip between the detector
+                           and the final boxes, ONE device-to-host copy.  ocml's cos / sin / atan2 and exact squares
+                           differ from glibc in last bits; the chaotic Newton-CG end points then differ.
+  solver='scipy'           the reference's own arrangement (host numpy `infer_boundary`, scipy solves, optionally fanned
+                           out to a process pool) as the comparison path: model/utils/box_estimator.py, kitti_utils.py."""
 import collections
 import ctypes
 import math as m
@@ -135,7 +140,10 @@ class _Stage3D(object):
         self.ws = torch.empty(int(L.srcnn_box3d_workspace_bytes(n, 4096)), dtype=torch.uint8, device=dev)
         self.rec_host = torch.empty((n + 1, REC_COLS), dtype=torch.float32, pin_memory=True)
         self.state_host = torch.empty((2, n, 4), dtype=torch.float64, pin_memory=True)
+        self.align_host = torch.empty((2, n), dtype=torch.float32, pin_memory=True)     # solver='host': status, disparity
         self.event = torch.cuda.Event()
+        self.phase = 0               # solver='host': 1 = waiting for the 4-DoF solve, 2 = for the 3-DoF solve, 0 = complete
+        self.ctx = None
 
 
 _stages = {}
@@ -149,9 +157,12 @@ def _stage(n, dev, slot):
 
 
 def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape, eval_thresh=0.05, class_index=1,
-              dense_align=True, slot=0):
+              dense_align=True, slot=0, solver='device'):
     """Everything after the forward, asynchronously on the current stream.  out: the forward's tuple; scale: im_info[0, 2] as a
-    Python float (passing it spares a device read).  Returns a handle for collect_3d()."""
+    Python float (passing it spares a device read).  Returns a handle for collect_3d().
+    solver='host': only class NMS, record and borders are launched here; the two Newton-CG solves then run on the HOST (the
+    same row functions built for the host, bit-identical to the reference's scipy path) in step_3d() / collect_3d(), with
+    the dense alignment on the device in between."""
     L = _lib.lib()
     det = postprocess.decode_detections(*out[:8], im_info)
     keep_idx, num = postprocess.class_nms_device(det, class_index, eval_thresh, cfg.TEST.NMS)
@@ -165,6 +176,15 @@ def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape,
     im_h, im_w = int(im_shape[0]), int(im_shape[1])
     _lib.check(L.srcnn_infer_boundary(st.rec.data_ptr(), n, REC_COLS, im_w, st.ws.data_ptr(), st.ws.numel(), s),
                "srcnn_infer_boundary")
+    st.phase, st.ctx = 0, None
+    if solver == 'host':
+        st.rec_host.copy_(st.rec, non_blocking=True)
+        st.event.record()
+        st.phase = 1
+        st.ctx = (torch.cuda.current_stream(), im_left_data, im_right_data, float(scale), cal, im_h, im_w, float(eval_thresh),
+                  bool(dense_align))
+        return st
+    assert solver == 'device', solver
     _lib.check(L.srcnn_solve_4dof(st.rec.data_ptr(), n, REC_COLS, im_h, im_w, cal[0], cal[1], cal[2], cal[3],
                                   float(eval_thresh), st.state[0].data_ptr(), s), "srcnn_solve_4dof")
     if dense_align:
@@ -185,8 +205,57 @@ def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape,
     return st
 
 
+HOST_SOLVER_THREADS = 0          # srcnn_solve_*_records_host: <= 0 = one thread per 8 detections, at most 16
+
+
+def step_3d(st):
+    """solver='host' handles: run the next host phase (blocks until the device work it needs has finished).  Phase 1: 4-DoF
+    solves on the pinned record, record back to the device, dense alignment launched.  Phase 2: 3-DoF solves."""
+    if st.phase == 0:
+        return
+    L = _lib.lib()
+    stream, iml, imr, scale, cal, im_h, im_w, thresh, dense = st.ctx
+    n = st.n
+    st.event.synchronize()
+    if st.phase == 1:
+        if st.rec_host[0, 1] > 0:                              # range guard: collect_3d raises
+            st.phase = 0
+            return
+        _lib.check(L.srcnn_solve_4dof_records_host(st.rec_host.data_ptr(), n, REC_COLS, im_h, im_w, cal[0], cal[1], cal[2],
+                                                   cal[3], thresh, st.state_host[0].data_ptr(), HOST_SOLVER_THREADS),
+                   "srcnn_solve_4dof_records_host")
+        st.state_host[1].zero_()
+        if not dense or not bool((st.rec_host[1:1 + int(st.rec_host[0, 0]), 20] > 0).any()):
+            st.phase = 0
+            return
+        with torch.no_grad(), torch.cuda.stream(stream):
+            s = _lib.stream()
+            st.rec.copy_(st.rec_host, non_blocking=True)
+            _lib.check(L.srcnn_align_inputs(st.rec.data_ptr(), n, REC_COLS, st.boxes.data_ptr(), st.borders.data_ptr(),
+                                            st.poses.data_ptr(), st.valid.data_ptr(), s), "srcnn_align_inputs")
+            _, _, H, W = iml.shape
+            ws = _lib.workspace(L.srcnn_dense_align_workspace_bytes(H, W, n, MAX_PIXELS), iml.device, "dense_align")
+            _lib.check(L.srcnn_dense_align(_lib.ptr(iml), _lib.ptr(imr), H, W, scale, cal[0], cal[1], cal[2], cal[3],
+                                           st.boxes.data_ptr(), st.borders.data_ptr(), st.poses.data_ptr(), st.valid.data_ptr(),
+                                           n, MAX_PIXELS, st.align_status.data_ptr(), st.best_dis.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), s), "srcnn_dense_align")
+            st.align_host[0].copy_(st.align_status, non_blocking=True)
+            st.align_host[1].copy_(st.best_dis, non_blocking=True)
+            st.event.record()
+        st.phase = 2
+        return
+    _lib.check(L.srcnn_solve_3dof_records_host(st.rec_host.data_ptr(), n, REC_COLS, im_h, im_w, cal[0], cal[1], cal[2], cal[3],
+                                               st.align_host[0].data_ptr(), st.align_host[1].data_ptr(),
+                                               st.state_host[1].data_ptr(), HOST_SOLVER_THREADS),
+               "srcnn_solve_3dof_records_host")
+    st.phase = 0
+
+
 def collect_3d(st):
     """Wait for a launch_3d() handle and turn its record into the object list detect_3d returns."""
+    while st.phase:
+        step_3d(st)
+    st.ctx = None
     st.event.synchronize()
     rec, state = st.rec_host.numpy(), st.state_host.numpy()
     if rec[0, 1] > 0:           # SPLIT16 range guard tripped during this (or a concurrently running) forward
@@ -272,21 +341,23 @@ def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shap
 
 # ------------------------------------------------------------------------------------------------ public entry points
 def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh=0.05, class_index=1,
-              dense_align=True, pool=None, solver='device', slot=0):
+              dense_align=True, pool=None, solver='host', slot=0):
     """One preprocessed pair -> list of dicts (one per solved object, descending score):
     box_left (4), box_right (4), score, dim (w,h,l), alpha, xyz (3), theta, aligned (bool), xyz_init / theta_init (the 4-DoF
     solve), disparity (aligned objects), kpts (5, borders after the inference step).
-    solver: 'device' (default; native Newton-CG kernels, one D2H copy), 'host' (the reference's host arrangement with the
-    native Newton-CG compiled for the host: end points bit-identical to scipy's on identical arithmetic) or 'scipy' (host
-    numpy + scipy, optional `pool`)."""
-    if solver in ('scipy', 'host'):
+    solver: 'host' (default: device record flow, the two Newton-CG solves on the host in C -- final boxes BIT-IDENTICAL to
+    the reference's scipy path, same throughput as 'device' when streamed); 'device' (Newton-CG kernels, no host bounce at
+    all, one D2H copy; its libm differs from glibc in last bits, so chaotic end points differ); 'scipy' (the
+    reference's own arrangement: host numpy + scipy per object, optional `pool`); 'host_py' (that arrangement with the native
+    solver called per object)."""
+    if solver in ('scipy', 'host_py'):
         return _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
-                                dense_align, pool if solver == 'scipy' else None, native=(solver == 'host'))
+                                dense_align, pool if solver == 'scipy' else None, native=(solver == 'host_py'))
     from . import engine
     with torch.no_grad():
         out = model(im_left_data, im_right_data, im_info, slot=slot)
         st = launch_3d(out, im_left_data, im_right_data, im_info, _scale32(im_info), calib, im_shape, eval_thresh,
-                       class_index, dense_align, slot)
+                       class_index, dense_align, slot, solver)
     try:
         return collect_3d(st)
     except engine.Split16RangeError:
@@ -302,7 +373,7 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
 
 
 def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, class_index=1, dense_align=True, slot=0,
-                     wait=True):
+                     wait=True, solver='host'):
     """The same from the decoded uint8 RGB images on the device: preprocessing fused in front of the forward
     (model.forward_images), then the device 3-D flow.  wait=False returns the handle for collect_3d()."""
     with torch.no_grad():
@@ -310,15 +381,18 @@ def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, 
         from . import engine
         scale = float(np.float32(engine.preprocess_size(int(img_left_u8.shape[0]), int(img_left_u8.shape[1]),
                                                         cfg.TEST.SCALES[0])[2]))
-        st = launch_3d(out, iml, imr, info, scale, calib, tuple(img_left_u8.shape), eval_thresh, class_index, dense_align, slot)
+        st = launch_3d(out, iml, imr, info, scale, calib, tuple(img_left_u8.shape), eval_thresh, class_index, dense_align, slot,
+                       solver)
     return collect_3d(st) if wait else st
 
 
-def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=2, solver='device'):
+def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=3, solver='host'):
     """Generator form for a sequence of pairs: yields one object list per frame, in order, with up to `slots` pairs in flight
     on their own HIP streams.  frames: iterable of (im_left_data, im_right_data, im_info, calib, im_shape[, scale]) with device
     tensors, or (img_left_u8, img_right_u8, calib) with uint8 device images (fused preprocessing).  Per pair the results are
-    those of detect_3d (same launches).  solver='scipy' (needs `pool`) keeps the staged host/scipy arrangement."""
+    those of detect_3d (same launches).  solver='host': the Newton-CG solves of the pairs in flight run on the host between
+    the launches (one phase per pair per new frame), use slots >= 3.  solver='scipy' (needs `pool`) keeps the staged
+    host/scipy arrangement."""
     if solver == 'scipy':
         for objs in _detect_3d_stream_scipy(model, frames, pool, eval_thresh, class_index, dense_align, min(slots, 2)):
             yield objs
@@ -338,8 +412,10 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
             prev, model.precision = model.precision, 'f32'
             try:
                 if len(frame) == 3:
-                    return detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align, 0)
-                return detect_3d(model, frame[0], frame[1], frame[2], frame[3], frame[4], eval_thresh, class_index, dense_align)
+                    return detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align, 0,
+                                            solver=solver)
+                return detect_3d(model, frame[0], frame[1], frame[2], frame[3], frame[4], eval_thresh, class_index, dense_align,
+                                 solver=solver)
             finally:
                 model.precision = prev
                 engine.range_flag(reset=True)
@@ -352,12 +428,15 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
         s.wait_stream(torch.cuda.current_stream())
         with torch.no_grad(), torch.cuda.stream(s):
             if len(frame) == 3:
-                st = detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align, slot, wait=False)
+                st = detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align, slot, wait=False,
+                                      solver=solver)
             else:
                 l, r, info, calib, im_shape = frame[:5]
                 scale = float(np.float32(frame[5])) if len(frame) > 5 else _scale32(info)
                 out = model(l, r, info, slot=slot)
-                st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot)
+                st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot, solver)
+        for older, _ in inflight:                              # solver='host': one host phase of every pair already in flight
+            step_3d(older)
         inflight.append((st, frame))
     while inflight:
         yield finish(inflight.popleft())

@@ -37,15 +37,16 @@ def read_png_rgb(path):
 
 
 def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4,
-              solver='device', slots=2, detect_stream=None, records=None):
+              solver='host', slots=3, detect_stream=None, records=None):
     """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds).
     `detect_stream(frames)`: replaces the detector (a generator of object lists, one per frame) -- the CPU tests drive the
     sharding / writer / gather logic with it; `records`: a list that receives one detection record per frame
     (distributed.objects_to_record) for the gather of the split.
     Frames go through pipeline.detect_3d_stream: PNG decoding runs `prefetch` frames ahead on host threads, the decoded
     uint8 images are copied to the device and everything else -- preprocessing, forward, decode, NMS, borders, 4-DoF solve,
-    dense alignment, 3-DoF rectification -- is device work with `slots` pairs in flight (solver='device').
-    solver='scipy' (with a SolverPool) runs the reference's host arrangement instead: the comparison path."""
+    dense alignment, 3-DoF rectification -- runs on the record flow with `slots` pairs in flight: solver='host' (default; the
+    Newton-CG solves in C on the host between the device stages, bit-identical to the scipy path) or 'device' (solves as
+    kernels).  solver='scipy' (with a SolverPool) runs the reference's host arrangement instead: the comparison path."""
     import collections
     import concurrent.futures as cf
     t0, n_obj = time.time(), 0
@@ -76,7 +77,7 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
         if detect_stream is not None:
             return (left, right, calib)                         # injected detector: frames stay on the host
         lu, ru = torch.from_numpy(left).to(device, non_blocking=True), torch.from_numpy(right).to(device, non_blocking=True)
-        if solver == 'device':
+        if solver in ('device', 'host'):
             return (lu, ru, calib)                              # preprocessing is fused in front of the forward
         l, scale = engine.preprocess(lu, cfg.TEST.SCALES[0])
         r, _ = engine.preprocess(ru, cfg.TEST.SCALES[0])
@@ -87,7 +88,7 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
         if detect_stream is not None:
             for objs in detect_stream(frames()):
                 yield objs
-        elif solver == 'device' or pool is not None:
+        elif solver in ('device', 'host') or pool is not None:
             for objs in pipeline.detect_3d_stream(model, frames(), pool, solver=solver, slots=slots):
                 yield objs
         else:
@@ -115,8 +116,9 @@ def main(argv=None):
     ap.add_argument('--split', required=True, help='text file with one frame id per line (e.g. data/kitti/splits/val.txt)')
     ap.add_argument('--checkpoint', required=True, help="torch checkpoint with a 'model' state_dict (reference schema) or a bare state_dict")
     ap.add_argument('--result-dir', required=True)
-    ap.add_argument('--solver', choices=['device', 'scipy'], default='device',
-                    help="3-D stage: 'device' = native Newton-CG kernels (default), 'scipy' = the reference's host arrangement")
+    ap.add_argument('--solver', choices=['host', 'device', 'scipy'], default='host',
+                    help="3-D stage: 'host' = native Newton-CG on the host between the device stages, bit-identical to scipy "
+                         "(default); 'device' = Newton-CG kernels; 'scipy' = the reference's host arrangement")
     ap.add_argument('--solver-workers', type=int, default=0, help='scipy path: worker processes (0 = cpu_count / ranks, <= 32)')
     ap.add_argument('--precision', choices=['f16x3', 'f32'], default='f16x3')
     ap.add_argument('--gather', action='store_true',
@@ -147,7 +149,8 @@ def main(argv=None):
             frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, pool, log=log, solver='scipy',
                                          records=records)
     else:
-        frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, log=log, records=records)
+        frames, objs, dt = run_split(model, args.kitti_root, mine, args.result_dir, device, log=log, records=records,
+                                     solver=args.solver)
     print('[rank %d] %d frames, %d objects, %.1f s (%.1f frames/s)' % (rank, frames, objs, dt, frames / max(dt, 1e-9)), flush=True)
     if args.gather:
         from .distributed import gather_split_records

@@ -89,8 +89,8 @@ def _cases(n, seed):
 
 def test_solve_kernels_vs_host_build(dev):
     """srcnn_solve_4dof / srcnn_solve_3dof (device) against the SAME code compiled for the host (which is bit-identical to
-    scipy's iteration, tests/test_solvers_cpu.py): status equal; end points equal except where the device libm's cos / sin /
-    atan2 differ from glibc's in the last bit on a chaotic case."""
+    the scipy path, tests/test_solvers_cpu.py): status equal; end points equal except where the device's arithmetic -- ocml
+    cos / sin / atan2 instead of glibc's, exact squares instead of pow(v, 2) -- differs in the last bit on a chaotic case."""
     from stereo_rcnn_amd import _lib
     from stereo_rcnn_amd.model.utils import box_estimator as pbe
     L = _lib.lib()
@@ -179,7 +179,7 @@ def test_device_flow_vs_scipy_flow(dev):
     mdl = _model(dev, fixture.make_state_dict(3))
     l, r, info = fixture.make_inputs(3, 200, 660, target_short=320)
     args = (mdl, l.to(dev), r.to(dev), info.to(dev), calib, (200, 660, 3))
-    a = pipeline.detect_3d(*args)
+    a = pipeline.detect_3d(*args, solver='device')
     b = pipeline.detect_3d(*args, solver='scipy')
     # an object is dropped when its 4-DoF depth ends beyond 100 m (box_estimator.py:383): on these noise-image detections a
     # few sit at that edge, so the two lists may differ by those
@@ -205,6 +205,50 @@ def test_device_flow_vs_scipy_flow(dev):
     assert max(ddis, default=0.0) < 2e-3
 
 
+def test_host_solver_flow_equals_scipy_flow_bit_for_bit(dev):
+    """solver='host' (device record flow, the two Newton-CG solves by the host build of the same row functions) against the
+    reference's arrangement (host numpy infer_boundary + scipy per object) on the same forward: the SAME objects with
+    bit-identical borders, 4-DoF end points, aligned disparities and final boxes -- every one, not a fraction."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    total = 0
+    for seed, h, w, short in ((3, 200, 660, 320), (4, 200, 660, 320), (5, 120, 400, 192)):
+        l, r, info = fixture.make_inputs(seed, h, w, target_short=short)
+        args = (mdl, l.to(dev), r.to(dev), info.to(dev), calib, (h, w, 3))
+        a = pipeline.detect_3d(*args, solver='host')
+        b = pipeline.detect_3d(*args, solver='scipy')
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert np.array_equal(x['box_left'], y['box_left']) and np.array_equal(x['kpts'], y['kpts']) and x['score'] == y['score']
+            assert np.array_equal(x['xyz_init'], y['xyz_init']) and x['theta_init'] == y['theta_init']
+            assert x['aligned'] == y['aligned']
+            if x['aligned']:
+                assert x['disparity'] == y['disparity']
+            assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta']
+        total += len(a)
+    assert total >= 10
+
+
+def test_host_solver_streaming_equals_serial(dev):
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    frames = []
+    for seed in (3, 4, 5, 6):
+        l, r, info = fixture.make_inputs(seed, 120, 400, target_short=192)
+        frames.append((l.to(dev), r.to(dev), info.to(dev), calib, (120, 400, 3), float(info[0, 2])))
+    serial = [pipeline.detect_3d(mdl, *f[:5], solver='host') for f in frames]
+    for slots in (1, 3):
+        streamed = list(pipeline.detect_3d_stream(mdl, frames + frames, slots=slots, solver='host'))
+        assert len(streamed) == 8
+        for want, got in zip(serial + serial, streamed):
+            assert len(want) == len(got)
+            for x, y in zip(want, got):
+                assert np.array_equal(x['box_left'], y['box_left']) and x['aligned'] == y['aligned']
+                assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta']
+
+
 def test_streaming_equals_serial_and_images_entry(dev):
     from oracle.dense_align import KITTI_DEMO_CALIB as calib
     from stereo_rcnn_amd import fixture, pipeline
@@ -215,14 +259,15 @@ def test_streaming_equals_serial_and_images_entry(dev):
         pairs.append((torch.from_numpy(lu).to(dev), torch.from_numpy(ru).to(dev), calib))
     import stereo_rcnn_amd.model.utils.config as C
     short = C.cfg.TEST.SCALES[0]
-    serial = [pipeline.detect_3d_images(mdl, *p) for p in pairs]
-    streamed = list(pipeline.detect_3d_stream(mdl, pairs + pairs, slots=3))
-    assert len(streamed) == 8
-    for want, got in zip(serial + serial, streamed):
-        assert len(want) == len(got)
-        for x, y in zip(want, got):
-            assert np.array_equal(x['box_left'], y['box_left']) and x['aligned'] == y['aligned']
-            assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta']
+    for solver in ('device', 'host'):
+        serial = [pipeline.detect_3d_images(mdl, *p, solver=solver) for p in pairs]
+        streamed = list(pipeline.detect_3d_stream(mdl, pairs + pairs, slots=3, solver=solver))
+        assert len(streamed) == 8
+        for want, got in zip(serial + serial, streamed):
+            assert len(want) == len(got)
+            for x, y in zip(want, got):
+                assert np.array_equal(x['box_left'], y['box_left']) and x['aligned'] == y['aligned']
+                assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta']
 
 
 def test_pipeline_falls_back_to_fp32_when_the_split16_range_is_exceeded(dev):

@@ -88,26 +88,13 @@ def test_solvers_recover_pose_and_agree_statistically():
     assert np.median(err) < 0.02                 # depth recovered to ~2 % on clean synthetic observations
 
 
-def _mul_evaluate():
-    """_Terms.evaluate with every `v ** 2` written `v * v`: what the native code computes (glibc's pow(v, 2.0) differs from
-    the correctly rounded v * v in ~0.06 % of the calls; numpy scalars go through pow)."""
-    import inspect
-    import re
-    import textwrap
-    src = inspect.getsource(pbe._Terms.evaluate)
-    src = re.sub(r'(\w+) \*\* 2', r'(\1 * \1)', src).replace('(-x / z) ** 2', '((-x / z) * (-x / z))')
-    assert '** 2' not in src
-    ns = {}
-    exec(textwrap.dedent(src), {'np': np, 'm': math}, ns)
-    return ns['evaluate']
-
-
-def test_native_newton_cg_is_scipys_iteration_bit_for_bit(monkeypatch):
-    """csrc/box_solver.h (the code the device kernels run, here in its host build) against scipy.optimize's Newton-CG on
-    the same cost / gradient arithmetic: END POINTS BIT-IDENTICAL on every case, 4-DoF and 3-DoF.  I.e. the optimiser --
-    CG loop, finite-difference Hessian products, MINPACK-2 dcsrch, the wolfe2 / zoom fall-back, every stopping rule -- is
-    restated exactly; np.dot is matched as the fused multiply-add chain OpenBLAS' ddot runs on x86."""
-    monkeypatch.setattr(pbe._Terms, 'evaluate', _mul_evaluate())
+def test_native_newton_cg_is_scipys_iteration_bit_for_bit():
+    """csrc/box_solver.h in its host build against the Python path as shipped (scipy.optimize's Newton-CG on the reference's
+    cost / gradient): END POINTS BIT-IDENTICAL on every case, 4-DoF and 3-DoF.  I.e. the optimiser -- CG loop,
+    finite-difference Hessian products, MINPACK-2 dcsrch, the wolfe2 / zoom fall-back, every stopping rule -- is restated
+    exactly; np.dot is matched as the fused multiply-add chain OpenBLAS' ddot runs on x86, and `v ** 2` as libm's
+    pow(v, 2.0) (not always the correctly rounded v * v).  The device build of the same header squares exactly and uses
+    ocml's cos / sin: its end points are compared on the GPU (tests/test_box3d_gpu.py)."""
     rng = np.random.default_rng(3)
     n4 = n3 = 0
     for _ in range(120):
@@ -128,8 +115,8 @@ def test_native_newton_cg_is_scipys_iteration_bit_for_bit(monkeypatch):
 
 
 def test_native_solver_vs_scipy_path_as_shipped():
-    """Against the Python path as it is (`** 2` through pow): cost / gradient equal to rounding, >= 90 % of the end points
-    bit-identical, the rest are the chaotic ones set off by a last-bit pow difference."""
+    """Perturbed evaluation points: cost / gradient of the native code equal the Python path's to the last bit, and so do the
+    end points of both solvers on every case."""
     rng = np.random.default_rng(5)
     same4, same3, d4, dc, dg = [], [], [], [], []
     for _ in range(150):
@@ -150,10 +137,10 @@ def test_native_solver_vs_scipy_path_as_shipped():
         r_ref, _ = pbe.solve_x_y_theta_from_kpt(IM_SHAPE, calib, alpha, dim, bl, disp, kp)
         r_nat, _ = pbe.solve_x_y_theta_from_kpt_native(IM_SHAPE, calib, alpha, dim, bl, disp, kp)
         same3.append(np.array_equal(r_nat, r_ref))
-    assert max(dc) < 1e-13 and max(dg) < 1e-9
+    assert max(dc) == 0 and max(dg) == 0
     print('native vs scipy path: bit-identical 4-DoF %.3f, 3-DoF %.3f; 4-DoF L-inf median %.1e max %.1e'
           % (np.mean(same4), np.mean(same3), np.median(d4), np.max(d4)))
-    assert np.mean(same4) >= 0.90 and np.mean(same3) >= 0.95
+    assert np.mean(same4) == 1.0 and np.mean(same3) == 1.0
 
 
 def test_native_solver_with_float32_rows_as_the_pipeline_passes_them():
@@ -254,3 +241,66 @@ def test_solver_pool_matches_serial():
         par = pool.map(tasks)
     for a, b in zip(serial, par):
         assert np.array_equal(np.asarray(a[0]), np.asarray(b[0])) and np.array_equal(np.asarray(a[1]), np.asarray(b[1]))
+
+
+def test_record_forms_on_the_host_equal_the_scipy_path_bit_for_bit():
+    """srcnn_solve_4dof_records_host / srcnn_solve_3dof_records_host (what pipeline solver='host' runs between the device
+    stages) on a synthetic image record: every row's status and end point equal to the Python scipy path called as demo.py
+    calls it (float32 rows for the 4-DoF solve; float32 alpha / dim, double boxes for the 3-DoF one), for any thread count."""
+    import ctypes
+    from stereo_rcnn_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    calib = KITTI_DEMO_CALIB
+    n, k = 64, 40
+    rec = np.zeros((n + 1, _lib.REC_COLS), np.float32)
+    rec[0, 0] = k
+    cases = []
+    for i in range(k):
+        _, pose, dim, bl, br, kp, alpha = _case(rng)
+        row = rec[1 + i]
+        row[0] = 0.9 if i % 7 else 0.01                      # one in seven below the threshold
+        row[1:5], row[5:9], row[9:12] = bl, br, dim
+        row[12], row[13] = math.sin(alpha), math.cos(alpha)
+        row[14:19] = kp
+        cases.append(pose)
+    cal = (float(calib.p2[0, 0]), float(calib.p2[0, 2]), float(calib.p2[1, 2]), float(calib.p2[0, 3] - calib.p3[0, 3]))
+    outs = []
+    for threads in (1, 5):
+        r, st = rec.copy(), np.full((2, n, 4), 7.0)
+        assert L.srcnn_solve_4dof_records_host(r.ctypes.data, n, _lib.REC_COLS, 375, 1242, *cal, 0.05, st[0].ctypes.data, threads) == 0
+        status = (r[1:k + 1, 20] > 0).astype(np.float32)
+        status[::3] = 0                                       # alignment "failed" on a third of them
+        dis = np.zeros(n, np.float32)
+        dis[:k] = [cal[0] * (cal[3] / cal[0]) / max(p[2], 1.0) * 1.01 for p in cases]
+        full = np.zeros(n, np.float32); full[:k] = status
+        assert L.srcnn_solve_3dof_records_host(r.ctypes.data, n, _lib.REC_COLS, 375, 1242, *cal, full.ctypes.data, dis.ctypes.data,
+                                               st[1].ctypes.data, threads) == 0
+        outs.append((r, st.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1][0], outs[1][1][0])
+    r, st = outs[0]
+    assert (st[0, k:] == 0).all()
+    n4 = n3 = 0
+    for i in range(k):
+        row = rec[1 + i]
+        if not row[0] > 0.05:
+            assert r[1 + i, 20] == 0 and (st[0, i] == 0).all()
+            continue
+        alpha = math.atan2(row[12], row[13])
+        s_ref, b = pbe.solve_x_y_z_theta_from_kpt(IM_SHAPE, calib, alpha, row[9:12], row[1:5], row[5:9], row[14:19])
+        assert int(r[1 + i, 20]) == int(s_ref)
+        if not s_ref:
+            continue
+        assert np.array_equal(st[0, i], np.asarray(b, np.float64)), (i, st[0, i], b)
+        assert np.array_equal(r[1 + i, 21:25], np.asarray(b, np.float32))
+        n4 += 1
+        if not (full[i] > 0):
+            assert r[1 + i, 25] == 0
+            continue
+        f64 = lambda v: np.asarray(v, np.float64)
+        state, z = pbe.solve_x_y_theta_from_kpt(IM_SHAPE, calib, float(np.float32(alpha)), f64(row[9:12]), f64(row[1:5]),
+                                                float(dis[i]), f64(row[14:19]))
+        assert np.array_equal(st[1, i], np.array([state[0], state[1], z, state[2]])), (i, st[1, i], state, z)
+        assert r[1 + i, 26] == dis[i] and r[1 + i, 25] == 1
+        n3 += 1
+    assert n4 >= 25 and n3 >= 12

@@ -44,7 +44,7 @@ if __name__ == '__main__':
     calib = demo_calib()
     shape = (375, 1242, 3)
     res = {}
-    for mode in ('device', 'host', 'scipy'):
+    for mode in ('device', 'host', 'host_py', 'scipy'):
         for it in range(3):
             torch.cuda.synchronize(); t0 = time.time()
             objs = pipeline.detect_3d(m, l, r, info, calib, shape, solver=mode)
@@ -57,13 +57,22 @@ if __name__ == '__main__':
     N = 48
     for slots in (1, 2, 3, 4):
         frames = [(l, r, info, calib, shape, float(info[0, 2]))] * N
-        list(pipeline.detect_3d_stream(m, frames[:2 * slots], slots=slots))
+        list(pipeline.detect_3d_stream(m, frames[:2 * slots], slots=slots, solver='device'))
         torch.cuda.synchronize(); t0 = time.time()
-        out = list(pipeline.detect_3d_stream(m, frames, slots=slots))
+        out = list(pipeline.detect_3d_stream(m, frames, slots=slots, solver='device'))
         torch.cuda.synchronize(); dt = time.time() - t0
         ok = all(len(o) == len(res['device']) and all(np.array_equal(a['xyz'], b['xyz']) for a, b in zip(res['device'], o)) for o in out)
         print('streaming, device 3-D stage, %d pairs in flight: %.2f ms/pair = %.1f pairs/s (%d objects each), identical to serial: %s'
               % (slots, dt * 1e3 / N, N / dt, len(res['device']), ok))
+    for slots in (1, 2, 3, 4):
+        frames = [(l, r, info, calib, shape, float(info[0, 2]))] * N
+        list(pipeline.detect_3d_stream(m, frames[:2 * slots], slots=slots, solver='host'))
+        torch.cuda.synchronize(); t0 = time.time()
+        out = list(pipeline.detect_3d_stream(m, frames, slots=slots, solver='host'))
+        torch.cuda.synchronize(); dt = time.time() - t0
+        ok = all(len(o) == len(res['scipy']) and all(np.array_equal(a['xyz'], b['xyz']) for a, b in zip(res['scipy'], o)) for o in out)
+        print('streaming, host Newton-CG between device stages, %d pairs in flight: %.2f ms/pair = %.1f pairs/s, identical to the scipy flow: %s'
+              % (slots, dt * 1e3 / N, N / dt, ok))
     frames = [(lu8, ru8, calib)] * N
     list(pipeline.detect_3d_stream(m, frames[:6], slots=3))
     torch.cuda.synchronize(); t0 = time.time()
