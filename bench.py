@@ -60,6 +60,9 @@ def parse():
                          'written after the run otherwise (used to keep the rocprofv3 kernel statistics free of trial plans)')
     ap.add_argument('--gather-every', type=int, default=8,
                     help='(multi-GPU) steps whose detection records share one RCCL all_gather')
+    ap.add_argument('--no-3d-leg', action='store_true',
+                    help='skip the short full-3-D-flow measurement (configs[2] flow: + borders, 4-DoF solve, dense alignment, '
+                         '3-DoF rectification) that the default line carries as `config.full_3d_flow`')
     ap.add_argument('--no-f32-leg', action='store_true',
                     help='skip the short exact-fp32-engine measurement that the default line carries as `engines.f32`')
     ap.add_argument('--dry-run', action='store_true',
@@ -415,6 +418,33 @@ def main():
             model.use_graph = use_graph
             model.use_program = use_program
 
+    # ---- the whole 3-D flow of the same pair (the metric's "3D box" half; BASELINE configs[2] minus the batch): short,
+    #      N = 1 only, outside the timed region, reported beside the headline -- never as `value`
+    full3d = None
+    if rank == 0 and world == 1 and not args.no_3d_leg:
+        import numpy as np
+        from stereo_rcnn_amd import pipeline
+        from stereo_rcnn_amd.model.utils import kitti_utils
+        calib = kitti_utils.FrameCalibrationData()            # KITTI object calibration of the reference's demo pair
+        calib.p2 = np.array([721.5377, 0, 609.5593, 44.85728, 0, 721.5377, 172.854, 0.2163791, 0, 0, 1, 0.002745884]).reshape(3, 4)
+        calib.p3 = np.array([721.5377, 0, 609.5593, -339.5242, 0, 721.5377, 172.854, 2.199936, 0, 0, 1, 0.002729905]).reshape(3, 4)
+        calib.t_cam2_cam0 = np.array([calib.p2[0, 3] / calib.p2[0, 0], 0, 0])
+        frame = (im_l, im_r, im_info, calib, (args.height, args.width, 3), float(im_info[0, 2]))
+        nfr = max(6, min(args.steps, 36))
+        full3d = {'pairs_in_flight': 3, 'frames': nfr}
+        for solver in ('host', 'device'):
+            list(pipeline.detect_3d_stream(model, [frame] * 6, slots=3, solver=solver))
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            outs = list(pipeline.detect_3d_stream(model, [frame] * nfr, slots=3, solver=solver))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t4
+            full3d[solver] = {'value': round(nfr / dt, 3), 'ms_per_pair': round(dt / nfr * 1e3, 3), 'objects_per_pair': len(outs[0]),
+                              'aligned_per_pair': int(sum(o['aligned'] for o in outs[0]))}
+        full3d['note'] = ("forward + decode + class NMS + borders + 4-DoF Newton-CG + dense alignment + 3-DoF Newton-CG per pair; "
+                          "'host' = solves in C on the host between the device stages (bit-identical to the reference's scipy "
+                          "path), 'device' = solves as kernels")
+
     if rank == 0:
         pairs = args.steps * world
         res = {
@@ -432,6 +462,7 @@ def main():
                        'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
                        'host_enqueue_ms_per_step_idle_gpu': round(host_enqueue_idle_ms, 3), 'plans_preloaded': plans_loaded,
                        'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single, 'engines': engines,
+                       'full_3d_flow': full3d,
                        'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},
             'roofline': roofline,
         }
