@@ -249,6 +249,25 @@ def test_host_solver_streaming_equals_serial(dev):
                 assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta']
 
 
+def test_no_detection_and_no_alignment_edges(dev):
+    """Edge cases of the record flow for both solver placements: a threshold nothing passes (empty record: no solve, no
+    alignment, empty list), and dense_align=False (4-DoF results only)."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    l, r, info = fixture.make_inputs(3, 120, 400, target_short=192)
+    args = (mdl, l.to(dev), r.to(dev), info.to(dev), calib, (120, 400, 3))
+    for solver in ('host', 'device'):
+        assert pipeline.detect_3d(*args, eval_thresh=2.0, solver=solver) == []
+        assert list(pipeline.detect_3d_stream(mdl, [args[1:] + (float(info[0, 2]),)] * 3, eval_thresh=2.0, solver=solver)) == [[], [], []]
+        full = pipeline.detect_3d(*args, solver=solver)
+        init = pipeline.detect_3d(*args, dense_align=False, solver=solver)
+        assert len(init) == len(full) > 0
+        for a, b in zip(init, full):
+            assert not a['aligned'] and np.array_equal(a['xyz'], b['xyz_init']) and a['theta'] == b['theta_init']
+            assert np.array_equal(a['xyz'], a['xyz_init'])
+
+
 def test_streaming_equals_serial_and_images_entry(dev):
     from oracle.dense_align import KITTI_DEMO_CALIB as calib
     from stereo_rcnn_amd import fixture, pipeline
