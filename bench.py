@@ -336,7 +336,7 @@ def main():
                 step(gather=False)
             torch.cuda.synchronize()
             serial_ms = (time.perf_counter() - t2) * 1e3 / nprof        # same execution, events off
-            engine.FlopCounter.enabled, engine.FlopCounter.flops, engine.FlopCounter.launches = True, 0.0, 0
+            engine.FlopCounter.enabled, engine.FlopCounter.flops, engine.FlopCounter.launches, engine.FlopCounter.bytes = True, 0.0, 0, 0.0
             L.srcnn_prof_enable(1)
             for _ in range(nprof):
                 step(gather=False)
@@ -351,6 +351,7 @@ def main():
             issued = 3.0 if args.precision == 'f16x3' else 1.0     # MFMA flops issued per algorithmic flop
             launches = int(cnt.value // nprof)
             alg_step = alg / nprof
+            alg_bytes_launch = engine.FlopCounter.bytes / max(engine.FlopCounter.launches, 1)   # compulsory bytes per conv launch
             # HBM-side bytes per conv launch: PMC counters cannot be read from inside this process, so they come from the
             # newest committed rocprofv3 --pmc summary -- but ONLY if that file was measured on these kernel sources
             # (it carries the sha256 of stereo_rcnn_amd/csrc/*); otherwise traffic is null, never a stale number.
@@ -368,13 +369,18 @@ def main():
                     traffic = round((2.0 * pm['conv_fetch_size_kb_per_step'] + pm['conv_write_size_kb_per_step']) * 1024.0
                                     / max(launches, 1))
                     traffic_note = ('bytes per conv launch, HBM side: (2 x FETCH_SIZE + WRITE_SIZE) of the conv-engine launches of '
-                                    'one step / launches, separate rocprofv3 --pmc passes on these sources (%s); algorithmic: '
-                                    '~%.0f MB per launch' % (os.path.basename(tj[-1]), pm.get('algorithmic_mb_per_launch', 38)))
+                                    'one step / launches, separate rocprofv3 --pmc passes on these sources (%s; FETCH_SIZE doubled '
+                                    'as the gfx950 note prescribes -- uncorrected it is %.1f MB); compulsory bytes of the same launches '
+                                    '(every operand element read once, every result written once, 4 B each): `algorithmic_bytes_per_launch`'
+                                    % (os.path.basename(tj[-1]),
+                                       (pm['conv_fetch_size_kb_per_step'] + pm['conv_write_size_kb_per_step']) * 1024.0 / max(launches, 1) / 1e6))
             head_ms = elapsed / args.steps * 1e3
             roofline = {'bound': 'mfma', 'kernel': ENGINE_DESC[args.precision],
                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': round(achieved / peak, 4), 'traffic': traffic,
                         'traffic_note': traffic_note,
+                        'algorithmic_bytes_per_launch': round(alg_bytes_launch),
+                        'traffic_over_algorithmic': (round(traffic / alg_bytes_launch, 3) if traffic else None),
                         'issued_mfma_frac': round(achieved * issued / peak, 4),
                         'launches_per_step': launches,
                         'avg_launch_ms': round(ms.value / max(cnt.value, 1), 5),

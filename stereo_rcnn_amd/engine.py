@@ -88,10 +88,14 @@ def conv_out_hw(h, w, k_h, k_w, stride, pad):
 
 
 class FlopCounter(object):
-    """Algorithmic conv FLOPs (2*M*N*K with the true K) of the launches issued while enabled."""
+    """Algorithmic conv FLOPs (2*M*N*K with the true K) of the launches issued while enabled, and their COMPULSORY bytes:
+    every operand element the launch needs read once and every result written once, at the 4 bytes per element both activation
+    formats and both weight forms (fp32, or hi + lo f16) occupy -- input pixels x Cin (only the sampled pixels of a strided
+    1x1), weights Cout x K, residual and output M x Cout."""
     enabled = False
     flops = 0.0
     launches = 0
+    bytes = 0.0
 
 
 # ---- SPLIT16 range guard (include/srcnn_hip.h: srcnn_range_flag_read): layers are tagged by name so that a tripped flag
@@ -254,6 +258,8 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
+        px_in = B * OH * OW if (cw.kh == 1 and cw.kw == 1) else B * H * W
+        FlopCounter.bytes += 4.0 * (px_in * cw.cin + cw.cout * cw.alg_k + B * OH * OW * cw.cout * (2 if residual is not None else 1))
     if plan is not None:                   # explicit (tile_mr, tile_nr, waves, stages, splits): tests and tools
         _set_plan(d, plan)
     elif AUTOTUNE:
@@ -291,6 +297,7 @@ def conv_block(conv2, conv3, x, B, H, W, y, residual, name=None):
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * H * W * (conv2.cout * conv2.alg_k + conv3.cout * conv3.alg_k)
         FlopCounter.launches += 1
+        FlopCounter.bytes += 4.0 * (B * H * W * (conv2.cin + 2 * conv3.cout) + conv2.cout * conv2.alg_k + conv3.cout * conv3.alg_k)
     _lib.check(_lib.lib().srcnn_conv_block(ctypes.byref(d), _lib.stream()), "srcnn_conv_block")
 
 
