@@ -68,11 +68,12 @@ with torch.no_grad():
     st.event.synchronize()
     ref_rec, ref_state = st.rec_host.numpy().copy(), st.state_host.numpy().copy()
     k0 = int(ref_rec[0, 0])
+    FR = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     for S in (3, 3, 3):
         streams = [torch.cuda.Stream() for _ in range(S)]
         pend = []
         nbad = 0
-        for k in range(40 * S):
+        for k in range(FR * S):
             s = k % S
             if len(pend) == S:
                 h = pend.pop(0)
@@ -99,4 +100,4 @@ with torch.no_grad():
                 out = m(l, r, info, slot=s)
                 pend.append(pipeline.launch_3d(out, l, r, info, float(info[0, 2]), calib, shape, slot=s))
         torch.cuda.synchronize()
-        print('%d in flight: %d of %d frames differ' % (S, nbad, 40 * S - S), flush=True)
+        print('%d in flight: %d of %d frames differ' % (S, nbad, FR * S - S), flush=True)
