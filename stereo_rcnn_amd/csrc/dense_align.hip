@@ -58,7 +58,9 @@ struct BoxGeom {
     float planes[3][4];
 };
 
-__device__ void build_box(const float *pose, BoxGeom &g)
+// Pc: the 8 vertices in camera coordinates live in LDS (`pc`, written identically by every calling lane): they are read back by
+// data-dependent index, and a dynamically indexed REGISTER array would be lowered to GPR-index mode
+__device__ void build_box(const float *pose, BoxGeom &g, float (*Pc)[3])
 {
     const double sx = (double)pose[3], sy = (double)pose[4], sz = (double)pose[5], th = (double)pose[6];
     const float c = (float)cos(th), s = (float)sin(th);
@@ -69,7 +71,6 @@ __device__ void build_box(const float *pose, BoxGeom &g)
     const float hx = (float)(sx / 2), hz = (float)(sz / 2.0), hy = (float)sy;
     const float Po[8][3] = {{-hx, 0, -hz}, {-hx, 0, hz}, {hx, 0, hz}, {hx, 0, -hz},
                             {-hx, -hy, -hz}, {-hx, -hy, hz}, {hx, -hy, hz}, {hx, -hy, -hz}};   // box_3d.py:21-29
-    float Pc[8][3];
     int nearest = 0;
     float best = 100000000.f;
     for (int i = 0; i < 8; ++i) {
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ b
     __shared__ int wave_cnt[4];
     __shared__ int s_base;
     __shared__ BoxGeom s_g;
+    __shared__ float s_pc[8][3];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (valid && !(valid[r] > 0.f)) {            // masked row of a fixed-size batch: an object with no sample (status 0)
         if (tid == 0) { cnt[r] = 0; cnt[gridDim.x + r] = 0; }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ b
     // (0 of 3000 calls) and does 1/4 of the double-precision trigonometry; the cause itself is not established.
     if (wv == 0) {
         BoxGeom mine;
-        build_box(poses + r * 7, mine);
+        build_box(poses + r * 7, mine, s_pc);
         if (lane == 0) s_g = mine;
     }
     const float fcx = (float)cal.cx, fcy = (float)cal.cy, ff = (float)cal.f;

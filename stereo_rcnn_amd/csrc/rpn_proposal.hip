@@ -124,11 +124,27 @@ __global__ __launch_bounds__(64) void tk_pick_kernel(TkState *state, unsigned *_
         unsigned cum = before;
         int d = 0;
         unsigned h = 0;
-        for (int i = 0; i < 32; ++i) {
-            d = kind == 0 ? 31 - i : i;
-            h = mine[d];
-            if (cum + h >= rem) break;
-            cum += h;
+        // statically indexed walk (no dynamically indexed register array: hipcc lowers that to GPR-index mode, the form most
+        // exposed to the lane-quarter effect of profiles/dense_align_repeatability_r02.txt -- and this lane may be one of 48-63)
+        bool done = false;
+        if (kind == 0) {
+#pragma unroll
+            for (int i = 31; i >= 0; --i) {
+                const unsigned hv = mine[i];
+                const bool stop = !done && cum + hv >= rem;
+                if (stop) { d = i; h = hv; }
+                if (!done && !stop) cum += hv;
+                done = done || stop;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const unsigned hv = mine[i];
+                const bool stop = !done && cum + hv >= rem;
+                if (stop) { d = i; h = hv; }
+                if (!done && !stop) cum += hv;
+                done = done || stop;
+            }
         }
         const unsigned digit = (unsigned)(lane * 32 + d);
         st.remaining = rem - cum;

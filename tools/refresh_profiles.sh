@@ -47,4 +47,8 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
 done
 python $R/tools/pmc_sum.py $O/pmc 5 $O/pmc_${TAG}_traffic.json > $O/pmc_${TAG}_f16x3_bench_sums.txt 2>&1
 rm -rf $O/pmc
+# the headline line once more, now that the PMC traffic file of THESE sources exists (bench.py quotes it only on a hash match)
+cp $O/pmc_${TAG}_traffic.json $R/profiles/pmc_${TAG}_traffic.json
+cd $R
+python bench.py --plans /tmp/plans_${TAG}.json > $O/bench_${TAG}_f16x3.json 2>> $O/bench_err.log
 ls -la $O
