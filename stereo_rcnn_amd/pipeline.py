@@ -386,6 +386,19 @@ def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, 
     return collect_3d(st) if wait else st
 
 
+_stream_cache = {}
+
+
+def _slot_streams(n):
+    """The in-flight slots' HIP streams, created once per device: per-stream scratch buffers (_lib.workspace) and recorded launch
+    programs are keyed by stream, so fresh streams on every call would grow them without bound."""
+    dev = torch.cuda.current_device()
+    have = _stream_cache.setdefault(dev, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream())
+    return have[:n]
+
+
 def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=3, solver='host'):
     """Generator form for a sequence of pairs: yields one object list per frame, in order, with up to `slots` pairs in flight
     on their own HIP streams.  frames: iterable of (im_left_data, im_right_data, im_info, calib, im_shape[, scale]) with device
@@ -398,7 +411,7 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
             yield objs
         return
     from . import engine
-    streams = [torch.cuda.Stream() for _ in range(max(1, slots))]
+    streams = _slot_streams(max(1, slots))
     inflight = collections.deque()
 
     def finish(entry):
@@ -453,7 +466,7 @@ def _detect_3d_stream_scipy(model, frames, pool, eval_thresh, class_index, dense
     pool, async) -> dense alignment (GPU, async) -> 3-DoF tasks (pool, async) -> results; every loop iteration launches the
     next pair's forward and moves each pair in flight one stage on."""
     from . import distributed as sdist
-    streams = [torch.cuda.Stream() for _ in range(max(1, slots))]
+    streams = _slot_streams(max(1, slots))
     inflight = collections.deque()
 
     def launch(k, frame):
