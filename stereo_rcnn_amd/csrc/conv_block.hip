@@ -585,9 +585,14 @@ int srcnn_conv_block(const srcnn_block_desc *d, srcnn_stream_t stream)
     hipStream_t st = as_stream(stream);
     const bool prof = prof_enabled();
     if (prof) prof_begin(st);
-    // debug / tuning knobs (read once): SRCNN_BLK_FLAGS = kernel flags, SRCNN_BLK_VARIANT = bit 0 PB schedule in phase 1, bit 1 in phase 2
+    // timing-experiment knobs of profiles/fused_block_r02.txt (flags bit 1 / 2 produce INVALID results): compiled in only with
+    // -DSRCNN_BLOCK_EXPERIMENTS, never in the shipped library.  variant: bit 0 PB schedule in phase 1, bit 1 in phase 2.
+#ifdef SRCNN_BLOCK_EXPERIMENTS
     static const int env_flags = getenv("SRCNN_BLK_FLAGS") ? atoi(getenv("SRCNN_BLK_FLAGS")) : 0;
     static const int env_variant = getenv("SRCNN_BLK_VARIANT") ? atoi(getenv("SRCNN_BLK_VARIANT")) : 2;
+#else
+    const int env_flags = 0, env_variant = 2;
+#endif
     a.flags = env_flags;
     a.stamp = debug_stamp_buffer();
     a.range_flag = range_flag_word();
