@@ -123,39 +123,20 @@ typedef struct srcnn_conv_desc {
     /* launch plan override (0 = built-in heuristic): workgroup tile = (64*tile_mr) x (64*tile_nr), tile_mr/tile_nr
      * in {1,2}; splits = number of K slices (deterministic workspace reduction).  The SPLIT16 f16x3 engine also
      * takes tile_waves (4 or 8 wavefronts per workgroup; 0 = 4) and tile_stages (LDS ring depth 2..4 = K tiles of
-     * DMA in flight + 1; 0 = 2), and with 8 waves tile_mr = 4 (256x128).  An override the engine does not
+     * DMA in flight + 1; 0 = 2), and with 8 waves tile_mr = 4 (256x128, 3 stages) and tile_mr = tile_nr = 4 (256x256,
+     * 2 stages; layers whose channel counts / offsets are multiples of 8).  An override the engine does not
      * implement falls back to the heuristic.  Lets the host autotune each layer shape on the device it runs on. */
     int tile_mr, tile_nr, splits;
     /* activation formats (SRCNN_FMT_*).  SPLIT16: per pixel, each group of 8 channels is stored as
      * [8 x f16 hi][8 x f16 lo] (hi = f16(v), lo = f16(v - hi); same bytes as float32, channel strides
      * are still given in float32-equivalents).  With precision 1 and x_format SPLIT16 both GEMM
-     * operands are DMA'd straight into LDS (global_load_lds).  fp32 engine: all formats must be F32. */
+     * operands are DMA'd straight into LDS (buffer_load ... lds; one image of x must be <= 512 MB).  fp32 engine: all formats must be F32. */
     int x_format, y_format, res_format;
     int tile_waves, tile_stages;
     int layer_tag;         /* caller's id of this layer (> 0) for srcnn_range_flag_read; 0 = untagged */
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
-
-/* Fused tail of a ResNet bottleneck (resnet.py:82-101): y = relu(bn3(conv3(relu(bn2(conv2(x))))) + residual) in one launch
- * -- conv2 3x3 / stride 1 / pad 1 (C -> C), conv3 1x1 (C -> 4C), frozen BN folded by the caller as for srcnn_conv2d.
- * f16x3 engine only (precision 1 arithmetic, bit-for-bit the accumulation order of the stand-alone kernel's 8-wave
- * 32x64-per-wave plans), every activation in SRCNN_FMT_SPLIT16: x (B,H,W,C), residual and y (B,H,W,4C), dense channel
- * strides.  The C-channel intermediate stays in LDS.  C in {64, 128, 256} (layer1..3). */
-typedef struct srcnn_block_desc {
-    const void *x;
-    const void *w2_hi, *w2_lo;   /* (C, 3, 3, C) _Float16 halves of w2 * 2^k2 */
-    const float *bias2;          /* (C) */
-    float w2_inv_scale;          /* 2^-k2 */
-    const void *w3_hi, *w3_lo;   /* (4C, 1, 1, C) */
-    const float *bias3;          /* (4C) */
-    float w3_inv_scale;
-    const void *residual;
-    void *y;
-    int B, H, W, C;
-    int layer_tag;
-} srcnn_block_desc;
-SRCNN_API int srcnn_conv_block(const srcnn_block_desc *d, srcnn_stream_t stream);
 
 /* SPLIT16 range guard.  The format stores hi = f16(v) unscaled: an activation beyond +-65504 (or a NaN) becomes inf and
  * poisons what it touches, where the fp32 engine would carry on.  Every kernel that writes SPLIT16 from fresh arithmetic

@@ -34,14 +34,6 @@ class ConvDesc(ctypes.Structure):
                 ("tile_waves", c_int), ("tile_stages", c_int), ("layer_tag", c_int)]
 
 
-class BlockDesc(ctypes.Structure):
-    """struct srcnn_block_desc (include/srcnn_hip.h)."""
-    _fields_ = [("x", c_void_p), ("w2_hi", c_void_p), ("w2_lo", c_void_p), ("bias2", c_void_p), ("w2_inv_scale", c_float),
-                ("w3_hi", c_void_p), ("w3_lo", c_void_p), ("bias3", c_void_p), ("w3_inv_scale", c_float),
-                ("residual", c_void_p), ("y", c_void_p), ("B", c_int), ("H", c_int), ("W", c_int), ("C", c_int),
-                ("layer_tag", c_int)]
-
-
 _SIGNATURES = {
     # name: (restype, argtypes)
     "srcnn_version": (c_int, []),
@@ -62,7 +54,6 @@ _SIGNATURES = {
     "srcnn_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_size_t, c_void_p]),
     "srcnn_range_flag_read": (c_int, [c_int]),
     "srcnn_range_flag_device_word": (c_void_p, []),
-    "srcnn_conv_block": (c_int, [ctypes.POINTER(BlockDesc), c_void_p]),
     "srcnn_preprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_stem_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_maxpool3x3s2_ceil": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

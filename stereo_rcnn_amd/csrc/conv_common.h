@@ -14,8 +14,8 @@ struct ConvArgs {
     float *y, *partial;
     const void *w_lo;   // f16x3 engine: w = hi halves, w_lo = lo halves (both (Cout, K) _Float16)
     float out_scale;    // f16x3 engine: 1 / (power-of-two weight scale)
-    const void *zero_page;        // >= 256 zero bytes in HBM (padding source of the direct-to-LDS loads)
     int x_fmt, y_fmt, res_fmt;    // SRCNN_FMT_F32 / SRCNN_FMT_SPLIT16
+    int nimg;                     // images reachable from x (descriptor range of the SPLIT16 engine's DMA)
     int H, W, Cin, xcs;
     int OH, OW, Cout;
     int KH, KW, stride, pad;
@@ -125,7 +125,6 @@ struct Plan {
 
 void launch_conv_f16x3(const ConvArgs &a, const Plan &pl, hipStream_t st);   // A operand fp32 in HBM
 void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st);    // A operand split16 in HBM
-bool conv_f16s_plan_ok(const Plan &pl);
-const void *zero_page();
+bool conv_f16s_plan_ok(const Plan &pl, const ConvArgs &a);
 
 }  // namespace srcnn

@@ -8,10 +8,14 @@
 // operand chunks.  Both the A (activation) and B (weight) panels are then filled with
 // global_load_lds_dwordx4 -- no VGPR staging, no conversions, no ds_write: per K tile a wave
 // issues 2*(MR+NR) DMA loads, 4*(MR+NR) ds_read_b128 and 12*MR*NR MFMAs.
+//   * the DMAs are buffer loads (buffer_load_dwordx4 ... lds): a 128-bit descriptor in SGPRs, ONE 32-bit VGPR offset per
+//     16-row group and a scalar offset that walks the K tiles -- in steady state the address stream costs no vector
+//     instruction and no 64-bit pointer registers (a tap change of a 3x3 layer re-derives the lane offsets, nothing else);
 //   * the LDS image of a DMA is lane-linear (wave base + lane*16), so the XOR chunk swizzle that
 //     keeps ds_read_b128 conflict-free is applied on the SOURCE side: lane (row=l>>2, slot=l&3)
 //     fetches chunk slot ^ ((row>>2)&3) of its row;
-//   * zero padding (image borders, M/N tails) = lanes pointed at a zero page in HBM;
+//   * zero padding (image borders, M/N tails) = lanes whose offset lies outside the descriptor's range: the
+//     hardware bounds check writes zeros to LDS without touching memory;
 //   * NS-stage LDS ring; the one barrier per K tile is preceded by a hand-written `s_waitcnt vmcnt(n)`
 //     that waits only for the OLDEST tile in flight (vector-memory results return in order), so NS-1
 //     (or NS, see PB below) tiles of DMA stay outstanding across barriers -- the L2 -> LDS path
@@ -38,15 +42,34 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int SROW = BK;   // halves per LDS row (64 B), chunks XOR-swizzled
 
-// one global_load_lds_dwordx4: every lane moves 16 B from its own global address to
-// (wave-uniform LDS base) + lane*16.  Device-only builtin, hence the guard for the host pass.
-__device__ __forceinline__ void dma16(const void *gsrc, _Float16 *lds_wave_base)
+// one buffer_load_dwordx4 ... lds: every lane moves 16 B from (descriptor base + its own 32-bit offset + a wave-uniform
+// scalar offset + IMM) to (wave-uniform LDS base) + lane*16; lanes whose offset is outside the descriptor's num_records
+// write zeros.  Device-only builtin, hence the guard for the host pass.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#else
+struct rsrc_t {};            // host pass: the kernel body is parsed, never run
+#endif
+constexpr int OOB = (int)0x80000000u;      // lane offset of a padded row: beyond any descriptor (num_records <= 2^31 - 1)
+
+template <int IMM>
+__device__ __forceinline__ void dma16b(rsrc_t rsrc, int voff, int soff, _Float16 *lds_wave_base)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds_wave_base, 16, voff, soff, IMM, 0);
 #else
-    (void)gsrc;
-    (void)lds_wave_base;
+    (void)rsrc; (void)voff; (void)soff; (void)lds_wave_base;
+#endif
+}
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, size_t bytes)
+{
+    const unsigned n = bytes > 0x7fffffffull ? 0x7fffffffu : (unsigned)bytes;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)n, 0x00020000);
+#else
+    (void)n;
+    return rsrc_t{};
 #endif
 }
 
@@ -106,97 +129,87 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
     const int kt_end = min(p.nkt, kt_begin + p.kt_per_split);
 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    // ---- DMA geometry: wave w fills rows [w*16*MR, +16*MR) of the A panels and
-    //      [w*16*NR, +16*NR) of the B panels, 16 rows x 4 chunks per instruction.
+    // ---- DMA geometry: wave w fills rows [w*16*AG, +16*AG) of the A panels and [w*16*BG, +16*BG) of the B panels,
+    //      16 rows x 4 chunks per instruction.  Addressing = buffer descriptors: A relative to the first image this tile
+    //      touches (so any tensor size works: a tile spans at most a few images), B relative to the weight arrays.
     const int drow = lane >> 2;                               // row inside the 16-row group
     const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);         // source chunk (swizzle on the source side)
-    const char *zero = reinterpret_cast<const char *>(p.zero_page) + (lane & 3) * 16;
-    int a_ih0[AG], a_iw0[AG];
-    const char *a_base[AG];
+    const int ohw = p.OH * p.OW;
+    const int b0 = m0 / ohw;                                   // first image of this tile (workgroup-uniform)
+    const size_t img_bytes = (size_t)p.H * p.W * p.xcs * 4;
+    const rsrc_t rx = make_rsrc(reinterpret_cast<const char *>(p.x) + (size_t)b0 * img_bytes, (size_t)(p.nimg - b0) * img_bytes);
+    const rsrc_t rwh = make_rsrc(p.w, (size_t)p.Cout * p.K * 2), rwl = make_rsrc(p.w_lo, (size_t)p.Cout * p.K * 2);
+    // per-lane state of A group g: pixel index of the row's window origin relative to image b0 (negative inside the
+    // padding) and the origin (ih0, iw0) packed as two 16-bit fields for the border test; rows past M never match
+    int a_pix[AG], a_hw[AG];
 #pragma unroll
     for (int g = 0; g < AG; ++g) {
         const int m = m0 + wave * 16 * AG + g * 16 + drow;
         if (m < p.M) {
-            const int ohw = p.OH * p.OW;
             const int b = m / ohw;
             const int rem = m - b * ohw;
             const int oh = rem / p.OW;
             const int ow = rem - oh * p.OW;
-            a_ih0[g] = oh * p.stride - p.pad;
-            a_iw0[g] = ow * p.stride - p.pad;
-            a_base[g] = reinterpret_cast<const char *>(p.x) +
-                        ((size_t)((b * p.H + a_ih0[g]) * p.W + a_iw0[g]) * p.xcs) * 4 + dchunk * 32;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            a_pix[g] = ((b - b0) * p.H + ih0) * p.W + iw0;
+            a_hw[g] = (ih0 << 16) | (iw0 & 0xffff);
         } else {
-            a_ih0[g] = -(1 << 28);
-            a_iw0[g] = 0;
-            a_base[g] = zero;
+            a_pix[g] = 0;
+            a_hw[g] = (int)0x80008000u;                       // (-32768, -32768): outside every image for every tap
         }
     }
-    // ---- per-lane DMA source cursors.  A: pointer to the current (tap, channel tile) run of the lane's row, or the
-    //      zero page with step 0 when the tap falls outside the image / the row is past M.  Re-derived only when the
-    //      tap changes (every Cin/32 K tiles); otherwise one 64-bit add per K tile.  B: (row n, k) cursor, step 64 B.
-    const char *a_cur[AG];
-    int a_step[AG];
-    const char *bh_cur[BG], *bl_cur[BG];
-    int b_step[BG];
-    int ld_kh, ld_kw, ld_c0;
+    // ---- DMA source cursors.  A: lane offset of the current tap's (row, chunk) run, or OOB when the tap falls outside
+    //      the image / the row is past M; re-derived only when the tap changes (every Cin/32 K tiles).  The channel tile
+    //      inside the tap and B's K position are scalar offsets: one s_add per K tile.
+    int a_voff[AG], b_voff[BG];
+    int ld_kh, ld_kw, ld_c0, soff_b;
     {
         const int tap = kt_begin / p.ctiles;
         const int kh = tap / p.KW;
         ld_c0 = __builtin_amdgcn_readfirstlane((kt_begin - tap * p.ctiles) * BK);   // keep the tap state scalar
         ld_kh = __builtin_amdgcn_readfirstlane(kh);
         ld_kw = __builtin_amdgcn_readfirstlane(tap - kh * p.KW);
+        soff_b = __builtin_amdgcn_readfirstlane(kt_begin * BK * 2);
     }
-    auto retap = [&]() {
-        const size_t tap_off = ((size_t)(ld_kh * p.W + ld_kw) * p.xcs + ld_c0) * 4;   // wave-uniform byte offset
+    auto retap = [&]() __attribute__((always_inline)) {
+        const int tap_pix = ld_kh * p.W + ld_kw;                                      // wave-uniform
 #pragma unroll
         for (int g = 0; g < AG; ++g) {
-            const int ih = a_ih0[g] + ld_kh, iw = a_iw0[g] + ld_kw;
+            const int ih = (a_hw[g] >> 16) + ld_kh, iw = (int)(short)(a_hw[g] & 0xffff) + ld_kw;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            a_cur[g] = ok ? a_base[g] + tap_off : zero;
-            a_step[g] = ok ? BK * 4 : 0;
+            a_voff[g] = ok ? (a_pix[g] + tap_pix) * (p.xcs * 4) + dchunk * 32 : OOB;
         }
     };
     retap();
 #pragma unroll
     for (int g = 0; g < BG; ++g) {
         const int n = n0 + wave * 16 * BG + g * 16 + drow;
-        const bool ok = n < p.Cout;
-        const size_t off = ((size_t)(ok ? n : 0) * p.K + (size_t)kt_begin * BK + dchunk * 8) * 2;
-        bh_cur[g] = ok ? reinterpret_cast<const char *>(p.w) + off : zero;
-        bl_cur[g] = ok ? reinterpret_cast<const char *>(p.w_lo) + off : zero;
-        b_step[g] = ok ? BK * 2 : 0;
+        b_voff[g] = n < p.Cout ? (n * p.K + dchunk * 8) * 2 : OOB;
     }
     // one DMA instruction of the current K tile into ring stage at `stage_base` (halves); pc is a compile-time index
     // after unrolling: pieces 0..2*AG-1 = A (hi, lo per 16-row group), then B.
-    auto dma_piece = [&](int pc, _Float16 *stage_base) {
+    auto dma_piece = [&](int pc, _Float16 *stage_base) __attribute__((always_inline)) {
         _Float16 *sa_hi = stage_base + (wave * 16 * AG) * SROW;
         _Float16 *sb_hi = stage_base + 2 * PANEL_A + (wave * 16 * BG) * SROW;
+        const int soff_a = ld_c0 * 4;
         if (pc < 2 * AG) {
             const int g = pc >> 1;
-            if (pc & 1) dma16(a_cur[g] + 16, sa_hi + PANEL_A + g * 16 * SROW);
-            else dma16(a_cur[g], sa_hi + g * 16 * SROW);
+            if (pc & 1) dma16b<16>(rx, a_voff[g], soff_a, sa_hi + PANEL_A + g * 16 * SROW);
+            else dma16b<0>(rx, a_voff[g], soff_a, sa_hi + g * 16 * SROW);
         } else {
             const int g = (pc - 2 * AG) >> 1;
-            if (pc & 1) dma16(bl_cur[g], sb_hi + PANEL_B + g * 16 * SROW);
-            else dma16(bh_cur[g], sb_hi + g * 16 * SROW);
+            if (pc & 1) dma16b<0>(rwl, b_voff[g], soff_b, sb_hi + PANEL_B + g * 16 * SROW);
+            else dma16b<0>(rwh, b_voff[g], soff_b, sb_hi + g * 16 * SROW);
         }
     };
     // move the cursors to the next K tile
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
         ld_c0 += BK;
+        soff_b += BK * 2;
         if (ld_c0 == p.Cin) {
             ld_c0 = 0;
             if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
             retap();
-        } else {
-#pragma unroll
-            for (int g = 0; g < AG; ++g) a_cur[g] += a_step[g];
-        }
-#pragma unroll
-        for (int g = 0; g < BG; ++g) {
-            bh_cur[g] += b_step[g];
-            bl_cur[g] += b_step[g];
         }
     };
 
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
     const int a_row = (wm * 32 * MR + li) * SROW + r_sw, b_row = 2 * PANEL_A + (wn * 32 * NR + li) * SROW + r_sw;
     const int k_flip = (r_sw ^ 16) - r_sw;                     // second 16-wide slice of the swizzled row
     constexpr int NRD = 2 * (MR + NR);                        // ds_read_b128 per slice
-    auto read_piece = [&](Frag &f, const _Float16 *stage_base, int kk, int r) {
+    auto read_piece = [&](Frag &f, const _Float16 *stage_base, int kk, int r) __attribute__((always_inline)) {
         const _Float16 *sah = stage_base + a_row + (kk ? k_flip : 0);
         const _Float16 *sbh = stage_base + b_row + (kk ? k_flip : 0);
         if (r < 2 * MR) {
@@ -238,13 +251,13 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
             else f.bh[j] = *reinterpret_cast<const half8 *>(sbh + j * 32 * SROW);
         }
     };
-    auto read_frag = [&](Frag &f, const _Float16 *stage_base, int kk) {
+    auto read_frag = [&](Frag &f, const _Float16 *stage_base, int kk) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < NRD; ++r) read_piece(f, stage_base, kk, r);
     };
     // fetch of a slice spread behind the first MFMAs of the other slice, two reads per MFMA: the matrix pipe is fed
     // before the LDS queue (all waves fetch at the same moment, right after the barrier) has drained
-    auto read_slot = [&](Frag &f, const _Float16 *stage_base, int kk, int m) {
+    auto read_slot = [&](Frag &f, const _Float16 *stage_base, int kk, int m) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < NRD; ++r)
             if (r / 2 == m) {
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
     // the 3*MR*NR MFMAs of one slice; `between(m)` runs after the m-th (DMA pieces are slotted in there so that
     // their issue cost hides under the matrix pipe instead of forming a block in which no wave of the SIMD computes)
     constexpr int NM = 3 * MR * NR;
-    auto mfma_slice = [&](const Frag &f, auto &&between) {
+    auto mfma_slice = [&](const Frag &f, auto &&between) __attribute__((always_inline)) {
         int m = 0;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
@@ -283,87 +296,205 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
             }
     };
 
-    // ---- prologue: fill the ring, wait for the first tile, fetch its first slice.
-    // Two issue schedules for the DMA of a K tile (PB, per ring depth):
-    //   PB = false: tile kt+NS-1 is issued during phase A of tile kt (between slice 0's MFMAs) -> NS-1 tiles in flight;
-    //   PB = true : tile kt+NS is issued during phase B of tile kt, right behind the barrier that frees the stage tile kt
-    //               occupied -> NS tiles in flight, half a K tile more latency cover from the same LDS.  The shallow
-    //               rings need it (a 2-stage ring otherwise waits for every tile: profiles/stamp_conv_r01.txt).
-    constexpr bool PB = (NS <= SRCNN_PB_MAX_NS);
-    constexpr int PRE = PB ? NS : NS - 1;                     // tiles issued before the first MFMA
+    // ---- K loop.  Two forms.
+    // WIDE (256x256 workgroup tile, 8 waves of 64x128, 2-stage ring): the wave's 128 accumulators leave no room for two
+    // whole operand-fragment sets, so the B fragments (the wide side) live in ONE buffer that is refreshed in place, a pair
+    // of 32-column blocks at a time, as soon as the MFMAs that read it have issued; only the narrow A side is double-buffered.
+    // A K tile is four half-steps of 12 MFMAs (slice s, column pair p):  H0 (0,0)  H1 (0,1)  H2 (1,0)  [P]  H3 (1,1).
+    //   H0 fetches B pair 1 of slice 0 and A of slice 1; H1 B pair 0 of slice 1; H2 B pair 1 of slice 1 -- the last read of
+    //   this tile's stage; P = wait for tile kt+1's DMA + barrier (everybody is done with this stage, tile kt+1 is visible);
+    //   H3 fetches B pair 0 and A of slice 0 of tile kt+1.  The DMA of tile kt+2 into the stage just freed is issued 4 pieces
+    //   behind the reads of H3 and 4 behind those of the next H0, so it has H1 + H2 of every wave to land.
+    // One barrier per 48 MFMAs of a wave; 12 fragment reads per 24 MFMAs (16 with the 64x64 per-wave tile of 256x128).
+    constexpr bool WIDE = (MR == 2 && NR == 4 && WM == 4 && NS == 2);
+    unsigned long long w_vm = 0, w_bar = 0;                       // debug: time in the steady-state vmcnt waits / barriers
     const int nk = kt_end - kt_begin;
     if (p.stamp) st1 = __builtin_readcyclecounter();
-    {
-        const int pre = min(PRE, nk);
-        for (int i = 0; i < pre; ++i) {
+    if constexpr (WIDE) {
+        static_assert(!WIDE || LPT == 8, "DMA pieces per K tile");
+        half8 fa_h[2][MR], fa_l[2][MR], fb_h[NR], fb_l[NR];
+        const int a_row = (wm * 32 * MR + li) * SROW + r_sw, b_row = 2 * PANEL_A + (wn * 32 * NR + li) * SROW + r_sw;
+        const int k_flip = (r_sw ^ 16) - r_sw;
+        // r = 0..2*MR-1: (row block r>>1, hi / lo) of slice kk into A buffer s
+        auto rd_a = [&](int sbuf, const _Float16 *stage_base, int kk, int r) __attribute__((always_inline)) {
+            const _Float16 *sah = stage_base + a_row + (kk ? k_flip : 0) + (r >> 1) * 32 * SROW;
+            if (r & 1) fa_l[sbuf][r >> 1] = *reinterpret_cast<const half8 *>(sah + PANEL_A);
+            else fa_h[sbuf][r >> 1] = *reinterpret_cast<const half8 *>(sah);
+        };
+        // r = 0..3: (column block 2*pr + (r>>1), hi / lo) of slice kk
+        auto rd_b = [&](const _Float16 *stage_base, int kk, int pr, int r) __attribute__((always_inline)) {
+            const int j = 2 * pr + (r >> 1);
+            const _Float16 *sbh = stage_base + b_row + (kk ? k_flip : 0) + j * 32 * SROW;
+            if (r & 1) fb_l[j] = *reinterpret_cast<const half8 *>(sbh + PANEL_B);
+            else fb_h[j] = *reinterpret_cast<const half8 *>(sbh);
+        };
+        // 12 MFMAs: rows 0..1 x columns (2*pr, 2*pr+1) x the three products; four accumulators in rotation
+        auto half_step = [&](int sbuf, int pr, auto &&between) __attribute__((always_inline)) {
+            int m = 0;
 #pragma unroll
-            for (int pc = 0; pc < LPT; ++pc) dma_piece(pc, smem + i * STAGE);
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = 2 * pr + jj;
+                        const half8 &a = t == 0 ? fa_l[sbuf][i] : fa_h[sbuf][i];
+                        const half8 &b = t == 1 ? fb_l[j] : fb_h[j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
+                        between(m++);
+                    }
+        };
+        auto pinned = [&](auto &&fn) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            fn();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // reads of a half-step: the 4 B reads behind MFMAs 0 and 1, the 4 A reads (if any) behind MFMAs 2 and 3
+        auto reads_b = [&](const _Float16 *base, int kk, int pr, int m) __attribute__((always_inline)) {
+            if (m < 2) pinned([&]() __attribute__((always_inline)) { rd_b(base, kk, pr, 2 * m); rd_b(base, kk, pr, 2 * m + 1); });
+        };
+        auto reads_a = [&](int sbuf, const _Float16 *base, int kk, int m) __attribute__((always_inline)) {
+            if (m == 2 || m == 3) pinned([&]() __attribute__((always_inline)) { rd_a(sbuf, base, kk, 2 * (m - 2)); rd_a(sbuf, base, kk, 2 * (m - 2) + 1); });
+        };
+        // DMA pieces first..first+3 of the tile at the cursors, behind MFMAs 5, 7, 9, 11
+        auto dma4 = [&](int first, _Float16 *lbase, int m) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (m == 5 + 2 * q) pinned([&]() __attribute__((always_inline)) { dma_piece(first + q, lbase); });
+        };
+        // prologue: tile 0 whole, the first half of tile 1; tile 0's first fragments
+        {
+#pragma unroll
+            for (int pc = 0; pc < LPT; ++pc) dma_piece(pc, smem);
             advance();
+            if (nk > 1) {
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc) dma_piece(pc, smem + STAGE);
+                wait_vm_barrier<4>();
+            } else {
+                wait_vm_barrier<0>();
+            }
         }
-        if (PRE >= 4 && pre == 4) wait_vm_barrier<3 * LPT>();
-        else if (PRE >= 3 && pre == 3) wait_vm_barrier<2 * LPT>();
-        else if (PRE >= 2 && pre == 2) wait_vm_barrier<LPT>();
-        else wait_vm_barrier<0>();
+        if (p.stamp) st2 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd_b(smem, 0, 0, r);
+#pragma unroll
+        for (int r = 0; r < 2 * MR; ++r) rd_a(0, smem, 0, r);
+        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+        int cs = 0;
+        // D1: tile kt+1 exists (its pieces 4..7 go out in H0, its first fragments are fetched in H3); D2: tile kt+2 exists
+        auto k_tile = [&](auto d1, auto d2) __attribute__((always_inline)) {
+            constexpr bool D1 = decltype(d1)::value, D2 = decltype(d2)::value;
+            const _Float16 *cbase = smem + cs * STAGE;
+            _Float16 *obase = smem + (cs ^ 1) * STAGE;
+            half_step(0, 0, [&](int m) __attribute__((always_inline)) {
+                reads_b(cbase, 0, 1, m);
+                reads_a(1, cbase, 1, m);
+                if (D1) dma4(4, obase, m);
+            });
+            if (D1) advance();
+            half_step(0, 1, [&](int m) __attribute__((always_inline)) { reads_b(cbase, 1, 0, m); });
+            half_step(1, 0, [&](int m) __attribute__((always_inline)) { reads_b(cbase, 1, 1, m); });
+            __builtin_amdgcn_sched_barrier(0);                // H2's MFMAs stay above the barrier: the wait comes as late as it can
+            __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the compiler's own count knows the reads are in
+            wait_vm_barrier<0>();                             // tile kt+1 has landed everywhere; this stage is free
+            __builtin_amdgcn_sched_barrier(0);
+            half_step(1, 1, [&](int m) __attribute__((always_inline)) {
+                if (D1) {
+                    reads_b(obase, 0, 0, m);
+                    reads_a(0, obase, 0, m);
+                }
+                if (D2) dma4(0, smem + cs * STAGE, m);
+            });
+            cs ^= 1;
+        };
+        int kt = kt_begin;
+        for (; kt + 2 < kt_end; ++kt) k_tile(std::true_type{}, std::true_type{});
+        if (kt + 1 < kt_end) {
+            k_tile(std::true_type{}, std::false_type{});
+            ++kt;
+        }
+        k_tile(std::false_type{}, std::false_type{});
+    } else {
+        // ---- prologue: fill the ring, wait for the first tile, fetch its first slice.
+        // Two issue schedules for the DMA of a K tile (PB, per ring depth):
+        //   PB = false: tile kt+NS-1 is issued during phase A of tile kt (between slice 0's MFMAs) -> NS-1 tiles in flight;
+        //   PB = true : tile kt+NS is issued during phase B of tile kt, right behind the barrier that frees the stage tile kt
+        //               occupied -> NS tiles in flight, half a K tile more latency cover from the same LDS.  The shallow
+        //               rings need it (a 2-stage ring otherwise waits for every tile: profiles/stamp_conv_r01.txt).
+        constexpr bool PB = (NS <= SRCNN_PB_MAX_NS);
+        constexpr int PRE = PB ? NS : NS - 1;                     // tiles issued before the first MFMA
+        {
+            const int pre = min(PRE, nk);
+            for (int i = 0; i < pre; ++i) {
+    #pragma unroll
+                for (int pc = 0; pc < LPT; ++pc) dma_piece(pc, smem + i * STAGE);
+                advance();
+            }
+            if (PRE >= 4 && pre == 4) wait_vm_barrier<3 * LPT>();
+            else if (PRE >= 3 && pre == 3) wait_vm_barrier<2 * LPT>();
+            else if (PRE >= 2 && pre == 2) wait_vm_barrier<LPT>();
+            else wait_vm_barrier<0>();
+        }
+        if (p.stamp) st2 = __builtin_readcyclecounter();
+        Frag f0, f1;
+        read_frag(f0, smem, 0);
+        int cs = 0, ls = NS - 1;                                  // compute stage / load stage (PB = false) of the ring
+        // One K tile.  Entry: slice 0 of tile kt is in f0.  Phase A: run slice 0's MFMAs, fetching slice 1 behind the first
+        // of them (and, PB = false, with the DMA pieces of tile kt+NS-1 slotted between them).  Then wait until tile kt+1
+        // (only) has landed, barrier (every wave has finished reading this stage, everybody's part of tile kt+1 is visible).
+        // Phase B: run slice 1's MFMAs, fetching slice 0 of tile kt+1 behind the first of them (and, PB = true, with the DMA
+        // pieces of tile kt+NS going into the stage just freed).  LDS latency and DMA issue never stall a wave's MFMAs.
+        auto k_tile = [&](auto with_dma, int n_after, bool has_next) __attribute__((always_inline)) {
+            constexpr bool DMA = decltype(with_dma)::value;
+            const _Float16 *cbase = smem + cs * STAGE;
+            _Float16 *lbase = smem + (PB ? cs : ls) * STAGE;
+            mfma_slice(f0, [&](int m) __attribute__((always_inline)) {
+                read_slot(f1, cbase, 1, m);                      // slice 1: not needed before phase B
+                if (DMA && !PB) {
+    #pragma unroll
+                    for (int pc = 0; pc < LPT; ++pc)
+                        if (1 + pc * (NM - 1) / LPT == m) {
+                            __builtin_amdgcn_sched_barrier(0);    // pin the piece to its slot
+                            dma_piece(pc, lbase);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+            });
+            if (DMA && !PB) advance();
+            // slice 1 has landed in registers -- said with the builtin so that the compiler's own wait-count tracking knows
+            // it (it cannot see into the asm below) and puts no lgkmcnt wait between the next fetch and slice 1's MFMAs
+            __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0), vmcnt / expcnt untouched
+            // tiles issued after tile kt+1 at this point: kt+2 .. min(kt+NS-1, last) in either schedule
+            if (n_after == NS - 2 && p.stamp) wait_vm_barrier_timed<(NS - 2) * LPT>(w_vm, w_bar);
+            else if (n_after == NS - 2) wait_vm_barrier<(NS - 2) * LPT>();
+            else if (NS >= 4 && n_after == 1) wait_vm_barrier<LPT>();
+            else wait_vm_barrier<0>();
+            ls = (ls + 1 == NS) ? 0 : ls + 1;
+            cs = (cs + 1 == NS) ? 0 : cs + 1;
+            const _Float16 *nbase = smem + cs * STAGE;
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_slice(f1, [&](int m) __attribute__((always_inline)) {
+                if (has_next) read_slot(f0, nbase, 0, m);        // slice 0 of the next tile: needed at the next phase A
+                if (DMA && PB) {
+    #pragma unroll
+                    for (int pc = 0; pc < LPT; ++pc)
+                        if (1 + pc * (NM - 1) / LPT == m) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            dma_piece(pc, lbase);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+            });
+            if (DMA && PB) advance();
+        };
+        // 8-wave workgroups: the second-dispatched half loses every VALU arbitration to its older SIMD sibling; one static
+        // priority raise for that half (no per-phase flips) evens the pair out (MI355X_MICROARCH.md, two waves per SIMD)
+        if (WM == 4 && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+        int kt = kt_begin;
+        for (; kt + PRE < kt_end; ++kt) k_tile(std::true_type{}, NS - 2, true);
+        for (; kt < kt_end; ++kt) k_tile(std::false_type{}, min(NS - 2, kt_end - 2 - kt), kt + 1 < kt_end);
     }
-    if (p.stamp) st2 = __builtin_readcyclecounter();
-    Frag f0, f1;
-    unsigned long long w_vm = 0, w_bar = 0;                   // debug: time in the steady-state vmcnt waits / barriers
-    read_frag(f0, smem, 0);
-    int cs = 0, ls = NS - 1;                                  // compute stage / load stage (PB = false) of the ring
-    // One K tile.  Entry: slice 0 of tile kt is in f0.  Phase A: run slice 0's MFMAs, fetching slice 1 behind the first
-    // of them (and, PB = false, with the DMA pieces of tile kt+NS-1 slotted between them).  Then wait until tile kt+1
-    // (only) has landed, barrier (every wave has finished reading this stage, everybody's part of tile kt+1 is visible).
-    // Phase B: run slice 1's MFMAs, fetching slice 0 of tile kt+1 behind the first of them (and, PB = true, with the DMA
-    // pieces of tile kt+NS going into the stage just freed).  LDS latency and DMA issue never stall a wave's MFMAs.
-    auto k_tile = [&](auto with_dma, int n_after, bool has_next) {
-        constexpr bool DMA = decltype(with_dma)::value;
-        const _Float16 *cbase = smem + cs * STAGE;
-        _Float16 *lbase = smem + (PB ? cs : ls) * STAGE;
-        mfma_slice(f0, [&](int m) {
-            read_slot(f1, cbase, 1, m);                      // slice 1: not needed before phase B
-            if (DMA && !PB) {
-#pragma unroll
-                for (int pc = 0; pc < LPT; ++pc)
-                    if (1 + pc * (NM - 1) / LPT == m) {
-                        __builtin_amdgcn_sched_barrier(0);    // pin the piece to its slot
-                        dma_piece(pc, lbase);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            }
-        });
-        if (DMA && !PB) advance();
-        // slice 1 has landed in registers -- said with the builtin so that the compiler's own wait-count tracking knows
-        // it (it cannot see into the asm below) and puts no lgkmcnt wait between the next fetch and slice 1's MFMAs
-        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0), vmcnt / expcnt untouched
-        // tiles issued after tile kt+1 at this point: kt+2 .. min(kt+NS-1, last) in either schedule
-        if (n_after == NS - 2 && p.stamp) wait_vm_barrier_timed<(NS - 2) * LPT>(w_vm, w_bar);
-        else if (n_after == NS - 2) wait_vm_barrier<(NS - 2) * LPT>();
-        else if (NS >= 4 && n_after == 1) wait_vm_barrier<LPT>();
-        else wait_vm_barrier<0>();
-        ls = (ls + 1 == NS) ? 0 : ls + 1;
-        cs = (cs + 1 == NS) ? 0 : cs + 1;
-        const _Float16 *nbase = smem + cs * STAGE;
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_slice(f1, [&](int m) {
-            if (has_next) read_slot(f0, nbase, 0, m);        // slice 0 of the next tile: needed at the next phase A
-            if (DMA && PB) {
-#pragma unroll
-                for (int pc = 0; pc < LPT; ++pc)
-                    if (1 + pc * (NM - 1) / LPT == m) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        dma_piece(pc, lbase);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            }
-        });
-        if (DMA && PB) advance();
-    };
-    // 8-wave workgroups: the second-dispatched half loses every VALU arbitration to its older SIMD sibling; one static
-    // priority raise for that half (no per-phase flips) evens the pair out (MI355X_MICROARCH.md, two waves per SIMD)
-    if (WM == 4 && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
-    int kt = kt_begin;
-    for (; kt + PRE < kt_end; ++kt) k_tile(std::true_type{}, NS - 2, true);
-    for (; kt < kt_end; ++kt) k_tile(std::false_type{}, min(NS - 2, kt_end - 2 - kt), kt + 1 < kt_end);
     if (p.stamp) st3 = __builtin_readcyclecounter();
     if (NX > 0) {
 #pragma unroll
@@ -415,8 +546,10 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
             bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
             bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
         }
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
+        // one pass as a function of the COMPILE-TIME pass index: a run-time `ps` loop that the optimizer declines to unroll
+        // (it did, for the two-pass tiles) would index the accumulators dynamically and push all of them into scratch
+        auto one_pass = [&](auto ps_c) __attribute__((always_inline)) {
+            constexpr int ps = decltype(ps_c)::value;
             const int mp = m0 + ps * RPP;                    // first output row of this pass
             uint4 res_a[NG], res_b[NG];
 #pragma unroll
@@ -434,14 +567,15 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
                 const int rb = (wm * MR + i) * 32 - ps * RPP;     // this 32-row block inside the pass (wave-uniform)
-                if (rb < 0 || rb >= RPP) continue;
+                if (PASSES == 1 || (rb >= 0 && rb < RPP)) {
 #pragma unroll
-                for (int j = 0; j < NR; ++j)
+                    for (int j = 0; j < NR; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int r = rb + (e & 3) + 8 * (e >> 2) + 4 * lg;
-                        tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
-                    }
+                        for (int e = 0; e < 16; ++e) {
+                            const int r = rb + (e & 3) + 8 * (e >> 2) + 4 * lg;
+                            tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
+                        }
+                }
             }
             __syncthreads();
             if (p.stamp && ps == 0) st4 = __builtin_readcyclecounter();
@@ -498,7 +632,10 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
                     }
                 }
             }
-        }
+        };
+        one_pass(std::integral_constant<int, 0>{});
+        if constexpr (PASSES > 1) one_pass(std::integral_constant<int, 1>{});
+        static_assert(PASSES <= 2, "epilogue passes");
         if (p.stamp && t == 0) {
             unsigned long long *o = p.stamp + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
             o[8] = rt0;
@@ -512,6 +649,10 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         }
         return;
     }
+    // General path (the 6-channel keypoint classifier, channel counts / offsets that are not multiples of 8).  The 256x256
+    // tile is only ever planned for layers that take the fast path (conv_f16s_plan_ok): its 128 accumulators x this body
+    // would not be unrolled, and accumulators indexed by a run-time loop live in scratch.
+    if constexpr (MR * NR < 8) {
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
 #pragma unroll
@@ -548,6 +689,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
             }
         }
     }
+    }
 }
 
 template <int MR, int NR, int WM, int NS>
@@ -567,7 +709,7 @@ static void launch(const ConvArgs &a, int splits, hipStream_t st)
 }
 
 // Plan -> instantiation.  Workgroup tile (64*mr) x (64*nr); waves 4 or 8; stages = LDS ring depth.
-bool conv_f16s_plan_ok(const Plan &pl)
+bool conv_f16s_plan_ok(const Plan &pl, const ConvArgs &a)
 {
     const int t = pl.mr * 100 + pl.nr * 10 + (pl.waves == 8 ? 8 : 4);
     switch (t) {
@@ -576,7 +718,10 @@ bool conv_f16s_plan_ok(const Plan &pl)
     case 224: return pl.stages == 2;
     case 228: return pl.stages == 2 || pl.stages == 4;
     case 428: return pl.stages == 3;
-    case 444: return pl.stages == 2;          // 256x256 on 4 waves of 128x128: one wave per SIMD, 512 registers
+    case 448: {                               // 256x256 on 8 waves of 64x128 (two waves per SIMD, 256 registers each):
+        const int cq = a.mode == 1 ? (a.Cout >> 2) : a.Cout;      // vector epilogue only (see the kernel's general path)
+        return pl.stages == 2 && (cq & 7) == 0 && (a.ycs & 7) == 0 && (a.yco & 7) == 0 && (!a.res || (a.rcs & 7) == 0);
+    }
     default: return false;
     }
 }
@@ -595,7 +740,7 @@ void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st)
     case 2282: launch<1, 2, 4, 2>(a, pl.splits, st); break;   // 128x128 on 8 waves of 32x64
     case 2284: launch<1, 2, 4, 4>(a, pl.splits, st); break;
     case 4283: launch<2, 2, 4, 3>(a, pl.splits, st); break;   // 256x128 on 8 waves of 64x64
-    case 4442: launch<4, 4, 2, 2>(a, pl.splits, st); break;   // 256x256 on 4 waves of 128x128
+    case 4482: launch<2, 4, 4, 2>(a, pl.splits, st); break;   // 256x256 on 8 waves of 64x128
     default: launch<1, 1, 2, 2>(a, pl.splits, st); break;     // unreachable: plan_for() validates with conv_f16s_plan_ok
     }
 }

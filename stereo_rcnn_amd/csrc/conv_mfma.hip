@@ -287,7 +287,7 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
     req.stages = d->tile_stages > 0 ? d->tile_stages : 2;
     const bool f16s = d->precision == 1 && d->x_format == 1;
     // the fp32 and fp32-input f16x3 kernels have the four 4-wave 2-stage tiles; the SPLIT16 kernel has more
-    const bool ok = f16s ? conv_f16s_plan_ok(req)
+    const bool ok = f16s ? conv_f16s_plan_ok(req, a)
                          : (req.mr <= 2 && req.nr <= 2 && req.waves == 4 && req.stages == 2);
     if (!ok) return pl;            // unknown override: fall back to the heuristic plan (never an error)
     int s = d->splits >= 1 ? d->splits : 1;
@@ -323,7 +323,6 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
                       "SPLIT16 needs channel strides that are multiples of 8 (or the packed-stem geometry)");
     if (a.y_fmt == 1) SRCNN_REQUIRE(d->y_cstride % 8 == 0 && d->y_coffset % 8 == 0, "SPLIT16 output alignment");
     if (d->precision == 1 && a.x_fmt == 0) SRCNN_REQUIRE(a.y_fmt == 0 && a.res_fmt == 0, "f16x3 with F32 input writes F32");
-    a.zero_page = nullptr;
     a.stamp = debug_stamp_buffer();
     a.range_flag = nullptr;
     a.tag = d->layer_tag > 0 ? d->layer_tag : 0;
@@ -331,10 +330,10 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
         a.range_flag = range_flag_word();
         SRCNN_REQUIRE(a.range_flag != nullptr, "range flag allocation failed");
     }
-    if (d->precision == 1 && a.x_fmt == 1) {
-        a.zero_page = zero_page();
-        SRCNN_REQUIRE(a.zero_page != nullptr, "zero page allocation failed");
-    }
+    // the SPLIT16 engine addresses x through a buffer descriptor: 32-bit lane offsets relative to the first image of a tile
+    if (d->precision == 1 && a.x_fmt == 1)
+        SRCNN_REQUIRE((long long)d->H * d->W * d->x_cstride * 4 <= (1LL << 29), "SPLIT16 engine: one image must be <= 512 MB");
+    a.nimg = d->B;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.xcs = d->x_cstride;
     a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;

@@ -49,19 +49,6 @@ void prof_end(hipStream_t s, double flops)
     g_prof.used++;
 }
 
-// library-owned, never freed: 4 KB of zeros that padded conv taps DMA from (conv_f16s.hip)
-const void *zero_page()
-{
-    static void *page = nullptr;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!page) {
-        if (hipMalloc(&page, 4096) != hipSuccess) return nullptr;
-        (void)hipMemset(page, 0, 4096);
-    }
-    return page;
-}
-
 // ------------------------------------------------------------------ recorded launch programs
 struct ProgNode {
     enum Kind { KERNEL, MEMSET, RECORD, WAIT } kind;

@@ -137,9 +137,8 @@ _TUNE_LOG = {}       # key -> [(plan, ms)] of the last tuning run (dev tools pri
 # (tile_mr, tile_nr, waves, stages): workgroup tile (64*mr) x (64*nr), wavefronts, LDS ring depth
 _CANDIDATES = [(2, 2, 4, 2), (2, 1, 4, 2), (1, 2, 4, 2), (1, 1, 4, 2)]
 # extra variants of the SPLIT16 engine (csrc/conv_f16s.hip): 8-wave tiles and deeper DMA rings
-# ((4, 4, 4, 2) = the 256x256 tile on 4 waves / 512 registers exists and is tested, but measured 10-25 % slower than
-# (4, 2, 8, 3) on every big layer -- profiles/conv_microbench_r02_f16x3_split16.txt -- so the tuner does not try it)
-_CANDIDATES_F16S = [(4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
+# ((4, 4, 8, 2) = 256x256 on 8 waves of 64x128: 25 % fewer LDS fragment bytes per MFMA than the 64x64 per-wave tiles)
+_CANDIDATES_F16S = [(4, 4, 8, 2), (4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
 
 
 def save_plans(path):
@@ -274,31 +273,6 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _lib.workspace(need, x.device, "conv")
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")
-
-
-# f16x3 engine: conv2 + conv3 (+ residual) of a bottleneck as ONE launch (csrc/conv_block.hip).  Correct (bit-identical to the
-# two stand-alone launches) but measured SLOWER on MI355X in every layer (profiles/fused_block_r02.txt: the per-wave 32x64
-# tiles that a 64-pixel workgroup allows are LDS-bandwidth bound, and the no-LDS epilogue quadruples the cache-line requests
-# of the residual / output traffic), so it is off by default.
-FUSE_BLOCKS = False
-
-
-def conv_block(conv2, conv3, x, B, H, W, y, residual, name=None):
-    """Fused bottleneck tail (srcnn_conv_block): y = relu(conv3(relu(conv2(x))) + residual), SPLIT16 activations."""
-    assert conv2.kh == 3 and conv2.stride == 1 and conv2.pad == 1 and conv3.kh == 1 and conv3.cout == 4 * conv2.cout
-    conv2.split_f16x3()
-    conv3.split_f16x3()
-    d = _lib.BlockDesc()
-    d.x, d.residual, d.y = x.data_ptr(), residual.data_ptr(), y.data_ptr()
-    d.w2_hi, d.w2_lo, d.bias2, d.w2_inv_scale = conv2.w_hi.data_ptr(), conv2.w_lo.data_ptr(), conv2.bias.data_ptr(), conv2.inv_scale
-    d.w3_hi, d.w3_lo, d.bias3, d.w3_inv_scale = conv3.w_hi.data_ptr(), conv3.w_lo.data_ptr(), conv3.bias.data_ptr(), conv3.inv_scale
-    d.B, d.H, d.W, d.C = B, H, W, conv2.cout
-    d.layer_tag = layer_tag(name)
-    if FlopCounter.enabled:
-        FlopCounter.flops += 2.0 * B * H * W * (conv2.cout * conv2.alg_k + conv3.cout * conv3.alg_k)
-        FlopCounter.launches += 1
-        FlopCounter.bytes += 4.0 * (B * H * W * (conv2.cin + 2 * conv3.cout) + conv2.cout * conv2.alg_k + conv3.cout * conv3.alg_k)
-    _lib.check(_lib.lib().srcnn_conv_block(ctypes.byref(d), _lib.stream()), "srcnn_conv_block")
 
 
 def preprocess_size(H, W, target_short=600):

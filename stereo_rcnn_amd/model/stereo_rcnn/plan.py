@@ -149,7 +149,6 @@ class Plan(object):
         self.graphs = {}
         self.programs = {}      # precision -> (native launch program handle, buffers it keeps alive); run(use_program=True)
         self._rec = None        # program being recorded right now
-        self.fuse_channels = (64, 128, 256)     # bottleneck widths whose conv2 + conv3 run fused (engine.FUSE_BLOCKS)
         self.packed_fmt = -1    # format `packed` currently holds for the inputs of the NEXT run (-1: none, pack in trunk())
         self.fmt = 0            # activation format of the internal buffers for the current/last run
         # independent branches of the forward (FPN laterals, small RPN levels, box head vs keypoint head) are
@@ -179,17 +178,6 @@ class Plan(object):
             for bi, blk in enumerate(blocks):
                 nm = 'layer%d.%d.' % (li + 1, bi)
                 engine.conv2d(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, x_fmt=f, y_fmt=f, name=nm + 'conv1')
-                if f and engine.FUSE_BLOCKS and blk['conv2'].cout in self.fuse_channels:
-                    # conv2 + conv3 (+ residual, ReLU) in one launch: the C-channel map stays in LDS (csrc/conv_block.hip)
-                    if blk['down'] is not None:
-                        engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f, name=nm + 'downsample')
-                        res = nxt
-                    else:
-                        res = x
-                    engine.conv_block(blk['conv2'], blk['conv3'], bufs['m1'], N, h, w_, cur, res, name=nm + 'conv2+conv3')
-                    x, xh, xw = cur, h, w_
-                    cur, nxt = nxt, cur
-                    continue
                 engine.conv2d(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, x_fmt=f, y_fmt=f, name=nm + 'conv2')
                 if blk['down'] is not None:
                     engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f, name=nm + 'downsample')
