@@ -148,6 +148,12 @@ SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t wor
  * desc.precision = 0 (exact fp32 engine, F32 activations): stereo_rcnn_amd/pipeline.py does. */
 SRCNN_API int srcnn_range_flag_read(int reset);
 SRCNN_API const void *srcnn_range_flag_device_word(void);
+/* Gives the calling THREAD its own flag word (4 zero-initialised bytes of device memory owned by the caller, on the device
+ * the launches go to) for every library call it makes from now on; NULL returns to the library's process-wide word.
+ * With several forwards in flight on different streams each one binds its own word before it is enqueued, so that a
+ * forward is judged by its own range flag only.  srcnn_pack_detections copies the bound word into the record (row 0,
+ * column 1) and clears it on its stream; srcnn_range_flag_read reads (and resets) the bound word. */
+SRCNN_API int srcnn_range_flag_bind(void *device_word);
 
 /* A0 preprocessing (demo.py:103-129, blob.py:39-64): uint8 RGB (H,W,3) on the device -> BGR, PIXEL_MEANS subtracted
  * (in double, stored float32, as numpy's float32 -= float64), then cv2.resize(img, None, None, fx=scale, fy=scale,
@@ -326,6 +332,10 @@ SRCNN_API int srcnn_program_run(void *prog, srcnn_stream_t main_stream);
  * srcnn_prof_read (which synchronises those events). Used by bench.py for `roofline`. */
 SRCNN_API int srcnn_prof_enable(int on);
 SRCNN_API int srcnn_prof_read(double *conv_ms, double *conv_flops, long long *conv_launches);
+/* Per-launch form: elapsed ms of each recorded conv launch, in launch order, into ms[0..max) (same synchronisation);
+ * returns the number of launches recorded (which may exceed max) or a negative error.  Does not reset the recording --
+ * srcnn_prof_read / srcnn_prof_enable do.  Used by bench.py / tools/layer_table.py for the per-layer roofline table. */
+SRCNN_API int srcnn_prof_read_launches(float *ms, int max);
 
 #ifdef __cplusplus
 }

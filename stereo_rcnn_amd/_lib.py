@@ -54,6 +54,7 @@ _SIGNATURES = {
     "srcnn_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_size_t, c_void_p]),
     "srcnn_range_flag_read": (c_int, [c_int]),
     "srcnn_range_flag_device_word": (c_void_p, []),
+    "srcnn_range_flag_bind": (c_int, [c_void_p]),
     "srcnn_preprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_stem_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_maxpool3x3s2_ceil": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -105,6 +106,7 @@ _SIGNATURES = {
     "srcnn_program_size": (c_int, [c_void_p]),
     "srcnn_program_run": (c_int, [c_void_p, c_void_p]),
     "srcnn_prof_enable": (c_int, [c_int]),
+    "srcnn_prof_read_launches": (c_int, [ctypes.POINTER(ctypes.c_float), c_int]),
     "srcnn_prof_read": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_double),
                                 ctypes.POINTER(ctypes.c_longlong)]),
 }

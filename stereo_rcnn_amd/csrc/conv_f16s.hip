@@ -43,7 +43,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int SROW = BK;   // halves per LDS row (64 B), chunks XOR-swizzled
 
 // one buffer_load_dwordx4 ... lds: every lane moves 16 B from (descriptor base + its own 32-bit offset + a wave-uniform
-// scalar offset + IMM) to (wave-uniform LDS base) + lane*16; lanes whose offset is outside the descriptor's num_records
+// scalar offset) to (wave-uniform LDS base) + lane*16 (IMM, the instruction offset, is added to BOTH addresses: keep it 0); lanes whose offset is outside the descriptor's num_records
 // write zeros.  Device-only builtin, hence the guard for the host pass.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -194,7 +194,9 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         const int soff_a = ld_c0 * 4;
         if (pc < 2 * AG) {
             const int g = pc >> 1;
-            if (pc & 1) dma16b<16>(rx, a_voff[g], soff_a, sa_hi + PANEL_A + g * 16 * SROW);
+            // (the lo half sits 16 B behind the hi half: on the scalar offset -- the instruction's immediate offset would
+            //  move the LDS destination as well)
+            if (pc & 1) dma16b<0>(rx, a_voff[g], soff_a + 16, sa_hi + PANEL_A + g * 16 * SROW);
             else dma16b<0>(rx, a_voff[g], soff_a, sa_hi + g * 16 * SROW);
         } else {
             const int g = (pc - 2 * AG) >> 1;

@@ -222,9 +222,18 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] += rr.v[e];
             }
+            bool nan_pre = false;                    // fmaxf(NaN, 0) = 0: look before the ReLU launders an inf - inf
+            if (p.y_fmt == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) nan_pre = nan_pre || (v.v[e] != v.v[e]);
+            }
             if (p.relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+            }
+            if (p.y_fmt == 1) {                      // SPLIT16 result: same range guard as the conv kernels' epilogues
+                if (nan_pre) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
+                split16_guard(v, p.range_flag, p.tag);
             }
             act_store8(p.y, p.y_fmt, row, p.ycs, (p.yco >> 3) + g, v);
         }
@@ -237,7 +246,9 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
         for (int s = 0; s < splits; ++s) v += p.partial[(size_t)s * total + idx];
         if (p.bias) v += p.bias[col];
         if (p.res) v += act_load(p.res, p.res_fmt, (size_t)row, p.rcs, col);
+        const bool nan_pre = v != v;                                  // before the ReLU launders it
         if (p.relu) v = fmaxf(v, 0.f);
+        if (p.y_fmt == 1 && (nan_pre || !(fabsf(v) <= 65504.f))) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
         act_store(p.y, p.y_fmt, (size_t)row, p.ycs, p.yco + col, v);
     }
 }

@@ -116,8 +116,11 @@ void program_add_memset(Program *p, void *dst, int value, size_t bytes, hipStrea
     p->nodes.push_back(std::move(n));
 }
 
+static thread_local unsigned *t_bound_flag = nullptr;
+
 unsigned *range_flag_word()
 {
+    if (t_bound_flag) return t_bound_flag;          // the caller's own word (srcnn_range_flag_bind): one per forward in flight
     static unsigned *word = nullptr;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
@@ -145,12 +148,19 @@ int srcnn_range_flag_read(int reset)
     unsigned *w = srcnn::range_flag_word();
     if (!w) return SRCNN_ERR_HIP;
     unsigned v = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return SRCNN_ERR_HIP;     // non-blocking streams do not order with the copy below
     if (hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return SRCNN_ERR_HIP;
     if (reset && v) (void)hipMemset(w, 0, sizeof(v));
     return (int)v;
 }
 
 const void *srcnn_range_flag_device_word(void) { return srcnn::range_flag_word(); }
+
+int srcnn_range_flag_bind(void *device_word)
+{
+    srcnn::t_bound_flag = static_cast<unsigned *>(device_word);
+    return SRCNN_OK;
+}
 
 // ---- launch programs (include/srcnn_hip.h)
 void *srcnn_program_create(void) { return new srcnn::Program(); }
@@ -251,6 +261,17 @@ int srcnn_prof_enable(int on)
     srcnn::g_prof.used = 0;
     srcnn::g_prof.flops.clear();
     return SRCNN_OK;
+}
+
+int srcnn_prof_read_launches(float *ms, int max)
+{
+    using namespace srcnn;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (size_t i = 0; i < g_prof.used && (int)i < max; ++i) {
+        SRCNN_HIP_TRY(hipEventSynchronize(g_prof.pool[2 * i + 1]));
+        SRCNN_HIP_TRY(hipEventElapsedTime(&ms[i], g_prof.pool[2 * i], g_prof.pool[2 * i + 1]));
+    }
+    return (int)g_prof.used;
 }
 
 int srcnn_prof_read(double *conv_ms, double *conv_flops, long long *conv_launches)

@@ -5,7 +5,7 @@
 // Reference: stereo_rcnn/stereo_rcnn.py:256-271 (softmaxes, sum over H),
 // demo.py:144-218 (de-interleave, de-normalise, decode, clip, /scale),
 // rpn/bbox_transform.py:133-155 (keypoint / border decode), demo.py:231-257 (per-class NMS).
-#include "common.h"
+#include "conv_common.h"
 
 namespace srcnn {
 
@@ -200,7 +200,7 @@ __global__ void pack_detections_kernel(const float *__restrict__ scores, const f
                                        const float *__restrict__ boxes_r, const float *__restrict__ dim_orien,
                                        const float *__restrict__ kpts, const int *__restrict__ keep_idx,
                                        const int *__restrict__ num, int n, int ncls, int j, int cols,
-                                       float *__restrict__ rec, const unsigned *__restrict__ range_flag)
+                                       float *__restrict__ rec, unsigned *__restrict__ range_flag)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;     // record row, 0..n
     if (r > n) return;
@@ -210,6 +210,7 @@ __global__ void pack_detections_kernel(const float *__restrict__ scores, const f
     if (r == 0) {
         o[0] = (float)k;
         o[1] = (float)*range_flag;           // SPLIT16 range guard of the forward that produced these detections (0 = clean)
+        *range_flag = 0;                     // consumed: the flag travels in the record, the next forward starts clean
         return;
     }
     if (r - 1 >= k) return;
@@ -295,7 +296,7 @@ int srcnn_pack_detections(const float *scores, const float *boxes_left, const fl
     SRCNN_REQUIRE(rec_cols >= 20 && n > 0 && j >= 0 && j < n_cls, "bad sizes (rec_cols >= 20)");
     SRCNN_LAUNCH(pack_detections_kernel, dim3(cdiv(n + 1, 128)), dim3(128), 0, as_stream(stream), scores,
                        boxes_left, boxes_right, dim_orien, kpts, keep_idx, num_keep, n, n_cls, j, rec_cols, rec,
-                       static_cast<const unsigned *>(srcnn_range_flag_device_word()));
+                       range_flag_word());
     return check_launch("srcnn_pack_detections");
 }
 

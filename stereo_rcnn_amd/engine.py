@@ -96,6 +96,7 @@ class FlopCounter(object):
     flops = 0.0
     launches = 0
     bytes = 0.0
+    rows = None          # list: one dict per launch (name, M, N, K, flops, bytes, plan) while enabled; see layer_table.py
 
 
 # ---- SPLIT16 range guard (include/srcnn_hip.h: srcnn_range_flag_read): layers are tagged by name so that a tripped flag
@@ -141,6 +142,17 @@ _CANDIDATES = [(2, 2, 4, 2), (2, 1, 4, 2), (1, 2, 4, 2), (1, 1, 4, 2)]
 _CANDIDATES_F16S = [(4, 4, 8, 2), (4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 1, 4, 3), (1, 2, 4, 3), (1, 1, 4, 4)]
 
 
+# Largest LDS footprint (KB per workgroup) a tuned plan may have.  Isolated-launch timing always favours the deepest ring /
+# biggest tile (up to 144 KB: one workgroup per CU, nothing else fits beside it); with several pairs in flight a smaller
+# footprint lets workgroups of OTHER launches share the CU and fill the matrix pipe's idle slots (profiles/lds_cap_r03.txt).
+import os as _os
+MAX_LDS_KB = int(_os.environ.get('SRCNN_MAX_LDS_KB', '160'))
+
+
+def plan_lds_kb(mr, nr, waves, stages):
+    return stages * 128 * 64 * (mr + nr) // 1024
+
+
 def save_plans(path):
     """Write the tuned plans (shape key -> plan) as JSON: a later process on the same GPU model can skip the tuning launches."""
     import json
@@ -176,6 +188,8 @@ def _tune(d, key, device):
     if d.precision == 1 and d.x_format == 1:
         tiles = _CANDIDATES_F16S + tiles
     for mr, nr, waves, stages in tiles:
+        if plan_lds_kb(mr, nr, waves, stages) > MAX_LDS_KB:
+            continue
         if nr == 2 and d.Cout <= 64:
             continue
         if nr == 4 and (d.Cout <= 128 or M < 256 * 64):       # the 256x256 tile: only where it still fills the chip
@@ -258,7 +272,11 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
         px_in = B * OH * OW if (cw.kh == 1 and cw.kw == 1) else B * H * W
-        FlopCounter.bytes += 4.0 * (px_in * cw.cin + cw.cout * cw.alg_k + B * OH * OW * cw.cout * (2 if residual is not None else 1))
+        nbytes = 4.0 * (px_in * cw.cin + cw.cout * cw.alg_k + B * OH * OW * cw.cout * (2 if residual is not None else 1))
+        FlopCounter.bytes += nbytes
+        if FlopCounter.rows is not None:
+            FlopCounter.rows.append({'name': name or 'conv %dx%d %d->%d' % (cw.kh, cw.kw, cw.cin, cw.cout), 'M': B * OH * OW,
+                                     'N': cw.cout, 'K': cw.alg_k, 'flops': 2.0 * B * OH * OW * cw.cout * cw.alg_k, 'bytes': nbytes})
     if plan is not None:                   # explicit (tile_mr, tile_nr, waves, stages, splits): tests and tools
         _set_plan(d, plan)
     elif AUTOTUNE:
@@ -270,6 +288,8 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
             else:
                 plan = _tune(d, key, x.device)
         _set_plan(d, plan)
+    if FlopCounter.enabled and FlopCounter.rows is not None:
+        FlopCounter.rows[-1]['plan'] = (d.tile_mr, d.tile_nr, d.tile_waves, d.tile_stages, d.splits)
     need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _lib.workspace(need, x.device, "conv")
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")

@@ -146,6 +146,9 @@ class Plan(object):
         self.kpts_prob = e(R, 4 * G)
         self.left_prob = e(R, G)
         self.right_prob = e(R, G)
+        # this plan's own SPLIT16 range-flag word (srcnn_range_flag_bind): a forward in flight on another slot / stream never
+        # sets or clears it, and it lives on the plan's device
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.graphs = {}
         self.programs = {}      # precision -> (native launch program handle, buffers it keeps alive); run(use_program=True)
         self._rec = None        # program being recorded right now
@@ -225,7 +228,7 @@ class Plan(object):
         engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
         engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
                       x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
-        engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_, x_fmt=f)
+        engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_, x_fmt=f, name='rpn_head.P%d' % (l + 2))
         _lib.check(_lib.lib().srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(),
                                               self.deltas.data_ptr(), off, self.A, _lib.stream()), "srcnn_rpn_score")
 
@@ -243,7 +246,7 @@ class Plan(object):
             self._fork(s_lat)
             with torch.cuda.stream(s_lat):
                 for i, (cin, (h, w_)) in enumerate(((c4, (h4, w4)), (c3, (h3, w3)), (c2, (h2, w2)))):
-                    engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)     # lateral stays F32
+                    engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f, name='fpn.lateral%d' % (i + 1))     # lateral stays F32
                     lat_done.append(self._signal(s_lat))
         engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, x_fmt=f, y_fmt=f, name='fpn.toplayer')
         h6, w6 = self.rpn_shapes[4]
@@ -263,7 +266,7 @@ class Plan(object):
             if par:
                 self._wait(torch.cuda.current_stream(), lat_done[i])
             else:
-                engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f)
+                engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f, name='fpn.lateral%d' % (i + 1))
             engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i], top_fmt=f, y_fmt=f)   # stereo_rcnn.py:91-108
             engine.conv2d(w.smooth[i], self.summed[i], N, h, w_, out, h, w_, x_fmt=f, y_fmt=f, name='fpn.smooth%d' % (i + 1))
             if i + 1 < 3:
@@ -323,7 +326,7 @@ class Plan(object):
         self._pyramid(True, self.rois_right, P, self.sem, 512, 256)
         engine.conv2d(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, x_fmt=f, y_fmt=f, name='box.top0')   # 7x7/7 conv == GEMM (resnet.py:257)
         engine.conv2d(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, x_fmt=f, y_fmt=f, name='box.top3')
-        engine.conv2d(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, x_fmt=f)
+        engine.conv2d(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, x_fmt=f, name='box.fc')
         _lib.check(_lib.lib().srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, w.fc.cout,
                                                  self.cls_prob.data_ptr(), _lib.stream()), "srcnn_softmax_rows")
 
@@ -339,7 +342,7 @@ class Plan(object):
             x = y
         engine.conv2d(w.kpts_up, x, R, s, s, self.kp_up, s, s, x_fmt=f, y_fmt=f, name='kpts.deconv')
         G = cfg.KPTS_GRID
-        engine.conv2d(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, x_fmt=f)
+        engine.conv2d(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, x_fmt=f, name='kpts.class')
         _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, self.kpts_prob.data_ptr(),
                                               self.left_prob.data_ptr(), self.right_prob.data_ptr(), _lib.stream()),
                    "srcnn_kpts_tail")
@@ -416,6 +419,9 @@ class Plan(object):
         launch code -- same launches, same streams, same results."""
         prev = engine.PRECISION
         engine.PRECISION = precision
+        # every launch of this forward -- and the decode / pack calls the caller makes right after it on this thread -- report
+        # range violations to this plan's word (it stays bound until the next forward binds its own)
+        _lib.check(_lib.lib().srcnn_range_flag_bind(self.range_flag.data_ptr()), "srcnn_range_flag_bind")
         # the f16x3 engine keeps activations in the SPLIT16 format between convolutions so that
         # both GEMM operands are DMA'd into LDS (csrc/conv_f16s.hip); the fp32 engine uses F32
         self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32

@@ -258,10 +258,10 @@ def collect_3d(st):
     st.ctx = None
     st.event.synchronize()
     rec, state = st.rec_host.numpy(), st.state_host.numpy()
-    if rec[0, 1] > 0:           # SPLIT16 range guard tripped during this (or a concurrently running) forward
+    if rec[0, 1] > 0:           # SPLIT16 range guard of THIS pair's forward (its plan's own word, copied and cleared by the pack)
         from . import engine
-        flag, name = engine.range_flag(reset=True)
-        raise engine.Split16RangeError('SPLIT16 range exceeded in %s' % (name or engine.TAG_NAMES.get(int(rec[0, 1]), '?')))
+        raise engine.Split16RangeError('SPLIT16 range exceeded in %s'
+                                       % engine.TAG_NAMES.get(int(rec[0, 1]), 'layer tag %d' % (int(rec[0, 1]) - 1)))
     k = int(rec[0, 0])
     objs = []
     for i in range(k):
@@ -414,6 +414,8 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
     streams = _slot_streams(max(1, slots))
     inflight = collections.deque()
 
+    retry_slot = len(streams)        # a buffer set no pair in flight can own: the fp32 re-run must not touch slots 0..n-1
+
     def finish(entry):
         st, frame = entry
         try:
@@ -421,17 +423,17 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
         except engine.Split16RangeError:
             if model.precision == 'f32':
                 raise
-            torch.cuda.synchronize()                           # the SPLIT16 range guard tripped: this pair again, exact fp32 engine
+            # the SPLIT16 range guard of THIS pair tripped: the pair again on the exact fp32 engine, on the caller's stream and
+            # in its own slot -- the pairs still in flight keep their plans, 3-D stage buffers and images untouched
             prev, model.precision = model.precision, 'f32'
             try:
                 if len(frame) == 3:
-                    return detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align, 0,
-                                            solver=solver)
+                    return detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align,
+                                            retry_slot, solver=solver)
                 return detect_3d(model, frame[0], frame[1], frame[2], frame[3], frame[4], eval_thresh, class_index, dense_align,
-                                 solver=solver)
+                                 solver=solver, slot=retry_slot)
             finally:
                 model.precision = prev
-                engine.range_flag(reset=True)
 
     for k, frame in enumerate(frames):
         slot = k % len(streams)

@@ -316,3 +316,32 @@ def test_pipeline_falls_back_to_fp32_when_the_split16_range_is_exceeded(dev):
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert np.array_equal(a['box_left'], b['box_left']) and np.array_equal(a['xyz'], b['xyz'])
+
+
+@pytest.mark.parametrize("solver", ['host', 'device'])
+def test_streamed_fp32_fallback_does_not_disturb_the_pairs_in_flight(dev, solver):
+    """one out-of-range pair (image x2000) in the MIDDLE of a stream with three pairs in flight.  Its fp32 re-run
+    happens while two younger pairs are in flight on slots it must not touch: every frame's objects equal the serial ones
+    (the hot frame's equal the fp32 engine's), nothing duplicated, nothing dropped."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    frames = []
+    for k, seed in enumerate((3, 4, 5, 6, 7, 8, 9)):
+        l, r, info = fixture.make_inputs(seed, 120, 400, target_short=192)
+        if k == 3:
+            l, r = l * 2000.0, r * 2000.0
+        frames.append((l.to(dev), r.to(dev), info.to(dev), calib, (120, 400, 3), float(info[0, 2])))
+    serial = []
+    for k, f in enumerate(frames):
+        mdl.precision = 'f32' if k == 3 else 'f16x3'
+        serial.append(pipeline.detect_3d(mdl, *f[:5], solver=solver))
+    mdl.precision = 'f16x3'
+    streamed = list(pipeline.detect_3d_stream(mdl, frames, slots=3, solver=solver))
+    assert mdl.precision == 'f16x3' and len(streamed) == len(frames)
+    assert sum(len(s) for s in serial) >= 10
+    for k, (want, got) in enumerate(zip(serial, streamed)):
+        assert len(want) == len(got), (k, len(want), len(got))
+        for x, y in zip(want, got):
+            assert np.array_equal(x['box_left'], y['box_left']) and x['aligned'] == y['aligned'], k
+            assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta'], k

@@ -443,3 +443,22 @@ def test_split16_range_guard_trips_and_names_the_layer(dev):
     engine.act_convert(x * 1.0e5, 0, S)
     flag, name = engine.range_flag()
     assert flag == 9002 and 'input conversion' in name
+
+
+def test_split16_range_guard_covers_the_split_k_reduction(dev, cout=256):
+    """with an explicit split-K plan the SPLIT16 result is written by splitk_reduce_kernel, not by the conv
+    epilogue -- an out-of-range sum (and a NaN that a ReLU would launder) must trip the flag there too."""
+    from stereo_rcnn_amd import _lib, engine
+    g = torch.Generator().manual_seed(9)
+    C = 256
+    S = _lib.FMT_SPLIT16
+    cw = engine.prep_conv(torch.randn(cout, C, 1, 1, generator=g), torch.zeros(cout), 1, 0, True, None, dev)
+    x = torch.randn(1, 8, 8, C, generator=g).to(dev)
+    y = torch.empty(1, 8, 8, cout, device=dev)
+    plan = (1, 1, 4, 2, 4)                       # 4 K slices -> workspace reduction writes the result
+    engine.range_flag(reset=True)
+    engine.conv2d(cw, engine.act_convert(x * 100.0, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=S, plan=plan, name='sk.fine')
+    assert engine.range_flag(reset=True) == (0, None)
+    engine.conv2d(cw, engine.act_convert(x * 3.0e3, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=S, plan=plan, name='sk.hot')
+    flag, name = engine.range_flag(reset=True)
+    assert flag > 0 and name == 'sk.hot', (flag, name)
