@@ -113,7 +113,10 @@ typedef struct srcnn_conv_desc {
     int KH, KW, stride, pad;
     int y_cstride, y_coffset, res_cstride;
     int relu;
-    int mode;              /* 0 = conv; 1 = ConvTranspose2d(k=2,s=2): Cout = 4*Cq ordered (i,j,co) */
+    int mode;              /* 0 = conv; 1 = ConvTranspose2d(k=2,s=2): Cout = 4*Cq ordered (i,j,co); 2 = conv over a batch of
+                            * B = 2*B' images whose second half is written beside the first: image b >= B' goes to pixel
+                            * (b - B', oh, ow), channels y_coffset + Cout + co -- the stereo RPN's [left | right] concatenation
+                            * (stereo_rpn.py:77-78) in one launch (SPLIT16 f16x3 engine only, no residual) */
     /* precision 0: fp32 MFMA, `w` is float32.
      * precision 1: error-compensated 3xf16 MFMA (fp32-class result): `w` = hi halves and `w_lo` = lo
      *   halves of (weight * 2^k), both (Cout, KH, KW, Cin) _Float16; w_inv_scale = 2^-k. */

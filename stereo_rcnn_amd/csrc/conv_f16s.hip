@@ -629,8 +629,16 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
                             const int oh = rem / p.OW, ow = rem - oh * p.OW;
                             opix = ((size_t)bb * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
                         }
+                        int eye_off = 0;
+                        if (p.mode == 2) {                           // rows of the second half of the batch: same pixel, next Cout channels
+                            const int half_rows = (p.nimg >> 1) * p.OH * p.OW;
+                            if (row >= half_rows) {
+                                opix = (size_t)(row - half_rows);
+                                eye_off = p.Cout;
+                            }
+                        }
                         if (OUT_SPLIT) split16_guard(v, p.range_flag, p.tag);
-                        act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + co) >> 3, v);
+                        act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + eye_off + co) >> 3, v);
                     }
                 }
             }
@@ -672,11 +680,13 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
                     continue;
                 }
                 v += bv;
-                if (p.mode == 0) {
+                if (p.mode != 1) {
                     if (p.res) v += act_load(p.res, p.res_fmt, (size_t)row, p.rcs, col);
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (OUT_SPLIT && !(fabsf(v) <= 65504.f)) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
-                    act_store(p.y, OUT_SPLIT ? 1 : 0, (size_t)row, p.ycs, p.yco + col, v);
+                    const int half_rows = (p.nimg >> 1) * p.OH * p.OW;
+                    const bool second = p.mode == 2 && row >= half_rows;
+                    act_store(p.y, OUT_SPLIT ? 1 : 0, (size_t)(second ? row - half_rows : row), p.ycs, p.yco + col + (second ? p.Cout : 0), v);
                 } else {
                     const int cq = p.Cout >> 2;
                     const int ij = col / cq, co = col - ij * cq;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p)
     }
 }
 
-// deterministic split-K reduction + epilogue (mode 0 only)
+// deterministic split-K reduction + epilogue (modes 0 and 2)
 __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
 {
     const size_t total = (size_t)p.M * p.Cout;
@@ -235,7 +235,9 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
                 if (nan_pre) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
                 split16_guard(v, p.range_flag, p.tag);
             }
-            act_store8(p.y, p.y_fmt, row, p.ycs, (p.yco >> 3) + g, v);
+            const size_t half_rows = (size_t)(p.nimg >> 1) * p.OH * p.OW;
+            const bool second = p.mode == 2 && row >= half_rows;      // see srcnn_conv_desc.mode
+            act_store8(p.y, p.y_fmt, second ? row - half_rows : row, p.ycs, ((p.yco + (second ? p.Cout : 0)) >> 3) + g, v);
         }
         return;
     }
@@ -249,7 +251,9 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
         const bool nan_pre = v != v;                                  // before the ReLU launders it
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.y_fmt == 1 && (nan_pre || !(fabsf(v) <= 65504.f))) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
-        act_store(p.y, p.y_fmt, (size_t)row, p.ycs, p.yco + col, v);
+        const int half_rows = (p.nimg >> 1) * p.OH * p.OW;
+        const bool second = p.mode == 2 && row >= half_rows;
+        act_store(p.y, p.y_fmt, (size_t)(second ? row - half_rows : row), p.ycs, p.yco + col + (second ? p.Cout : 0), v);
     }
 }
 
@@ -274,7 +278,7 @@ static Plan make_plan(int M, int N, int nkt, int mode, int precision)
         pl.mr = 1;
         pl.nr = 1;
         long blocks = (long)cdiv(M, 64) * cdiv(N, 64);
-        if (mode == 0 && blocks < 256 && nkt >= 16) {
+        if (mode != 1 && blocks < 256 && nkt >= 16) {
             int s = (int)((target + blocks - 1) / blocks);
             s = min(s, nkt / 8);   // keep >= 8 K tiles per slice
             s = min(s, 32);
@@ -302,7 +306,7 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
                          : (req.mr <= 2 && req.nr <= 2 && req.waves == 4 && req.stages == 2);
     if (!ok) return pl;            // unknown override: fall back to the heuristic plan (never an error)
     int s = d->splits >= 1 ? d->splits : 1;
-    if (a.mode != 0) s = 1;
+    if (a.mode == 1) s = 1;
     s = min(s, a.nkt);
     req.kt_per_split = cdiv(a.nkt, s);
     req.splits = cdiv(a.nkt, req.kt_per_split);
@@ -315,7 +319,8 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     SRCNN_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, "Cin must be a positive multiple of 32");
     SRCNN_REQUIRE(d->x_cstride % 4 == 0, "x_cstride must be a multiple of 4 floats (16-B loads)");
     SRCNN_REQUIRE(d->B > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "bad output shape");
-    SRCNN_REQUIRE(d->mode == 0 || (d->mode == 1 && d->Cout % 4 == 0 && d->KH == 1 && d->KW == 1 && !d->residual),
+    SRCNN_REQUIRE(d->mode == 0 || (d->mode == 1 && d->Cout % 4 == 0 && d->KH == 1 && d->KW == 1 && !d->residual) ||
+                      (d->mode == 2 && d->B % 2 == 0 && !d->residual && d->precision == 1 && d->x_format == 1),
                   "bad mode");
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.res = d->residual; a.y = d->y; a.partial = nullptr;
     SRCNN_REQUIRE(d->precision == 0 || (d->precision == 1 && d->w_lo), "bad precision / missing w_lo");

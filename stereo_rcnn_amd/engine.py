@@ -149,6 +149,9 @@ import os as _os
 MAX_LDS_KB = int(_os.environ.get('SRCNN_MAX_LDS_KB', '160'))
 
 
+RPN_PAIR_LAUNCH = _os.environ.get('SRCNN_RPN_PAIR', '1') != '0'     # A/B switch of the one-launch stereo RPN conv (conv mode 2)
+
+
 def plan_lds_kb(mr, nr, waves, stages):
     return stages * 128 * 64 * (mr + nr) // 1024
 
@@ -198,7 +201,7 @@ def _tune(d, key, device):
             continue
         blocks = -(-M // (64 * mr)) * -(-d.Cout // (64 * nr))
         splits = [1]
-        if d.mode == 0:
+        if d.mode != 1:
             for s in (2, 3, 4, 6, 8, 12, 16):
                 if blocks * s <= 4096 and nkt // s >= 4 and blocks < 1024:
                     splits.append(s)

@@ -58,6 +58,8 @@ class Weights(object):
         self.smooth = [cb('RCNN_smooth%d' % i, 1, 1) for i in (1, 2, 3)]
         self.lateral = [cb('RCNN_latlayer%d' % i) for i in (1, 2, 3)]
         self.rpn_conv = cb('RCNN_rpn.RPN_Conv', 1, 1, True)
+        # the same weights as ONE launch over [left images | right images] that writes [left 512 | right 512] per pixel
+        self.rpn_conv_pair = engine.ConvW(self.rpn_conv.weight, self.rpn_conv.bias, 3, 3, 1, 1, True, mode=2)
         hw = torch.cat((sd['RCNN_rpn.RPN_cls_score.weight'], sd['RCNN_rpn.RPN_bbox_pred_left_right.weight']), 0)
         hb = torch.cat((sd['RCNN_rpn.RPN_cls_score.bias'], sd['RCNN_rpn.RPN_bbox_pred_left_right.bias']), 0)
         self.rpn_head = engine.prep_conv(hw, hb, 1, 0, False, None, device)
@@ -225,9 +227,13 @@ class Plan(object):
         h, w_ = self.rpn_shapes[l]
         cat, hd = self.rpn_cat[l], self.rpn_hd[l]
         off = sum(3 * a * b for a, b in self.rpn_shapes[:l])
-        engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
-        engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
-                      x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
+        if f and engine.RPN_PAIR_LAUNCH:       # SPLIT16 engine: both eyes in one launch (conv mode 2: the right half lands 512 channels further)
+            engine.conv2d(w.rpn_conv_pair, feats[l], 2 * B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f,
+                          name='rpn_conv.P%d' % (l + 2))
+        else:
+            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
+            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
+                          x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
         engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_, x_fmt=f, name='rpn_head.P%d' % (l + 2))
         _lib.check(_lib.lib().srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(),
                                               self.deltas.data_ptr(), off, self.A, _lib.stream()), "srcnn_rpn_score")

@@ -462,3 +462,29 @@ def test_split16_range_guard_covers_the_split_k_reduction(dev, cout=256):
     engine.conv2d(cw, engine.act_convert(x * 3.0e3, 0, S), 1, 8, 8, y, 8, 8, precision='f16x3', x_fmt=S, y_fmt=S, plan=plan, name='sk.hot')
     flag, name = engine.range_flag(reset=True)
     assert flag > 0 and name == 'sk.hot', (flag, name)
+
+
+@pytest.mark.parametrize("plan", [(2, 2, 4, 2, 1), (4, 2, 8, 3, 1), (4, 4, 8, 2, 1), (1, 1, 4, 4, 3), (2, 1, 4, 3, 2)])
+@pytest.mark.parametrize("B,H,W", [(1, 19, 31), (2, 10, 13)])
+def test_conv_mode2_pair_concat_equals_two_launches(dev, plan, B, H, W):
+    """Conv mode 2 (the stereo RPN's [left | right] channel concatenation, stereo_rpn.py:77-78, as ONE launch over the 2B
+    images) against the two launches it replaces, same plan: bit-identical, including split-K plans (reduction kernel path)
+    and tiles that straddle the left / right boundary of the batch."""
+    from stereo_rcnn_amd import _lib, engine
+    g = torch.Generator().manual_seed(B * 100 + H)
+    C, N = 64, 72
+    S = _lib.FMT_SPLIT16
+    w = torch.randn(N, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    b = torch.randn(N, generator=g)
+    cw = engine.prep_conv(w, b, 1, 1, True, None, dev)
+    cw2 = engine.ConvW(cw.weight, cw.bias, 3, 3, 1, 1, True, mode=2)
+    x = engine.act_convert(torch.randn(2 * B, H, W, C, generator=g).to(dev), 0, S)
+    want = torch.zeros(B, H, W, 2 * N + 8, device=dev)
+    got = torch.zeros_like(want)
+    kw = dict(precision='f16x3', x_fmt=S, y_fmt=S, plan=plan, y_cstride=2 * N + 8)
+    engine.conv2d(cw, x, B, H, W, want, H, W, y_coffset=0, **kw)
+    engine.conv2d(cw, x, B, H, W, want, H, W, y_coffset=N, x_offset_elems=B * H * W * C, **kw)
+    engine.conv2d(cw2, x, 2 * B, H, W, got, H, W, y_coffset=0, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert float(engine.act_convert(got, S, 0)[..., :2 * N].abs().max()) > 0.1
