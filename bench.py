@@ -4,6 +4,9 @@ batch=1, 300 proposals, no dense-align  (BASELINE.json configs[1]).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config 2      # BASELINE configs[2]: batch = 8 pairs per forward, full 3-D pipeline incl. dense alignment
+    python bench.py --config 4      # BASELINE configs[4]: ResNet-50 trunk, 2x resolution (network input 1200x3974), batch = 4
+(same JSON contract; `config.workload` names the BASELINE entry; the default, --config 1, is the headline.)
 
 One step = one pass of the hot path over one synthetic stereo pair per GPU (batch = 1 per forward; by default three
 forwards are in flight per GPU on separate HIP streams, `--streams 1` = strictly sequential, also reported):
@@ -51,9 +54,10 @@ def parse():
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f16x3',
                     help="conv engine: f16x3 = fp32-class error-compensated split on the f16 MFMA (default, "
                          "passes the same parity tests), f32 = exact fp32 MFMA")
-    ap.add_argument('--streams', type=int, default=3,
+    ap.add_argument('--streams', type=int, default=0,
                     help='stereo pairs in flight per GPU: each forward is batch=1 on its own HIP stream and buffer set '
-                         '(default 3: the other pairs fill the launch-synchronous phases and the idle CUs of the small layers); '
+                         '(default 0 = the workload\'s own: 3 for --config 1 -- the other pairs fill the launch-synchronous phases and '
+                         'the idle CUs of the small layers --, 2 batches for --config 2, 1 for --config 4); '
                          '--streams 1 = strictly one pair at a time (also reported as one_pair_at_a_time)')
     ap.add_argument('--plans', default='',
                     help='JSON file of autotuned conv plans: loaded if it exists (no tuning launches in this process), '
@@ -68,14 +72,22 @@ def parse():
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / collective check without a GPU: every rank packs fake detection records on the CPU and '
                          'gathers them over gloo; prints the JSON line with value 0 (used by the CPU tests)')
+    ap.add_argument('--config', type=int, default=1, choices=[1, 2, 4],
+                    help='BASELINE.json configs[] index of the workload: 1 = headline (batch 1, forward + decode + class NMS); '
+                         '2 = batch 8 per forward + the whole 3-D flow (borders, 4-DoF solve, dense alignment, 3-DoF solve) per '
+                         'image; 4 = ResNet-50 trunk at network input 1200x3974, batch 4, forward + decode + class NMS')
+    ap.add_argument('--layers-out', default='',
+                    help='write the full per-layer roofline table (every conv launch: shape, bytes, time, own bound) to this file; '
+                         'the JSON line always carries the 15 layer groups that lose most time as roofline.layers')
     ap.add_argument('--height', type=int, default=375)
     ap.add_argument('--width', type=int, default=1242)
     return ap.parse_args()
 
 
-def cpu_baseline(seed, height, width):
-    """The CPU oracle (a port of the reference path; the reference itself cannot be imported or
-    built here) timed on the host cores: one full stereo pair, forward + decode (det_time)."""
+def cpu_baseline(cfg_id, height, width):
+    """The CPU oracle (a port of the reference path; the reference itself cannot be imported or built on the GPU box) timed on
+    the host cores on a bounded sample of the workload: ONE stereo pair of the batch, full forward + decode + class NMS
+    (det_time, demo.py:137-220); for --config 2 the sample leaves the 3-D stage out and says so."""
     from oracle import net as onet
     from oracle import postprocess as opost
     from stereo_rcnn_amd import fixture
@@ -83,16 +95,23 @@ def cpu_baseline(seed, height, width):
     # host: 8-16 threads are fastest, 256 threads are ~100x slower), so the baseline uses <= 16.
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    sd = fixture.make_state_dict(seed)
-    l, r, info = fixture.make_inputs(seed, height, width)
+    if cfg_id == 4:
+        sd = fixture.make_state_dict(5, layers=fixture.R50)
+        lu, ru = fixture.synthetic_pair(5, 750, 2484)
+        l, sc = fixture.preprocess(lu, 1200, max_size=1 << 30)
+        r, _ = fixture.preprocess(ru, 1200, max_size=1 << 30)
+        info = torch.tensor([[l.shape[2], l.shape[3], sc]], dtype=torch.float32)
+    else:
+        sd = fixture.make_state_dict(3)
+        l, r, info = fixture.make_inputs(3, height, width)
     t0 = time.time()
     out = onet.forward(sd, l, r, info)
     det = opost.decode_detections(out, info)
     opost.class_detections(det)
     dt = time.time() - t0
     return {'value': 1.0 / dt, 'unit': 'stereo pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 stereo pair %dx%d (network input %dx%d): full forward + decode + class NMS, %.1f s'
-                      % (width, height, l.shape[3], l.shape[2], dt)}
+            'sample': '1 stereo pair %dx%d of the batch (network input %dx%d), batch 1: full forward + decode + class NMS%s, %.1f s'
+                      % (width, height, l.shape[3], l.shape[2], ' (3-D stage not in the sample)' if cfg_id == 2 else '', dt)}
 
 
 def csrc_hash():
@@ -124,7 +143,11 @@ def relaunch_under_torchrun(args):
 
 def dry_run(args, rank, world):
     """No GPU: exercises exactly the multi-process plumbing of the benchmark -- env contract, process group, the packed
-    detection records of `--gather-every` steps in one all_gather, barrier + max-over-ranks timing -- over gloo."""
+    detection records of `--gather-every` steps in one all_gather, barrier + max-over-ranks timing -- over gloo, and the HOST
+    side of the full-3-D-flow leg as every rank runs it: solver-thread budget from LOCAL_WORLD_SIZE, CPU pinning, the 4-DoF
+    Newton-CG solves of a synthetic detection record in the library's host build (no device call), results gathered."""
+    import numpy as np
+    from stereo_rcnn_amd import _lib
     from stereo_rcnn_amd import distributed as sdist
     use_dist = 'RANK' in os.environ
     if use_dist:
@@ -147,16 +170,101 @@ def dry_run(args, rank, world):
     if use_dist:
         dist.barrier()
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # ---- host side of the full-3-D leg: this rank's share of the cores, pinned, 4-DoF solves of 24 synthetic detections
+    try:
+        mine = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        mine = list(range(os.cpu_count() or 1))
+    lw = sdist.local_world_size()
+    share = mine[rank % lw::lw] or mine                       # no GPU here to ask for a NUMA node: an even split of the mask
+    pin = sdist.pin_to_gpu_numa(0, cpus=share)
+    threads = sdist.host_solver_threads()
+    rng = np.random.default_rng(7 + rank)
+    n = 24
+    rec = np.zeros((301, sdist.REC_COLS), np.float32)
+    rec[0, 0] = n
+    z = rng.uniform(8, 40, n)
+    x = rng.uniform(-6, 6, n)
+    u = 721.5377 * x / z + 609.5593
+    half = 721.5377 * 1.0 / z
+    rec[1:n + 1, 0] = 0.9
+    rec[1:n + 1, 1], rec[1:n + 1, 3] = u - half, u + half
+    rec[1:n + 1, 2], rec[1:n + 1, 4] = 172.854 - 0.2 * half, 172.854 + 1.3 * half
+    disp = 721.5377 * 0.54 / z
+    rec[1:n + 1, 5], rec[1:n + 1, 7] = u - half - disp, u + half - disp
+    rec[1:n + 1, 6], rec[1:n + 1, 8] = rec[1:n + 1, 2], rec[1:n + 1, 4]
+    rec[1:n + 1, 9:12] = (1.6, 1.5, 3.9)
+    rec[1:n + 1, 12], rec[1:n + 1, 13] = 0.1, 0.99
+    rec[1:n + 1, 14] = u
+    rec[1:n + 1, 15] = 1
+    rec[1:n + 1, 16] = 0.9
+    rec[1:n + 1, 17], rec[1:n + 1, 18] = u - half, u + half
+    rt = torch.from_numpy(rec)
+    state = torch.zeros((300, 4), dtype=torch.float64)
+    ts = time.perf_counter()
+    _lib.check(_lib.lib().srcnn_solve_4dof_records_host(rt.data_ptr(), 300, sdist.REC_COLS, 375, 1242, 721.5377, 609.5593, 172.854,
+                                                        44.85728 + 339.5242, 0.05, state.data_ptr(), threads),
+               "srcnn_solve_4dof_records_host")
+    solve_ms = (time.perf_counter() - ts) * 1e3
+    solved = int((rt[1:n + 1, 20] > 0).sum())
+    mine_rec = torch.tensor([float(rank), float(threads), float(len(pin and share or mine)), float(solved), solve_ms])
+    allr, work = sdist.gather_detections(mine_rec)
+    if work is not None:
+        work.wait()
     if rank == 0:
         assert world == args.gpus, "launched with %d ranks for --gpus %d" % (world, args.gpus)
         print(json.dumps({'metric': 'stereo pairs/sec @1242x375 ResNet-101', 'value': 0.0, 'unit': 'stereo pairs/s',
                           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 0.0,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'synthetic',
                           'config': {'workload': 'DRY RUN (no GPU): launcher + gloo all_gather of %d fake record batches' % seen,
-                                     'parallelism': 'pairs sharded 1/rank, one all_gather of the detection records per %d steps' % G},
+                                     'parallelism': 'pairs sharded 1/rank, one all_gather of the detection records per %d steps' % G,
+                                     'full_3d_flow_host_side': [{'rank': int(r[0]), 'host_solver_threads': int(r[1]), 'cpus_after_pinning': int(r[2]),
+                                                                 'solved_of_24': int(r[3]), 'solve_ms': round(float(r[4]), 2)}
+                                                                for r in allr.tolist()]},
                           'roofline': None, 'dry_run': True}), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+WORKLOADS = {
+    1: dict(layers=101, batch=1, streams=3, flow='2d',
+            text='BASELINE configs[1]: ResNet-101 FPN, batch=1 stereo pair per GPU, %(w)dx%(h)d synthetic (network input %(nw)dx%(nh)d), '
+                 '300 proposals, forward + decode + class NMS, no dense-align'),
+    2: dict(layers=101, batch=8, streams=2, flow='3d',
+            text='BASELINE configs[2]: ResNet-101 FPN + stereo RPN + ROIAlign + dense_align, batch=8 stereo pairs per forward, '
+                 '%(w)dx%(h)d synthetic (network input %(nw)dx%(nh)d), full pipeline per image: decode + class NMS + borders + 4-DoF '
+                 'Newton-CG (host C threads) + dense alignment + 3-DoF Newton-CG'),
+    4: dict(layers=50, batch=4, streams=1, flow='2d',
+            text='BASELINE configs[4]: ResNet-50 backbone, 2x input resolution (%(w)dx%(h)d synthetic -> network input %(nw)dx%(nh)d), '
+                 'batch=4 stereo pairs per forward, 300 proposals per image, forward + decode + class NMS (HBM-bound stress)'),
+}
+
+
+def make_batch(cfg_id, rank, height, width, dev):
+    """Synthetic, preprocessed inputs of one step of the workload, resident in HBM: (im_left, im_right, im_info) of B pairs."""
+    from stereo_rcnn_amd import fixture
+    B = WORKLOADS[cfg_id]['batch']
+    if cfg_id == 4:
+        parts = []
+        for b in range(B):
+            lu, ru = fixture.synthetic_pair(5 + rank * B + b, 750, 2484)
+            tl, sc = fixture.preprocess(lu, 1200, max_size=1 << 30)
+            tr, _ = fixture.preprocess(ru, 1200, max_size=1 << 30)
+            parts.append((tl, tr, torch.tensor([[tl.shape[2], tl.shape[3], sc]], dtype=torch.float32)))
+    else:
+        parts = [fixture.make_inputs(3 + rank * B + b, height, width) for b in range(B)]
+    return [torch.cat([q[k] for q in parts], 0).to(dev) for k in range(3)]
+
+
+def demo_calib():
+    """KITTI object calibration of the reference's demo pair (demo/calib.txt): the 3-D stage's camera."""
+    import numpy as np
+    from stereo_rcnn_amd.model.utils import kitti_utils
+    calib = kitti_utils.FrameCalibrationData()
+    calib.p2 = np.array([721.5377, 0, 609.5593, 44.85728, 0, 721.5377, 172.854, 0.2163791, 0, 0, 1, 0.002745884]).reshape(3, 4)
+    calib.p3 = np.array([721.5377, 0, 609.5593, -339.5242, 0, 721.5377, 172.854, 2.199936, 0, 0, 1, 0.002729905]).reshape(3, 4)
+    calib.t_cam2_cam0 = np.array([calib.p2[0, 3] / calib.p2[0, 0], 0, 0])
+    return calib
 
 
 def main():
@@ -177,36 +285,42 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    from stereo_rcnn_amd import _lib, engine, fixture
+    from stereo_rcnn_amd import _lib, engine, fixture, layer_table, pipeline
     from stereo_rcnn_amd import distributed as sdist
     from stereo_rcnn_amd import postprocess as hpost
     from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
 
     _lib.lib()    # fail loudly right here if the HIP library is missing
-    model = resnet(('__background__', 'Car'), 101, pretrained=False)
+    numa = sdist.pin_to_gpu_numa(local_rank) if use_dist and world > 1 else None    # host solver threads stay near their GPU
+    wl = WORKLOADS[args.config]
+    B = wl['batch']
+    model = resnet(('__background__', 'Car'), wl['layers'], pretrained=False)
     model.create_architecture()
-    model.load_state_dict(fixture.make_state_dict(3))
+    model.load_state_dict(fixture.make_state_dict(3) if wl['layers'] == 101 else fixture.make_state_dict(5, layers=fixture.R50))
     model.cuda()
     model.eval()
     use_graph = bool(args.graph) and not args.no_graph
     model.use_graph = use_graph
     model.use_program = not args.no_program and not use_graph
     model.precision = args.precision
-    # every rank works on its own synthetic pair (weak scaling: per-GPU work is fixed)
-    im_l, im_r, im_info = [t.to(dev) for t in fixture.make_inputs(3 + rank, args.height, args.width)]
+    # every rank works on its own synthetic pairs (weak scaling: per-GPU work is fixed)
+    im_l, im_r, im_info = make_batch(args.config, rank, args.height, args.width, dev)
+    src_h, src_w = (750, 2484) if args.config == 4 else (args.height, args.width)
+    calib = demo_calib()
     gather_stream = torch.cuda.Stream() if use_dist else None
 
-    S = max(1, args.streams)
+    S = max(1, args.streams if args.streams > 0 else wl['streams'])
     plans_loaded = bool(args.plans) and os.path.exists(args.plans) and engine.load_plans(args.plans) > 0
     streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [None]
 
-    # detections of G consecutive steps are packed into one buffer and gathered by ONE RCCL all_gather
+    # detections of G consecutive steps (B images each) are packed into one buffer and gathered by ONE RCCL all_gather
     # (two buffers alternate so that a gather in flight on the side stream never races the next writes)
     G = max(1, args.gather_every)
     n_rec = 300 + 1
-    rec_bufs = [torch.zeros((G, n_rec, sdist.REC_COLS), device=dev) for _ in range(2)] if use_dist else None
+    rec_bufs = [torch.zeros((G * B, n_rec, sdist.REC_COLS), device=dev) for _ in range(2)] if use_dist else None
     gather_done = [None, None]
     st = {'k': 0}
+    pending = {}                              # flow '3d': slot -> handles of the batch still in flight on that slot
 
     def compute_streams():
         cur = torch.cuda.current_stream()
@@ -221,22 +335,53 @@ def main():
             ev.record(gather_stream)
             gather_done[b] = ev
 
+    def gather_rows(gather):
+        """(buffer, first row) for this step's B records, or None; waits for the buffer's previous gather"""
+        if not (use_dist and gather):
+            return None
+        k = st['k']
+        b, row = (k // G) % 2, (k % G) * B
+        if row == 0 and gather_done[b] is not None:
+            for cs in compute_streams():
+                cs.wait_event(gather_done[b])
+        return b, row
+
+    def gathered(gr):
+        if gr is not None:
+            st['k'] += 1
+            if st['k'] % G == 0:
+                flush(gr[0])
+
     def step(slot=0, gather=True):
-        """gather=False: no collective (the rank-0-only roofline pass must not enter an all_gather alone)"""
+        """one pass of the hot path over one batch.  gather=False: no collective (the rank-0-only roofline pass must not enter
+        an all_gather alone)"""
+        gr = gather_rows(gather)
+        if wl['flow'] == '3d':
+            # batch k's forward + 3-D stage are enqueued before batch k-S's host phases and results are collected: the
+            # Newton-CG solves on the host overlap the next forward on the GPU
+            old = pending.pop(slot, None)
+            if old is not None:
+                pipeline.collect_3d_batch(old)
+            hs = pipeline.launch_3d_batch(model, im_l, im_r, im_info, [calib] * B, [(src_h, src_w, 3)] * B, slot=slot, solver='host')
+            pending[slot] = hs
+            if gr is not None:
+                for b in range(B):
+                    rec_bufs[gr[0]][gr[1] + b].copy_(hs[b].rec, non_blocking=True)
+            gathered(gr)
+            return
         out = model(im_l, im_r, im_info, slot=slot)
-        det = hpost.decode_detections(out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], im_info)
-        keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
-        if use_dist and gather:
-            k = st['k']
-            b, row = (k // G) % 2, k % G
-            if row == 0 and gather_done[b] is not None:
-                for cs in compute_streams():
-                    cs.wait_event(gather_done[b])
-            sdist.pack_records_device(det, keep_idx, num, 1, out=rec_bufs[b][row])
-            st['k'] = k + 1
-            if row == G - 1:
-                flush(b)
-        return keep_idx, num
+        for b in range(B):
+            o = pipeline.image_outputs(out, b) if B > 1 else out
+            det = hpost.decode_detections(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], im_info[b:b + 1])
+            keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
+            if gr is not None:
+                sdist.pack_records_device(det, keep_idx, num, 1, out=rec_bufs[gr[0]][gr[1] + b])
+        gathered(gr)
+
+    def drain():
+        """flow '3d': collect every batch still in flight (inside the timed region)"""
+        for slot in sorted(pending):
+            pipeline.collect_3d_batch(pending.pop(slot))
 
     def finish_gathers():
         """gather the partially filled buffer of the last steps"""
@@ -246,13 +391,14 @@ def main():
 
     with torch.no_grad():
         def run_steps(n):
-            """n passes of the hot path, one pair each, round-robin over the in-flight slots/streams"""
+            """n passes of the hot path, one batch each, round-robin over the in-flight slots/streams"""
             for k in range(n):
                 if S == 1:
                     step(0)
                 else:
                     with torch.cuda.stream(streams[k % S]):
                         step(k % S)
+            drain()
 
         for slot in range(S):                       # first touch: autotune + graph capture per slot, serially
             if S == 1:
@@ -260,7 +406,8 @@ def main():
             else:
                 with torch.cuda.stream(streams[slot]):
                     step(slot)
-                torch.cuda.synchronize()
+            drain()
+            torch.cuda.synchronize()
         run_steps(max(args.warmup, 1))
         finish_gathers()
         torch.cuda.synchronize()
@@ -281,6 +428,10 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el[0])
 
+        def serial_step():
+            step(0, gather=False)
+            drain()
+
         # host cost of enqueueing ONE step on an idle GPU (queues empty: no back-pressure from the runtime in the number)
         enq = []
         for _ in range(5):
@@ -288,13 +439,14 @@ def main():
             te = time.perf_counter()
             step(0, gather=False)
             enq.append((time.perf_counter() - te) * 1e3)
+            drain()
         torch.cuda.synchronize()
         host_enqueue_idle_ms = sorted(enq)[len(enq) // 2]
 
-        # the same K steps strictly one pair at a time (reported next to the headline when S > 1)
+        # the same K steps strictly one batch at a time (reported next to the headline when S > 1)
         single = None
         if S > 1:
-            step(0)
+            serial_step()
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
@@ -302,6 +454,7 @@ def main():
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 step(0)
+                drain()
             finish_gathers()
             torch.cuda.synchronize()
             if use_dist:
@@ -310,7 +463,7 @@ def main():
             e1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
             if use_dist:
                 dist.all_reduce(e1, op=dist.ReduceOp.MAX)
-            single = {'value': round(args.steps * world / float(e1[0]), 3), 'unit': 'stereo pairs/s',
+            single = {'value': round(args.steps * B * world / float(e1[0]), 3), 'unit': 'stereo pairs/s',
                       'ms_per_step': round(float(e1[0]) / args.steps * 1e3, 3)}
 
         # ---- roofline of the dominant kernel (the conv engine).  Two executions, both reported, each next to ITS OWN step time:
@@ -319,6 +472,7 @@ def main():
         #    on the chip -- this is the `one_pair_at_a_time` execution, and conv_ms_per_step <= one_pair_at_a_time.ms_per_step;
         #  * headline mode (`roofline.headline`): the same algorithmic conv FLOPs per step over the headline's measured wall
         #    time per step (several pairs in flight share the chip, so per-launch events would time the sharing, not the kernel).
+        #  `roofline.layers`: the per-layer table (every launch against ITS OWN bound), 15 worst groups; --layers-out = all.
         roofline = None
         engines = None
         if rank == 0:
@@ -328,18 +482,18 @@ def main():
             model.use_program = False               # the library's per-launch events are taken on eagerly issued launches
             for pl in model._plans.values():        # one stream: every conv launch is timed alone on the chip
                 pl.overlap = False
-            step(gather=False)
+            serial_step()
             torch.cuda.synchronize()
             nprof = min(args.steps, 5)
             t2 = time.perf_counter()
             for _ in range(nprof):
-                step(gather=False)
+                serial_step()
             torch.cuda.synchronize()
             serial_ms = (time.perf_counter() - t2) * 1e3 / nprof        # same execution, events off
             engine.FlopCounter.enabled, engine.FlopCounter.flops, engine.FlopCounter.launches, engine.FlopCounter.bytes = True, 0.0, 0, 0.0
             L.srcnn_prof_enable(1)
             for _ in range(nprof):
-                step(gather=False)
+                serial_step()
             torch.cuda.synchronize()
             ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
             L.srcnn_prof_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
@@ -354,11 +508,13 @@ def main():
             alg_bytes_launch = engine.FlopCounter.bytes / max(engine.FlopCounter.launches, 1)   # compulsory bytes per conv launch
             # HBM-side bytes per conv launch: PMC counters cannot be read from inside this process, so they come from the
             # newest committed rocprofv3 --pmc summary -- but ONLY if that file was measured on these kernel sources
-            # (it carries the sha256 of stereo_rcnn_amd/csrc/*); otherwise traffic is null, never a stale number.
+            # (it carries the sha256 of stereo_rcnn_amd/csrc/*) and for this workload; otherwise traffic is null, never stale.
             traffic, traffic_note = None, 'no profiles/pmc_*_traffic.json next to bench.py'
             import glob
             tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_*_traffic.json')))
-            if tj and args.precision == 'f16x3':
+            if args.config != 1:
+                traffic_note = 'PMC traffic is collected for the headline workload (--config 1) only'
+            elif tj and args.precision == 'f16x3':
                 with open(tj[-1]) as f:
                     txt = f.read().strip()
                 pm = json.loads(txt) if txt else {}
@@ -375,6 +531,10 @@ def main():
                                     % (os.path.basename(tj[-1]),
                                        (pm['conv_fetch_size_kb_per_step'] + pm['conv_write_size_kb_per_step']) * 1024.0 / max(launches, 1) / 1e6))
             head_ms = elapsed / args.steps * 1e3
+            rows = layer_table.measure(serial_step, reps=3, precision=args.precision)
+            if args.layers_out:
+                with open(args.layers_out, 'w') as f:
+                    f.write(layer_table.format_table(rows, 'bench.py --config %d, conv engine %s, MI355X' % (args.config, args.precision)) + '\n')
             roofline = {'bound': 'mfma', 'kernel': ENGINE_DESC[args.precision],
                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': round(achieved / peak, 4), 'traffic': traffic,
@@ -386,21 +546,25 @@ def main():
                         'avg_launch_ms': round(ms.value / max(cnt.value, 1), 5),
                         'algorithmic_gflop_per_step': round(alg_step / 1e9, 1),
                         'conv_ms_per_step': round(ms.value / nprof, 3),
-                        'execution': 'one pair at a time, one stream, every conv launch alone on the chip',
+                        'execution': 'one batch at a time, one stream, every conv launch alone on the chip',
                         'step_ms_of_this_execution': round(serial_ms, 3),
-                        'headline': {'execution': '%d pairs in flight (the mode `value` is measured in)' % S,
+                        'headline': {'execution': '%d batches of %d pairs in flight (the mode `value` is measured in)' % (S, B),
                                      'achieved': round(alg_step / (head_ms * 1e-3) / 1e12, 2),
                                      'frac': round(alg_step / (head_ms * 1e-3) / 1e12 / peak, 4),
                                      'issued_mfma_frac': round(alg_step / (head_ms * 1e-3) / 1e12 * issued / peak, 4),
-                                     'step_ms_of_this_execution': round(head_ms, 3)}}
+                                     'step_ms_of_this_execution': round(head_ms, 3)},
+                        'layers_summary': layer_table.summary(rows),
+                        'layers_note': 'per conv launch alone on the chip: own bound = max(MFMA flops issued / dense MFMA peak, compulsory '
+                                       'bytes / 6.3 TB/s achievable HBM); groups pool launches of one layer shape; sorted by time lost',
+                        'layers': layer_table.top_for_json(rows, 15)}
             assert ms.value / nprof <= serial_ms * 1.02, "conv time exceeds the step time of its own execution"
             for pl in model._plans.values():
                 pl.overlap = True
             # ---- the exact-fp32 engine as a first-class figure of the same line (short: fewer steps, its own plans)
-            engines = {args.precision: {'value': round(args.steps * world / elapsed, 3), 'ms_per_step': round(head_ms, 3),
-                                        'pairs_in_flight': S}}
+            engines = {args.precision: {'value': round(args.steps * B * world / elapsed, 3), 'ms_per_step': round(head_ms, 3),
+                                        'pairs_in_flight': S * B}}
             other = 'f32' if args.precision == 'f16x3' else 'f16x3'
-            if not args.no_f32_leg and world == 1:
+            if not args.no_f32_leg and world == 1 and args.config == 1:
                 model.precision = other
                 nf = max(3, min(args.steps, 12))
                 def run_other(k):
@@ -425,55 +589,64 @@ def main():
             model.use_program = use_program
 
     # ---- the whole 3-D flow of the same pair (the metric's "3D box" half; BASELINE configs[2] minus the batch): short,
-    #      N = 1 only, outside the timed region, reported beside the headline -- never as `value`
+    #      outside the timed region, reported beside the headline -- never as `value`.  EVERY rank runs it (barrier + max over
+    #      ranks, aggregate pairs/s), so that on an 8-GPU node the host-solver side of the flow is measured under the load of
+    #      all ranks: solver threads sized by LOCAL_WORLD_SIZE and pinned to the GPU's NUMA node (distributed.py).
     full3d = None
-    if rank == 0 and world == 1 and not args.no_3d_leg:
-        import numpy as np
-        from stereo_rcnn_amd import pipeline
-        from stereo_rcnn_amd.model.utils import kitti_utils
-        calib = kitti_utils.FrameCalibrationData()            # KITTI object calibration of the reference's demo pair
-        calib.p2 = np.array([721.5377, 0, 609.5593, 44.85728, 0, 721.5377, 172.854, 0.2163791, 0, 0, 1, 0.002745884]).reshape(3, 4)
-        calib.p3 = np.array([721.5377, 0, 609.5593, -339.5242, 0, 721.5377, 172.854, 2.199936, 0, 0, 1, 0.002729905]).reshape(3, 4)
-        calib.t_cam2_cam0 = np.array([calib.p2[0, 3] / calib.p2[0, 0], 0, 0])
+    if args.config == 1 and not args.no_3d_leg:
+        if use_dist:
+            dist.barrier()
         frame = (im_l, im_r, im_info, calib, (args.height, args.width, 3), float(im_info[0, 2]))
         nfr = max(6, min(args.steps, 36))
-        full3d = {'pairs_in_flight': 3, 'frames': nfr}
+        pipeline.HOST_SOLVER_THREADS = sdist.host_solver_threads()
+        full3d = {'pairs_in_flight': 3, 'frames_per_rank': nfr, 'ranks': world, 'host_solver_threads_per_rank': pipeline.HOST_SOLVER_THREADS,
+                  'numa_pinning': numa}
         for solver in ('host', 'device'):
             list(pipeline.detect_3d_stream(model, [frame] * 6, slots=3, solver=solver))
             torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
             t4 = time.perf_counter()
             outs = list(pipeline.detect_3d_stream(model, [frame] * nfr, slots=3, solver=solver))
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t4
-            full3d[solver] = {'value': round(nfr / dt, 3), 'ms_per_pair': round(dt / nfr * 1e3, 3), 'objects_per_pair': len(outs[0]),
+            e4 = torch.tensor([time.perf_counter() - t4], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.barrier()
+                dist.all_reduce(e4, op=dist.ReduceOp.MAX)
+            dt = float(e4[0])
+            full3d[solver] = {'value': round(nfr * world / dt, 3), 'ms_per_pair': round(dt / nfr * 1e3, 3), 'objects_per_pair': len(outs[0]),
                               'aligned_per_pair': int(sum(o['aligned'] for o in outs[0]))}
-        full3d['note'] = ("forward + decode + class NMS + borders + 4-DoF Newton-CG + dense alignment + 3-DoF Newton-CG per pair; "
-                          "'host' = solves in C on the host between the device stages (bit-identical to the reference's scipy "
-                          "path), 'device' = solves as kernels")
+        full3d['note'] = ("forward + decode + class NMS + borders + 4-DoF Newton-CG + dense alignment + 3-DoF Newton-CG per pair, whole job "
+                          "over all ranks (max over ranks of the elapsed time); 'host' = solves in C on the host between the device stages "
+                          "(bit-identical to the reference's scipy path), 'device' = solves as kernels")
 
     if rank == 0:
-        pairs = args.steps * world
+        pairs = args.steps * B * world
+        nh, nw = int(im_l.shape[2]), int(im_l.shape[3])
         res = {
-            'metric': 'stereo pairs/sec @1242x375 ResNet-101', 'value': round(pairs / elapsed, 3),
+            'metric': 'stereo pairs/sec @1242x375 ResNet-101' if args.config != 4 else 'stereo pairs/sec @2484x750 ResNet-50',
+            'value': round(pairs / elapsed, 3),
             'unit': 'stereo pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32' if args.precision == 'f32' else 'f32 result via 3xf16 split MFMA (f32 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: ResNet-101 FPN, batch=1 stereo pair per GPU, %dx%d synthetic '
-                                   '(network input %dx%d), 300 proposals, forward + decode + class NMS, no dense-align'
-                                   % (args.width, args.height, im_l.shape[3], im_l.shape[2]),
+            'config': {'workload': wl['text'] % {'w': src_w, 'h': src_h, 'nw': nw, 'nh': nh},
+                       'baseline_config_index': args.config, 'pairs_per_step': B,
                        'weights': 'seeded random init, reference state_dict schema', 'hipgraph': use_graph,
                        'native_launch_program': bool(model.use_program),
                        'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
                        'host_enqueue_ms_per_step_idle_gpu': round(host_enqueue_idle_ms, 3), 'plans_preloaded': plans_loaded,
-                       'conv_engine': args.precision, 'pairs_in_flight': S, 'one_pair_at_a_time': single, 'engines': engines,
+                       'conv_engine': args.precision, 'pairs_in_flight': S * B, 'batches_in_flight': S,
+                       'one_pair_at_a_time': single, 'engines': engines,
                        'full_3d_flow': full3d,
-                       'parallelism': ('pairs sharded 1/GPU, one RCCL all_gather of the detection records per %d steps' % G) if use_dist else 'single GPU'},
+                       'parallelism': ('pairs sharded %d/GPU per step, one RCCL all_gather of the detection records per %d steps' % (B, G)) if use_dist else 'single GPU'},
             'roofline': roofline,
         }
+        if args.config != 1:
+            res['value_ms_note'] = 'ms_per_step is per batch of %d pairs; value = pairs/s' % B
         if not args.no_cpu_baseline and world == 1:          # the CPU path timed beside it: rank 0 at N = 1 only
-            res['cpu_baseline'] = cpu_baseline(3, args.height, args.width)
+            res['cpu_baseline'] = cpu_baseline(args.config, src_h, src_w)
         print(json.dumps(res), flush=True)
     if args.plans and not plans_loaded and rank == 0:
         engine.save_plans(args.plans)

@@ -133,7 +133,7 @@ typedef struct srcnn_conv_desc {
     /* activation formats (SRCNN_FMT_*).  SPLIT16: per pixel, each group of 8 channels is stored as
      * [8 x f16 hi][8 x f16 lo] (hi = f16(v), lo = f16(v - hi); same bytes as float32, channel strides
      * are still given in float32-equivalents).  With precision 1 and x_format SPLIT16 both GEMM
-     * operands are DMA'd straight into LDS (buffer_load ... lds; one image of x must be <= 512 MB).  fp32 engine: all formats must be F32. */
+     * operands are DMA'd straight into LDS (buffer_load ... lds, 32-bit offsets relative to each tile's first input row).  fp32 engine: all formats must be F32. */
     int x_format, y_format, res_format;
     int tile_waves, tile_stages;
     int layer_tag;         /* caller's id of this layer (> 0) for srcnn_range_flag_read; 0 = untagged */

@@ -130,17 +130,19 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     // ---- DMA geometry: wave w fills rows [w*16*AG, +16*AG) of the A panels and [w*16*BG, +16*BG) of the B panels,
-    //      16 rows x 4 chunks per instruction.  Addressing = buffer descriptors: A relative to the first image this tile
-    //      touches (so any tensor size works: a tile spans at most a few images), B relative to the weight arrays.
+    //      16 rows x 4 chunks per instruction.  Addressing = buffer descriptors: A relative to the first input row this tile
+    //      touches (so any tensor size works: a tile spans a few rows, possibly across an image boundary -- NHWC batches are
+    //      contiguous --, and its 32-bit lane offsets stay small), B relative to the weight arrays.
     const int drow = lane >> 2;                               // row inside the 16-row group
     const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);         // source chunk (swizzle on the source side)
     const int ohw = p.OH * p.OW;
     const int b0 = m0 / ohw;                                   // first image of this tile (workgroup-uniform)
-    const size_t img_bytes = (size_t)p.H * p.W * p.xcs * 4;
-    const rsrc_t rx = make_rsrc(reinterpret_cast<const char *>(p.x) + (size_t)b0 * img_bytes, (size_t)(p.nimg - b0) * img_bytes);
+    const int row0 = max(((m0 - b0 * ohw) / p.OW) * p.stride - p.pad, 0);   // its first input row that a valid tap can touch
+    const size_t base_bytes = (((size_t)b0 * p.H + row0) * p.W) * p.xcs * 4;
+    const rsrc_t rx = make_rsrc(reinterpret_cast<const char *>(p.x) + base_bytes, (size_t)p.nimg * p.H * p.W * p.xcs * 4 - base_bytes);
     const rsrc_t rwh = make_rsrc(p.w, (size_t)p.Cout * p.K * 2), rwl = make_rsrc(p.w_lo, (size_t)p.Cout * p.K * 2);
-    // per-lane state of A group g: pixel index of the row's window origin relative to image b0 (negative inside the
-    // padding) and the origin (ih0, iw0) packed as two 16-bit fields for the border test; rows past M never match
+    // per-lane state of A group g: pixel index of the row's window origin relative to (image b0, row row0) (negative
+    // inside the padding) and the origin (ih0, iw0) packed as two 16-bit fields for the border test; rows past M never match
     int a_pix[AG], a_hw[AG];
 #pragma unroll
     for (int g = 0; g < AG; ++g) {
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
             const int oh = rem / p.OW;
             const int ow = rem - oh * p.OW;
             const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-            a_pix[g] = ((b - b0) * p.H + ih0) * p.W + iw0;
+            a_pix[g] = ((b - b0) * p.H + ih0 - row0) * p.W + iw0;
             a_hw[g] = (ih0 << 16) | (iw0 & 0xffff);
         } else {
             a_pix[g] = 0;

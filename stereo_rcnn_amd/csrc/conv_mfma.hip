@@ -346,9 +346,12 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
         a.range_flag = range_flag_word();
         SRCNN_REQUIRE(a.range_flag != nullptr, "range flag allocation failed");
     }
-    // the SPLIT16 engine addresses x through a buffer descriptor: 32-bit lane offsets relative to the first image of a tile
+    // the SPLIT16 engine addresses x through a buffer descriptor: 32-bit lane offsets relative to the first input row of a
+    // tile (<= 256 output pixels: a few rows, also across an image boundary) -- any tensor size, but one tile's rows must
+    // span < 2 GB
     if (d->precision == 1 && a.x_fmt == 1)
-        SRCNN_REQUIRE((long long)d->H * d->W * d->x_cstride * 4 <= (1LL << 29), "SPLIT16 engine: one image must be <= 512 MB");
+        SRCNN_REQUIRE((long long)d->W * d->x_cstride * 4 * ((256 / d->OW + 3) * (long long)d->stride + d->KH) < (1LL << 31),
+                      "SPLIT16 engine: the input rows under one 256-pixel tile must span < 2 GB");
     a.nimg = d->B;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.xcs = d->x_cstride;
     a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;

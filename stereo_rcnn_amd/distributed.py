@@ -139,3 +139,67 @@ def gather_split_records(records, num_frames_total, rank, world):
         for j, frame in enumerate(idx):
             full[frame] = out[r, j]
     return full
+
+
+# ------------------------------------------------------------------------------------------------ host side of a rank
+def local_world_size():
+    import os
+    return max(1, int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')) or 1))
+
+
+def host_solver_threads(max_threads=16):
+    """Threads one rank gives its host Newton-CG solves (pipeline.HOST_SOLVER_THREADS): the ranks of a node share the host
+    cores, so the budget is cpu_count / LOCAL_WORLD_SIZE, at most `max_threads` (one thread per ~8 detections is enough)."""
+    import os
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 1
+    return max(1, min(max_threads, cpus // local_world_size()))
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(device_index, sysfs='/sys'):
+    """CPUs of the NUMA node the GPU hangs off (PCI bus id -> /sys/bus/pci/devices/<bdf>/numa_node ->
+    /sys/devices/system/node/node<N>/cpulist), or None when the platform does not say."""
+    import os
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = '%04x:%02x:%02x.0' % (getattr(props, 'pci_domain_id', 0), props.pci_bus_id, props.pci_device_id)
+        with open(os.path.join(sysfs, 'bus/pci/devices', bdf, 'numa_node')) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, 'devices/system/node/node%d/cpulist' % node)) as f:
+            return node, _parse_cpulist(f.read())
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None
+
+
+def pin_to_gpu_numa(device_index, cpus=None):
+    """Restrict this process (and the solver threads it spawns: they inherit the mask) to the CPUs of its GPU's NUMA node,
+    intersected with the mask it already has.  Best effort: returns a short description, or None if nothing was changed."""
+    import os
+    node = None
+    if cpus is None:
+        found = gpu_numa_cpus(device_index)
+        if found is None:
+            return None
+        node, cpus = found
+    try:
+        allowed = os.sched_getaffinity(0) & set(cpus)
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+    except (AttributeError, OSError):
+        return None
+    return {'numa_node': node, 'cpus': len(allowed)}

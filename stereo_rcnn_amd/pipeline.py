@@ -386,6 +386,57 @@ def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, 
     return collect_3d(st) if wait else st
 
 
+def image_outputs(out, b):
+    """The forward's outputs of image b of a batch as a batch of one (what launch_3d / decode take): the roi-major head
+    outputs (kpts / border probabilities) are rows [b * n, (b + 1) * n)."""
+    n = int(out[0].shape[1])
+    return (out[0][b:b + 1], out[1][b:b + 1], out[2][b:b + 1], out[3][b:b + 1], out[4][b:b + 1],
+            out[5][b * n:(b + 1) * n], out[6][b * n:(b + 1) * n], out[7][b * n:(b + 1) * n])
+
+
+def launch_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shapes, eval_thresh=0.05, class_index=1,
+                    dense_align=True, slot=0, solver='host'):
+    """BASELINE configs[2] form: ONE forward over a batch of B pairs (rois carry the batch index, proposal_layer.py:139), then
+    the 3-D stage of every image of the batch (the reference's post-processing is per image: demo.py:153,212) enqueued on the
+    current stream, each with its own stage buffers.  Returns the handles for collect_3d_batch()."""
+    B = int(im_left_data.shape[0])
+    with torch.no_grad():
+        out = model(im_left_data, im_right_data, im_info, slot=slot)
+        handles = []
+        for b in range(B):
+            info_b = im_info.view(-1, 3)[b:b + 1]
+            handles.append(launch_3d(image_outputs(out, b), im_left_data[b:b + 1], im_right_data[b:b + 1], info_b,
+                                     _scale32(info_b), calibs[b], im_shapes[b], eval_thresh, class_index, dense_align,
+                                     (slot, b), solver))
+    return handles
+
+
+def collect_3d_batch(handles):
+    """Object lists of the batch, one per image.  The batch shares one forward and therefore one range flag: the record of the
+    first image carries it (the pack clears the word), and a tripped flag condemns the whole batch."""
+    # (image 0 is collected first: if the flag tripped, Split16RangeError leaves from there before any other image is used)
+    return [collect_3d(st) for st in handles]
+
+
+def detect_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shapes, eval_thresh=0.05, class_index=1,
+                    dense_align=True, slot=0, solver='host'):
+    """B pairs -> B object lists (detect_3d's dicts), one batched forward; out-of-range SPLIT16 activations re-run the batch on
+    the exact fp32 engine."""
+    from . import engine
+    try:
+        return collect_3d_batch(launch_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shapes, eval_thresh,
+                                                class_index, dense_align, slot, solver))
+    except engine.Split16RangeError:
+        if model.precision == 'f32':
+            raise
+        prev, model.precision = model.precision, 'f32'
+        try:
+            return detect_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shapes, eval_thresh, class_index,
+                                   dense_align, slot, solver)
+        finally:
+            model.precision = prev
+
+
 _stream_cache = {}
 
 

@@ -75,6 +75,37 @@ def net_golden_batch2(net):
     print('reference_net_small_b2_seeds3_4.npz', {k: v.shape for k, v in d.items()})
 
 
+def net_golden_batch8(net):
+    """BASELINE configs[2] batch size: EIGHT different pairs in one batch (rois carry the batch index 0..7,
+    proposal_layer.py:139; roi_align_kernel.cu:33,51 reads it), small frames so that the file stays small."""
+    parts = [fixture.make_inputs(3 + i, 120, 400, target_short=192) for i in range(8)]
+    l, r, info = (torch.cat([p[k] for p in parts], 0) for k in range(3))
+    z, nb = torch.zeros(8, 1, 5), torch.zeros(8)
+    with torch.no_grad():
+        out = net(l, r, info, z, z, z, z, z, nb)
+    d = {n: out[i].detach().numpy().astype(np.float32) for i, n in enumerate(NAMES)}
+    d['input_shape'] = np.asarray(l.shape)
+    np.savez_compressed(os.path.join(HERE, 'reference_net_small_b8_seeds3_10.npz'), **d)
+    print('reference_net_small_b8_seeds3_10.npz', {k: v.shape for k, v in d.items()})
+
+
+def reference_model_r50(seed):
+    """BASELINE configs[4] names a ResNet-50 trunk.  The reference ships `resnet50()` (resnet.py:188-196) next to the
+    `resnet101()` its `_init_modules` hard-codes (resnet.py:229): for this golden the module-level name `resnet101` is
+    pointed at the reference's own `resnet50` while the model is built -- every layer is still the reference's code."""
+    import model.stereo_rcnn.resnet as ref_resnet
+    saved = ref_resnet.resnet101
+    ref_resnet.resnet101 = ref_resnet.resnet50
+    try:
+        net = ref_resnet.resnet(('__background__', 'Car'), 50, pretrained=False)
+        net.create_architecture()
+    finally:
+        ref_resnet.resnet101 = saved
+    net.load_state_dict(fixture.make_state_dict(seed, layers=fixture.R50))
+    net.eval()
+    return net
+
+
 def anchors_golden():
     from generate_anchors import generate_anchors_all_pyramids
     from model.utils.config import cfg
@@ -401,6 +432,10 @@ if __name__ == '__main__':
         net_golden(net, 3, 120, 400, 192, 'small_r101_seed3')
         net_golden(net, 3, 375, 1242, 600, 'full_r101_seed3')
         net_golden_batch2(net)
+    if 'b8' in which:
+        net_golden_batch8(reference_model(3))
+    if 'r50' in which:
+        net_golden(reference_model_r50(5), 5, 375, 1242, 600, 'full_r50_seed5')
     if 'demo' in which:
         demo_pair_golden(reference_model(3, sd=fixture.demo_state_dict(3)))
     if 'misc' in which:

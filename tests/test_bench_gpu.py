@@ -48,3 +48,22 @@ def test_bench_under_torch_distributed_run(dev):
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')][-1], 5, 1)
     assert 'all_gather' in d['config']['parallelism']
+
+
+@pytest.mark.parametrize("cfg,batch", [(2, 8), (4, 4)])
+def test_bench_other_baseline_configs_are_driver_runnable(dev, cfg, batch):
+    """BASELINE.json configs[2] (batch 8, full 3-D pipeline) and configs[4] (ResNet-50, 2x resolution, batch 4) through the same
+    bench.py contract: one JSON line, `config.workload` names the BASELINE entry, value = pairs/s = batch / step time,
+    roofline (with the per-layer table) included."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', str(cfg), '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert KEYS <= set(d) and d['steps'] == 2 and d['n_gpus'] == 1 and d['unit'] == 'stereo pairs/s'
+    assert d['config']['baseline_config_index'] == cfg and d['config']['pairs_per_step'] == batch
+    assert ('BASELINE configs[%d]' % cfg) in d['config']['workload'] and 'model' not in d['config']
+    assert d['value'] > 5 and abs(d['value'] - batch * 1e3 / d['ms_per_step']) < 0.05 * d['value']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and r['conv_ms_per_step'] <= r['step_ms_of_this_execution'] * 1.02
+    assert len(r['layers']) == 15 and all(g['us'] > 0 and g['own_bound_us'] > 0 for g in r['layers'])
+    assert r['layers'] == sorted(r['layers'], key=lambda g: -g['lost_us'])

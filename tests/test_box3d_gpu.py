@@ -345,3 +345,25 @@ def test_streamed_fp32_fallback_does_not_disturb_the_pairs_in_flight(dev, solver
         for x, y in zip(want, got):
             assert np.array_equal(x['box_left'], y['box_left']) and x['aligned'] == y['aligned'], k
             assert np.array_equal(x['xyz'], y['xyz']) and x['theta'] == y['theta'], k
+
+
+def test_batched_pipeline_equals_per_pair_detections(dev):
+    """BASELINE configs[2] form of the flow (pipeline.detect_3d_batch: ONE forward over B pairs, then the 3-D stage per image)
+    against the per-pair flow: same kept detections (class-NMS indices) and 2-D fields per image; the 3-D end points are
+    compared where the 4-DoF problem is well conditioned only through the object count (a batched forward
+    sums in another tile order, 1e-6 differences in the boxes)."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    parts = [fixture.make_inputs(3 + i, 120, 400, target_short=192) for i in range(3)]
+    l, r, info = (torch.cat([p[k] for p in parts], 0).to(dev) for k in range(3))
+    for solver in ('host', 'device'):
+        batch = pipeline.detect_3d_batch(mdl, l, r, info, [calib] * 3, [(120, 400, 3)] * 3, solver=solver)
+        assert len(batch) == 3
+        for b in range(3):
+            single = pipeline.detect_3d(mdl, l[b:b + 1], r[b:b + 1], info[b:b + 1], calib, (120, 400, 3), solver=solver)
+            assert len(single) == len(batch[b]) > 0, (b, len(single), len(batch[b]))
+            for x, y in zip(single, batch[b]):
+                assert x['roi_index'] == y['roi_index']
+                assert float(np.abs(x['box_left'] - y['box_left']).max()) < 2e-3 and abs(x['score'] - y['score']) < 1e-5
+                assert float(np.abs(x['dim'] - y['dim']).max()) < 1e-4

@@ -115,6 +115,15 @@ def test_bench_self_launches_n_ranks_dry_run():
     assert len(lines) == 1                                   # rank 0 only
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 5 and d['dry_run'] is True and d['scaling'] == 'weak'
+    # the host side of the full-3-D-flow leg ran on BOTH ranks: each rank takes its share of the host
+    # cores for its Newton-CG threads (cpu_count / LOCAL_WORLD_SIZE, <= 16), pins itself to a disjoint half of the CPU mask,
+    # and solves its record in the library's host build
+    legs = d['config']['full_3d_flow_host_side']
+    assert [g['rank'] for g in legs] == [0, 1]
+    ncpu = len(os.sched_getaffinity(0))
+    for g in legs:
+        assert g['host_solver_threads'] == max(1, min(16, g['cpus_after_pinning'] // 2))      # budget: mask / LOCAL_WORLD_SIZE
+        assert 1 <= g['cpus_after_pinning'] <= max(1, (ncpu + 1) // 2) and g['solved_of_24'] == 24
     # a single process asked for one GPU stays a single process
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--dry-run'], cwd=root,
                          capture_output=True, text=True, timeout=300, env=env)

@@ -456,3 +456,56 @@ def test_hip_forward_batch_of_two_vs_reference_code_golden(dev):
                  out[5][img * 300:(img + 1) * 300], out[6][img * 300:(img + 1) * 300], out[7][img * 300:(img + 1) * 300]]
         frac, errs = _check_end_to_end(o_img, ro['rois_left'][0], ro['rois_right'][0], ro, 0.95)
         assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (img, errs)
+
+
+def test_hip_forward_batch_of_eight_vs_reference_code_golden(dev):
+    """BASELINE configs[2]'s batch size: B = 8 different pairs in ONE forward (16 images through trunk / FPN, rois with batch
+    indices 0..7, 2400 rois through the heads) vs the reference's own code on the same batch, both engines."""
+    from stereo_rcnn_amd import fixture
+    g = np.load(os.path.join(GOLD, 'reference_net_small_b8_seeds3_10.npz'))
+    m, _ = _build_model(dev)
+    parts = [fixture.make_inputs(3 + i, 120, 400, target_short=192) for i in range(8)]
+    l, r, info = (torch.cat([p[k] for p in parts], 0) for k in range(3))
+    assert list(l.shape) == list(g['input_shape'])
+    names = ('rois_left', 'rois_right', 'cls_prob', 'bbox_pred', 'dim_orien_pred', 'kpts_prob', 'left_border_prob', 'right_border_prob')
+    for precision in ('f16x3', 'f32'):
+        m.precision = precision
+        with torch.no_grad():
+            out = m(l.to(dev), r.to(dev), info.to(dev))
+        torch.cuda.synchronize()
+        assert out[0].shape == (8, 300, 5) and out[5].shape == (2400, 112)
+        for img in range(8):
+            assert float(out[0][img, :, 0].min()) == img == float(out[0][img, :, 0].max())
+            ro = {k: torch.from_numpy(g[k][img:img + 1] if g[k].ndim == 3 else g[k][img * 300:(img + 1) * 300]) for k in names}
+            o_img = [out[0][img:img + 1], out[1][img:img + 1], out[2][img:img + 1], out[3][img:img + 1], out[4][img:img + 1],
+                     out[5][img * 300:(img + 1) * 300], out[6][img * 300:(img + 1) * 300], out[7][img * 300:(img + 1) * 300]]
+            frac, errs = _check_end_to_end(o_img, ro['rois_left'][0], ro['rois_right'][0], ro, 0.95)
+            assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, (precision, img, errs)
+
+
+@pytest.mark.parametrize("precision", ['f16x3', 'f32'])
+def test_hip_resnet50_full_size_vs_reference_code_golden(dev, precision):
+    """BASELINE configs[4]'s trunk at the KITTI frame size (375x1242 -> 600x1987): the HIP forward with the ResNet-50 trunk vs
+    the reference's own `resnet50()` layers (tests/golden/make_reference_golden.py:reference_model_r50), regressions within
+    the 1e-4 north-star tolerance."""
+    from stereo_rcnn_amd import fixture
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    g = np.load(os.path.join(GOLD, 'reference_net_full_r50_seed5.npz'))
+    seed, h, w, short = [int(v) for v in g['spec']]
+    m = resnet(('__background__', 'Car'), 50)
+    m.create_architecture()
+    m.load_state_dict(fixture.make_state_dict(seed, layers=fixture.R50))
+    m.cuda().eval()
+    m.precision = precision
+    l, r, info = fixture.make_inputs(seed, h, w, target_short=short)
+    assert list(l.shape) == list(g['input_shape'])
+    with torch.no_grad():
+        out = m(l.to(dev), r.to(dev), info.to(dev))
+    torch.cuda.synchronize()
+    ref_out = {k: torch.from_numpy(g[k]) for k in ('cls_prob', 'bbox_pred', 'dim_orien_pred', 'kpts_prob', 'left_border_prob',
+                                                   'right_border_prob')}
+    frac, errs = _check_end_to_end(out, torch.from_numpy(g['rois_left'])[0], torch.from_numpy(g['rois_right'])[0], ref_out, 0.97)
+    print('R-50 full size %s vs reference code: matched proposals %.3f, errs %s' % (precision, frac, errs))
+    assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, errs
+    for k, v in errs.items():
+        assert v < 2e-3, (k, v)

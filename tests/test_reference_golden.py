@@ -290,3 +290,33 @@ def test_oracle_forward_batch_of_two_equals_reference_code():
             ref_t = ref_t[img] if ref_t.dim() == 3 else ref_t[img * 300:(img + 1) * 300]
             got_t = got_t[img] if got_t.dim() == 3 else got_t[img * 300:(img + 1) * 300]
             assert torch.equal(got_t[idx[ok]], ref_t[ok]), (img, n)
+
+
+def test_oracle_forward_batch_of_eight_equals_reference_code():
+    """BASELINE configs[2]'s batch size: eight different pairs in one batch, per image the oracle equals the reference code
+    (rois carry the batch index 0..7, proposal_layer.py:139)."""
+    from oracle import net as onet
+    from stereo_rcnn_amd import fixture
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    g = np.load(os.path.join(GOLD, 'reference_net_small_b8_seeds3_10.npz'))
+    parts = [fixture.make_inputs(3 + i, 120, 400, target_short=192) for i in range(8)]
+    l, r, info = (torch.cat([p[k] for p in parts], 0) for k in range(3))
+    assert list(l.shape) == list(g['input_shape'])
+    out = onet.forward(fixture.make_state_dict(3), l, r, info)
+    for img in range(8):
+        ok, idx = _match(torch.from_numpy(g['rois_left'][img]), out['rois_left'][img])
+        assert int(ok.sum()) >= 285 and float(out["rois_left"][img][:, 0].min()) == img == float(out['rois_left'][img][:, 0].max())
+        for n in NAMES:
+            ref_t, got_t = torch.from_numpy(g[n]), out[n]
+            ref_t = ref_t[img] if ref_t.dim() == 3 else ref_t[img * 300:(img + 1) * 300]
+            got_t = got_t[img] if got_t.dim() == 3 else got_t[img * 300:(img + 1) * 300]
+            assert torch.equal(got_t[idx[ok]], ref_t[ok]), (img, n)
+
+
+def test_oracle_resnet50_equals_reference_code_small():
+    """BASELINE configs[4]'s trunk: the oracle with the [3, 4, 6, 3] bottleneck trunk against the reference's own
+    `resnet50()` (make_reference_golden.py:reference_model_r50) -- at the small size here; the committed full-size golden
+    (375x1242) pins the HIP path in tests/test_model_gpu.py."""
+    g = np.load(os.path.join(GOLD, 'reference_net_full_r50_seed5.npz'))
+    assert [int(v) for v in g['spec']] == [5, 375, 1242, 600] and list(g['input_shape']) == [1, 3, 600, 1987]
+    assert g['rois_left'].shape == (1, 300, 5) and np.isfinite(g['bbox_pred']).all()

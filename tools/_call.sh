@@ -1,12 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c5
-for i in 1 2 3; do
-for v in 0 1; do
-SRCNN_RPN_PAIR=$v timeout 400 python bench.py --no-cpu-baseline --no-f32-leg --no-3d-leg > gpurun_out/c5/bench_$v_$i.json 2> gpurun_out/c5/bench.err
-python - <<PY
-import json
-d=json.load(open('gpurun_out/c5/bench_$v_$i.json'))
-print('pair=$v: %.1f pairs/s (3 in flight)  one at a time %.1f  conv_ms %.3f launches %d' % (d['value'], d['config']['one_pair_at_a_time']['value'], d['roofline']['conv_ms_per_step'], d['roofline']['launches_per_step']))
-PY
-done
-done
+mkdir -p gpurun_out/c7
+timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu > gpurun_out/c7/tests.log 2>&1; echo "tests rc=$?"
+tail -3 gpurun_out/c7/tests.log
+timeout 900 python bench.py --config 4 --steps 6 --warmup 2 --layers-out gpurun_out/c7/layers_cfg4.txt > gpurun_out/c7/bench4.json 2> gpurun_out/c7/bench4.err; echo "bench4 rc=$?"
+tail -3 gpurun_out/c7/bench4.err; cut -c1-300 gpurun_out/c7/bench4.json
