@@ -149,6 +149,7 @@ import os as _os
 MAX_LDS_KB = int(_os.environ.get('SRCNN_MAX_LDS_KB', '160'))
 
 
+ACT_SCALES = _os.environ.get('SRCNN_ACT_SCALES', '1') != '0'    # per-tensor power-of-two SPLIT16 activation scales (plan.calibrate)
 RPN_PAIR_LAUNCH = _os.environ.get('SRCNN_RPN_PAIR', '1') != '0'     # A/B switch of the one-launch stereo RPN conv (conv mode 2)
 
 
@@ -244,19 +245,31 @@ def _tune(d, key, device):
 
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
-           res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None):
+           res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None,
+           in_shift=0, out_shift=0):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
-    *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h)."""
+    *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h).
+    in_shift / out_shift (f16x3 engine): the input tensor holds its values x 2^in_shift, the output (and the residual, which
+    must carry the output's scale) is to be stored x 2^out_shift -- per-tensor power-of-two activation scales that keep
+    SPLIT16 tensors in the middle of the f16 range (model/stereo_rcnn/plan.py: calibrate).  Exact: the factor goes into the
+    epilogue's power-of-two rescale and a pre-scaled copy of the bias; ReLU commutes with it."""
     L = _lib.lib()
     d = _lib.ConvDesc()
     d.x = x.data_ptr() + 4 * x_offset_elems
     precision = PRECISION if precision is None else precision
     if precision == 'f16x3':
         cw.split_f16x3()
-        d.w, d.w_lo, d.w_inv_scale, d.precision = cw.w_hi.data_ptr(), cw.w_lo.data_ptr(), cw.inv_scale, 1
+        d.w, d.w_lo, d.w_inv_scale, d.precision = cw.w_hi.data_ptr(), cw.w_lo.data_ptr(), cw.inv_scale * 2.0 ** (out_shift - in_shift), 1
     else:
+        assert in_shift == 0 and out_shift == 0, "activation scales belong to the f16x3 engine's SPLIT16 tensors"
         d.w, d.w_lo, d.w_inv_scale, d.precision = cw.weight.data_ptr(), None, 1.0, 0
-    d.bias = cw.bias.data_ptr() if cw.bias is not None else None
+    bias = cw.bias
+    if bias is not None and out_shift:
+        cache = cw.__dict__.setdefault('_bias_shifted', {})
+        bias = cache.get(out_shift)
+        if bias is None:
+            bias = cache[out_shift] = (cw.bias * 2.0 ** out_shift).contiguous()
+    d.bias = bias.data_ptr() if bias is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
     d.y = y.data_ptr()
     d.B, d.H, d.W, d.Cin = B, H, W, cw.cin

@@ -30,6 +30,10 @@ class Weights(object):
         sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in sd.items()
               if not k.endswith('num_batches_tracked')}
         self.device = device
+        # per-tensor power-of-two activation scales of the SPLIT16 engine: group name -> k (tensor stored x 2^k); empty until
+        # Plan.calibrate() has seen one input (then fixed for the life of these weights, for every plan / slot)
+        self.shifts = {}
+        self.calibrated = False
         self.stem = engine.prep_stem(sd['RCNN_layer0.0.weight'], _bn_dict(sd, 'RCNN_layer0.1'), device)
         self.layers = []
         for li in (1, 2, 3, 4):
@@ -151,6 +155,8 @@ class Plan(object):
         # this plan's own SPLIT16 range-flag word (srcnn_range_flag_bind): a forward in flight on another slot / stream never
         # sets or clears it, and it lives on the plan's device
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._calib = None      # group -> max |value| while calibrate() runs
+        self._buf_shift = {}    # data_ptr -> shift of the tensor the buffer holds after the last run (as_f32 undoes it)
         self.graphs = {}
         self.programs = {}      # precision -> (native launch program handle, buffers it keeps alive); run(use_program=True)
         self._rec = None        # program being recorded right now
@@ -162,6 +168,54 @@ class Plan(object):
         self.overlap = True
         self.side = [torch.cuda.Stream(device=dev) for _ in range(2)]
 
+    # ------------------------------------------------------------------ activation scales (SPLIT16 engine)
+    def _k(self, group):
+        """Shift of a scale group in the CURRENT run: tensors of the group are stored x 2^k (0 in F32 mode / before calibration)."""
+        return self.w.shifts.get(group, 0) if (self.fmt and group is not None) else 0
+
+    def _conv(self, cw, x, B, H, W, y, OH, OW, in_group, out_group, **kw):
+        """engine.conv2d with the scale bookkeeping: the input tensor belongs to `in_group`, the output (and the residual) to
+        `out_group` (None = an unscaled tensor: the image, the F32 results that leave the network)."""
+        ko = self._k(out_group)
+        engine.conv2d(cw, x, B, H, W, y, OH, OW, in_shift=self._k(in_group), out_shift=ko, **kw)
+        self._buf_shift[y.data_ptr()] = ko
+        if self._calib is not None and out_group is not None:
+            ycs = kw.get('y_cstride')
+            if ycs is None:
+                self._note(out_group, y)
+            else:                          # a channel slice of a wider buffer: only what this launch wrote
+                c0 = kw.get('y_coffset', 0)
+                self._note(out_group, y.view(-1, ycs)[:, c0:c0 + cw.cout * (2 if cw.mode == 2 else 1)])
+
+    def _note(self, group, t):
+        self._calib[group] = max(self._calib.get(group, 0.0), float(t.abs().max()))
+
+    def calibrate(self):
+        """Choose the power-of-two scale of every SPLIT16 tensor group from ONE forward of the inputs now in this plan, run on
+        the exact fp32 engine: k = round(log2(2^11 / max|v|)), so that the group's largest value sits 32x below the f16
+        overflow threshold (the range guard still watches it) and its `lo` halves stay normal down to values 2^13 times
+        smaller than the largest.  Power-of-two factors are exact: they travel in the weights' epilogue rescale and the
+        bias; ReLU, max-pool, ROIAlign's averages and the nearest / bilinear up-sampling commute with them.  The residual
+        stream of a layer, and the whole feature pyramid (mixed per roi by ROIAlign), share one scale each."""
+        import math
+        w = self.w
+        saved = (self.fmt, engine.PRECISION, self.overlap)
+        self.fmt, engine.PRECISION, self.overlap = _lib.FMT_F32, 'f32', False
+        self._calib = {}
+        try:
+            self.launch_all()
+            torch.cuda.synchronize()
+        finally:
+            calib, self._calib = self._calib, None
+            self.fmt, engine.PRECISION, self.overlap = saved
+        w.shifts = {}
+        for g, mx in calib.items():
+            if mx > 0 and math.isfinite(mx):
+                w.shifts[g] = int(max(-24, min(24, round(math.log2(2048.0 / mx)))))
+        w.calibrated = True
+        w.calibration_max = calib
+        self.packed_fmt = -1
+
     # ------------------------------------------------------------------ stages
     def trunk(self):
         w, N = self.w, self.N
@@ -172,26 +226,29 @@ class Plan(object):
             engine.stem_pack(self.im_right, self.packed, self.B, out_fmt=f)
         self.packed_fmt = -1                          # consumed: the next forward packs again unless set_images() ran
         sh, sw = self.stem_hw
-        engine.conv2d(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, x_cstride=4, x_fmt=f, name='stem')
+        self._conv(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, None, 'stem', x_cstride=4, x_fmt=f, name='stem')   # F32 out
         ph, pw = self.c1_hw
         engine.maxpool3x3s2_ceil(self.stem_out, N, sh, sw, 64, self.c1, ph, pw, y_fmt=f)
-        x, xh, xw = self.c1, ph, pw
+        self._buf_shift[self.c1.data_ptr()] = self._k('stem')
+        x, xh, xw, xg = self.c1, ph, pw, 'stem'
         for li, blocks in enumerate(w.layers):
             h, w_ = self.layer_hw[li]
             bufs = self.layer_bufs[li]
             cur, nxt = bufs['a'], bufs['b']
+            lg = 'L%d' % (li + 1)                         # the residual stream of this layer: ONE scale for all its blocks
             for bi, blk in enumerate(blocks):
                 nm = 'layer%d.%d.' % (li + 1, bi)
-                engine.conv2d(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, x_fmt=f, y_fmt=f, name=nm + 'conv1')
-                engine.conv2d(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, x_fmt=f, y_fmt=f, name=nm + 'conv2')
+                g1, g2 = lg + '.%d.m1' % bi, lg + '.%d.m2' % bi
+                self._conv(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, xg, g1, x_fmt=f, y_fmt=f, name=nm + 'conv1')
+                self._conv(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, g1, g2, x_fmt=f, y_fmt=f, name=nm + 'conv2')
                 if blk['down'] is not None:
-                    engine.conv2d(blk['down'], x, N, xh, xw, nxt, h, w_, x_fmt=f, y_fmt=f, name=nm + 'downsample')
+                    self._conv(blk['down'], x, N, xh, xw, nxt, h, w_, xg, lg, x_fmt=f, y_fmt=f, name=nm + 'downsample')
                     res = nxt
                 else:
                     res = x
-                engine.conv2d(blk['conv3'], bufs['m2'], N, h, w_, cur, h, w_, residual=res, x_fmt=f, y_fmt=f,
-                              res_fmt=f, name=nm + 'conv3')
-                x, xh, xw = cur, h, w_
+                self._conv(blk['conv3'], bufs['m2'], N, h, w_, cur, h, w_, g2, lg, residual=res, x_fmt=f, y_fmt=f,
+                           res_fmt=f, name=nm + 'conv3')
+                x, xh, xw, xg = cur, h, w_, lg
                 cur, nxt = nxt, cur
             self.c[li] = x
 
@@ -228,13 +285,14 @@ class Plan(object):
         cat, hd = self.rpn_cat[l], self.rpn_hd[l]
         off = sum(3 * a * b for a, b in self.rpn_shapes[:l])
         if f and engine.RPN_PAIR_LAUNCH:       # SPLIT16 engine: both eyes in one launch (conv mode 2: the right half lands 512 channels further)
-            engine.conv2d(w.rpn_conv_pair, feats[l], 2 * B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f,
-                          name='rpn_conv.P%d' % (l + 2))
+            self._conv(w.rpn_conv_pair, feats[l], 2 * B, h, w_, cat, h, w_, 'P', 'rpn', y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f,
+                       name='rpn_conv.P%d' % (l + 2))
         else:
-            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
-            engine.conv2d(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, y_cstride=1024, y_coffset=512,
-                          x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
-        engine.conv2d(w.rpn_head, cat, B, h, w_, hd, h, w_, x_fmt=f, name='rpn_head.P%d' % (l + 2))
+            self._conv(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, 'P', 'rpn', y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f,
+                       name='rpn_conv.P%d' % (l + 2))
+            self._conv(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, 'P', 'rpn', y_cstride=1024, y_coffset=512,
+                       x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
+        self._conv(w.rpn_head, cat, B, h, w_, hd, h, w_, 'rpn', None, x_fmt=f, name='rpn_head.P%d' % (l + 2))
         _lib.check(_lib.lib().srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(),
                                               self.deltas.data_ptr(), off, self.A, _lib.stream()), "srcnn_rpn_score")
 
@@ -252,11 +310,13 @@ class Plan(object):
             self._fork(s_lat)
             with torch.cuda.stream(s_lat):
                 for i, (cin, (h, w_)) in enumerate(((c4, (h4, w4)), (c3, (h3, w3)), (c2, (h2, w2)))):
-                    engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f, name='fpn.lateral%d' % (i + 1))     # lateral stays F32
+                    self._conv(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, 'L%d' % (3 - i), 'P', x_fmt=f,
+                               name='fpn.lateral%d' % (i + 1))     # lateral stays F32 (at the pyramid's scale: it is added to `top`)
                     lat_done.append(self._signal(s_lat))
-        engine.conv2d(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, x_fmt=f, y_fmt=f, name='fpn.toplayer')
+        self._conv(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, 'L4', 'P', x_fmt=f, y_fmt=f, name='fpn.toplayer')
         h6, w6 = self.rpn_shapes[4]
         engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                              # stereo_rcnn.py:168
+        self._buf_shift[self.p6.data_ptr()] = self._k('P')
         if par:
             self._fork(s_rpn)
             with torch.cuda.stream(s_rpn):
@@ -272,9 +332,11 @@ class Plan(object):
             if par:
                 self._wait(torch.cuda.current_stream(), lat_done[i])
             else:
-                engine.conv2d(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, x_fmt=f, name='fpn.lateral%d' % (i + 1))
+                self._conv(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, 'L%d' % (3 - i), 'P', x_fmt=f, name='fpn.lateral%d' % (i + 1))
             engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i], top_fmt=f, y_fmt=f)   # stereo_rcnn.py:91-108
-            engine.conv2d(w.smooth[i], self.summed[i], N, h, w_, out, h, w_, x_fmt=f, y_fmt=f, name='fpn.smooth%d' % (i + 1))
+            if self._calib is not None:
+                self._note('P', self.summed[i])
+            self._conv(w.smooth[i], self.summed[i], N, h, w_, out, h, w_, 'P', 'P', x_fmt=f, y_fmt=f, name='fpn.smooth%d' % (i + 1))
             if i + 1 < 3:
                 tops[i + 1] = (out, h, w_)
             level = 2 - i                        # p4 -> RPN level 2, p3 -> 1, p2 -> 0
@@ -330,9 +392,9 @@ class Plan(object):
         P = cfg.POOLING_SIZE
         self._pyramid(False, self.rois_left, P, self.sem, 512, 0)        # stereo_rcnn.py:248-249
         self._pyramid(True, self.rois_right, P, self.sem, 512, 256)
-        engine.conv2d(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, x_fmt=f, y_fmt=f, name='box.top0')   # 7x7/7 conv == GEMM (resnet.py:257)
-        engine.conv2d(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, x_fmt=f, y_fmt=f, name='box.top3')
-        engine.conv2d(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, x_fmt=f, name='box.fc')
+        self._conv(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, 'P', 'h1', x_fmt=f, y_fmt=f, name='box.top0')   # 7x7/7 conv == GEMM (resnet.py:257)
+        self._conv(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, 'h1', 'h2', x_fmt=f, y_fmt=f, name='box.top3')
+        self._conv(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, 'h2', None, x_fmt=f, name='box.fc')
         _lib.check(_lib.lib().srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, w.fc.cout,
                                                  self.cls_prob.data_ptr(), _lib.stream()), "srcnn_softmax_rows")
 
@@ -342,13 +404,14 @@ class Plan(object):
         self._pyramid(False, self.rois_left, 2 * P, self.kp_in, 256, 0)   # stereo_rcnn.py:260
         x = self.kp_in
         s = 2 * P
+        g = 'P'                                         # ROIAlign averages pyramid values: the pooled map keeps the pyramid's scale
         for i, cw in enumerate(w.kpts):
             y = self.kp_a if i % 2 == 0 else self.kp_b
-            engine.conv2d(cw, x, R, s, s, y, s, s, x_fmt=f, y_fmt=f, name='kpts.%d' % (2 * i))
-            x = y
-        engine.conv2d(w.kpts_up, x, R, s, s, self.kp_up, s, s, x_fmt=f, y_fmt=f, name='kpts.deconv')
+            self._conv(cw, x, R, s, s, y, s, s, g, 'k%d' % i, x_fmt=f, y_fmt=f, name='kpts.%d' % (2 * i))
+            x, g = y, 'k%d' % i
+        self._conv(w.kpts_up, x, R, s, s, self.kp_up, s, s, g, 'kup', x_fmt=f, y_fmt=f, name='kpts.deconv')
         G = cfg.KPTS_GRID
-        engine.conv2d(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, x_fmt=f, name='kpts.class')
+        self._conv(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, 'kup', None, x_fmt=f, name='kpts.class')
         _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, self.kpts_prob.data_ptr(),
                                               self.left_prob.data_ptr(), self.right_prob.data_ptr(), _lib.stream()),
                    "srcnn_kpts_tail")
@@ -431,6 +494,8 @@ class Plan(object):
         # the f16x3 engine keeps activations in the SPLIT16 format between convolutions so that
         # both GEMM operands are DMA'd into LDS (csrc/conv_f16s.hip); the fp32 engine uses F32
         self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
+        if self.fmt and engine.ACT_SCALES and not self.w.calibrated:
+            self.calibrate()               # once per weights: the scales of every SPLIT16 tensor group, from this first input
         try:
             if use_program and not use_graph:
                 self.packed_fmt = -1                  # the recorded list always contains the stem_pack launches
@@ -455,7 +520,11 @@ class Plan(object):
 
     def as_f32(self, buf):
         """fp32 NHWC copy of an internal activation buffer (whatever format the last run used)."""
-        return engine.act_convert(buf, self.fmt, _lib.FMT_F32) if self.fmt else buf
+        if not self.fmt:
+            return buf
+        y = engine.act_convert(buf, self.fmt, _lib.FMT_F32)
+        k = self._buf_shift.get(buf.data_ptr(), 0)
+        return y * (2.0 ** -k) if k else y
 
     def outputs(self):
         """The forward's results as tensors the caller owns.  After an eager run the result buffers themselves are

@@ -363,15 +363,15 @@ def test_batched_pipeline_equals_per_pair_detections(dev):
         for b in range(3):
             single = pipeline.detect_3d(mdl, l[b:b + 1], r[b:b + 1], info[b:b + 1], calib, (120, 400, 3), solver=solver)
             # the object lists hold the detections whose (chaotic) 4-DoF solve succeeded: compare the ones both
-            # flows solved, by roi index
-            a = {o['roi_index']: o for o in single}
-            c = {o['roi_index']: o for o in batch[b]}
-            both = sorted(set(a) & set(c))
-            assert len(both) >= 0.8 * max(len(a), len(c)) > 0, (b, len(a), len(c), len(both))
-            for k in both:
-                x, y = a[k], c[k]
-                assert float(np.abs(x['box_left'] - y['box_left']).max()) < 2e-3 and abs(x['score'] - y['score']) < 1e-5
-                assert float(np.abs(x['box_right'] - y['box_right']).max()) < 2e-3
+            # flows solved, matched by their left boxes (the proposal ORDER may differ between a batched and a lone forward)
+            pairs = []
+            for x in single:
+                y = min(batch[b], key=lambda q: float(np.abs(q['box_left'] - x['box_left']).max()))
+                if float(np.abs(y['box_left'] - x['box_left']).max()) < 2e-3:
+                    pairs.append((x, y))
+            assert len(pairs) >= 0.8 * max(len(single), len(batch[b])) > 0, (b, len(single), len(batch[b]), len(pairs))
+            for x, y in pairs:
+                assert abs(x['score'] - y['score']) < 1e-5 and float(np.abs(x['box_right'] - y['box_right']).max()) < 2e-3
                 assert float(np.abs(x['dim'] - y['dim']).max()) < 1e-4
 
 

@@ -509,3 +509,60 @@ def test_hip_resnet50_full_size_vs_reference_code_golden(dev, precision):
     assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, errs
     for k, v in errs.items():
         assert v < 2e-3, (k, v)
+
+
+def _trunk_scaled_state_dict(sd, s):
+    """The same network with every trunk activation multiplied by s: stem BN gamma / beta x s, every later trunk BN mean / beta
+    x s (frozen BN is affine), and the FPN entry convs (lateral, toplayer) x 1/s so that everything from the pyramid on is
+    unchanged.  For a power of two s all of it is exact in fp32: the fp32 network's outputs do not change by a bit."""
+    out = {k: v.clone() for k, v in sd.items()}
+    for k in out:
+        if k.startswith('RCNN_layer0.1.') and (k.endswith('.weight') or k.endswith('.bias')):
+            out[k] = out[k] * s
+        elif k.startswith(('RCNN_layer1.', 'RCNN_layer2.', 'RCNN_layer3.', 'RCNN_layer4.')) and \
+                ('.bn' in k or '.downsample.1.' in k) and (k.endswith('.bias') or k.endswith('.running_mean')):
+            out[k] = out[k] * s
+        elif k.startswith(('RCNN_latlayer', 'RCNN_toplayer')) and k.endswith('.weight'):
+            out[k] = out[k] / s
+    return out
+
+
+@pytest.mark.parametrize("s", [2.0 ** -12, 2.0 ** 12, 1.0e-3, 3.0e3])
+def test_split16_activation_scales_make_the_trunk_scale_invariant(dev, s):
+    """per-tensor power-of-two activation scales (plan.calibrate).  A trunk whose activations are s times
+    the usual ones -- a trained, BN-folded checkpoint can sit anywhere -- must give the same detections: x 2^-12 used to lose
+    the `lo` halves to f16 subnormals (2e-5 per layer), x 2^12 used to overflow `hi` and fall back to the fp32 engine.
+    With calibrated scales a power-of-two s changes NOTHING (same stored bits, same outputs, range guard clear); any other s
+    stays within the end-to-end tolerance of the unscaled run."""
+    from stereo_rcnn_amd import engine, fixture
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    sd = fixture.make_state_dict(3)
+    l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
+    outs = []
+    for scale in (1.0, s):
+        m = resnet(('__background__', 'Car'), 101)
+        m.create_architecture()
+        m.load_state_dict(_trunk_scaled_state_dict(sd, scale))
+        m.cuda().eval()
+        m.precision = 'f16x3'
+        with torch.no_grad():
+            out = m(l, r, info)
+        torch.cuda.synchronize()
+        assert engine.range_flag(reset=True) == (0, None), 'the range guard tripped at trunk scale %g' % scale
+        shifts = m._weights.shifts
+        assert m._weights.calibrated and 'L3' in shifts and 'P' in shifts
+        outs.append(([t.clone() for t in out[:8]], dict(shifts)))
+    (a, sa), (b, sb) = outs
+    import math
+    if math.log2(s) == round(math.log2(s)):
+        for g in ('stem', 'L1', 'L2', 'L3', 'L4', 'L3.5.m1'):
+            assert sb[g] == sa[g] - int(round(math.log2(s))), (g, sa[g], sb[g])
+        assert sb['P'] == sa['P'] and sb['k3'] == sa['k3']
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    else:
+        idx = _match_rois(b[0][0].cpu(), a[0][0].cpu(), 5e-2)
+        ok = idx >= 0
+        assert float(ok.float().mean()) >= 0.97
+        assert float((b[3][0].cpu()[idx[ok]] - a[3][0].cpu()[ok]).abs().max()) < 1e-4       # bbox_pred
+        assert float((b[4][0].cpu()[idx[ok]] - a[4][0].cpu()[ok]).abs().max()) < 1e-4       # dim_orien_pred

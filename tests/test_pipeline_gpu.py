@@ -172,3 +172,37 @@ def test_streaming_pipeline_equals_serial(dev):
         for a, b in zip(want, got):
             assert np.array_equal(a['box_left'], b['box_left']) and a['aligned'] == b['aligned']
             assert np.array_equal(a['xyz'], b['xyz']) and a['theta'] == b['theta']
+
+
+@pytest.mark.parametrize("solver", ['host', 'device'])
+def test_three_in_flight_soak_is_bit_repeatable(dev, solver):
+    """306 frames of the SAME full-size pair through the whole flow with three pairs in flight -- every
+    3-D-stage kernel (class select / sort, pack, infer_boundary, solve4 / solve3 or the host solves, align_inputs, the dense
+    alignment kernels) runs beside the MFMA kernels of the two other pairs' forwards, the co-residency under which the
+    lane-quarter anomaly of DESIGN section 6 showed -- and every frame's objects must equal the lone run's bit for bit."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    m = resnet(('__background__', 'Car'), 101)
+    m.create_architecture()
+    m.load_state_dict(fixture.make_state_dict(3))
+    m.cuda().eval()
+    m.precision = 'f16x3'
+    m.use_program = True
+    l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 375, 1242)]
+    frame = (l, r, info, calib, (375, 1242, 3), float(info[0, 2]))
+    lone = pipeline.detect_3d(m, *frame[:5], solver=solver)
+    assert len(lone) >= 5 and any(o['aligned'] for o in lone)
+    list(pipeline.detect_3d_stream(m, [frame] * 6, slots=3, solver=solver))          # first touch of every slot
+    bad = []
+    for k, objs in enumerate(pipeline.detect_3d_stream(m, [frame] * 306, slots=3, solver=solver)):
+        same = len(objs) == len(lone)
+        if same:
+            for a, b in zip(lone, objs):
+                for key, va in a.items():
+                    vb = b[key]
+                    if not (np.array_equal(va, vb) if isinstance(va, np.ndarray) else va == vb):
+                        same = False
+        if not same:
+            bad.append(k)
+    assert not bad, '%d of 306 frames differ from the lone run (first: %s)' % (len(bad), bad[:5])
