@@ -272,7 +272,24 @@ SRCNN_API int srcnn_dense_align(const float *im_left, const float *im_right, int
  * srcnn_solve_3dof: demo.py:311-319 = box_estimator.py:387-545 for rows whose 4-DoF solve and dense alignment
  *   succeeded (align_status / best_dis (n) from srcnn_dense_align, or both NULL = no alignment): columns 25-30 and
  *   state (n,4) doubles (x, y, z = f b / disparity, theta).
- * P2 / P3 entries are host doubles as in the reference (calib.p2[0,0], [0,2], [1,2], p2[0,3] - p3[0,3]). */
+ * P2 / P3 entries are host doubles as in the reference (calib.p2[0,0], [0,2], [1,2], p2[0,3] - p3[0,3]).
+ *
+ * PARITY GRADE of the two device solvers: numerically equivalent to the reference, NOT reference-identical.  They run the
+ * reference's iteration (same Newton-CG, same line searches, same stopping rules) with ROCm ocml's cos / sin / atan2 and
+ * exact squares where the reference's scipy / numpy path goes through glibc's libm and pow(v, 2).  Those differ in the last
+ * bit, and the reference's end point is not a smooth function of its inputs (its gradient is not the gradient of its cost;
+ * the iteration stops on scipy's step tolerance, 1e-3..1e-2 short of the optimum): against the host build, on the same
+ * inputs, 72 % of the 4-DoF and 98 % of the 3-DoF end points of well-posed cases agree within 1e-4 and the rest jump like
+ * the reference itself does when its inputs move by 1e-5 (tests/test_box3d_gpu.py, tests/test_box3d_conditioning.py,
+ * DESIGN.md section 7).  Status columns are identical.  Callers that need the reference's boxes bit for bit use the record
+ * forms on host memory below (srcnn_solve_*_records_host: the default of stereo_rcnn_amd.pipeline, solver='host').
+ *
+ * "Bit-identical to the reference's scipy path" is a statement about NumPy >= 2 (NEP 50) scalar promotion, the NumPy of
+ * this image: 1050.0f / b[3] in infer_boundary and the float32-row arithmetic of the solvers' box-size tests, start
+ * disparity and kpt2alpha ratio are evaluated in float32, as numpy 2 does for python-scalar (op) float32.  Under the
+ * reference's own era (numpy 1.x value-based casting) those four expressions are float64; tie cases of depth < pixel and
+ * the Newton-CG start point then differ in last bits -- srcnn_solve_4dof_host(..., boxes_are_float32 = 0) gives that
+ * arithmetic for the solver. */
 SRCNN_API size_t srcnn_box3d_workspace_bytes(int n, int im_w);
 SRCNN_API int srcnn_infer_boundary(float *rec, int n, int rec_cols, int im_w, void *workspace, size_t workspace_bytes,
                          srcnn_stream_t stream);
