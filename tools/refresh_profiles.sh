@@ -1,23 +1,33 @@
 #!/bin/bash
 # Regenerates every measured artefact of a round on the GPU box into gpurun_out/<tag>/ (copy what is to be judged to profiles/).
 #   usage (inside gpurun): bash tools/refresh_profiles.sh r01
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=/root/repo
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python -m oracle.build > /dev/null 2>&1
 rm -f /tmp/plans_${TAG}.json
-python bench.py --plans /tmp/plans_${TAG}.json > $O/bench_${TAG}_f16x3.json 2> $O/bench_err.log
+python bench.py --plans /tmp/plans_${TAG}.json --layers-out $O/layers_${TAG}_config1.txt > $O/bench_${TAG}_f16x3.json 2> $O/bench_err.log
+# the other BASELINE configs through the same contract (configs[2]: batch 8 + the whole 3-D flow; configs[4]: ResNet-50, 2x resolution, batch 4)
+python bench.py --config 2 --steps 12 --warmup 2 --layers-out $O/layers_${TAG}_config2.txt > $O/bench_${TAG}_config2.json 2>> $O/bench_err.log
+python bench.py --config 4 --steps 8 --warmup 2 --layers-out $O/layers_${TAG}_config4.txt > $O/bench_${TAG}_config4.json 2>> $O/bench_err.log
 python bench.py --precision f32 --no-cpu-baseline --no-f32-leg --no-3d-leg > $O/bench_${TAG}_f32.json 2>> $O/bench_err.log
 python bench.py --streams 1 --no-cpu-baseline --no-f32-leg --no-3d-leg > $O/bench_${TAG}_f16x3_1inflight.json 2>> $O/bench_err.log
 python tools/demo_pipeline.py > $O/full_pipeline_${TAG}.txt 2>&1
 python tools/enqueue_probe.py > $O/host_enqueue_${TAG}.txt 2>&1
-python tools/block_bench.py > $O/block_bench_${TAG}.txt 2>&1
 python tools/time_forward.py f16x3 > $O/stage_times_${TAG}_f16x3.txt 2>&1
 SWEEP=1 python tools/conv_bench.py f16s > $O/conv_microbench_${TAG}_f16x3_split16.txt 2>&1
 python tools/conv_bench.py f32 > $O/conv_microbench_${TAG}_f32.txt 2>&1
-python tools/bench_configs.py > $O/configs_3_5_${TAG}.txt 2>&1
+python tools/gemm_ceiling.py > $O/gemm_ceiling_${TAG}.txt 2>&1
+# what the tuner's LDS cap does to the multi-stream headline (co-residency experiment)
+( for cap in 160 128 96 64; do SRCNN_MAX_LDS_KB=$cap python bench.py --no-cpu-baseline --no-f32-leg --no-3d-leg --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('tuner LDS cap $cap KB per workgroup: %.1f pairs/s with 3 pairs in flight, %.1f one at a time, conv %.3f ms/step' % (d['value'], d['config']['one_pair_at_a_time']['value'], d['roofline']['conv_ms_per_step']))"; done ) > $O/lds_cap_${TAG}.txt 2>&1
+# same-box A/B of the one-launch stereo RPN conv (conv mode 2)
+( for i in 1 2 3; do for v in 0 1; do SRCNN_RPN_PAIR=$v python bench.py --no-cpu-baseline --no-f32-leg --no-3d-leg --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('stereo RPN conv as one launch = $v: %.1f pairs/s (3 in flight), %d conv launches per step' % (d['value'], d['roofline']['launches_per_step']))"; done; done ) > $O/rpn_pair_launch_${TAG}.txt 2>&1
+# the 3-D-box metric's yardstick and the SPLIT16 range / scale tests, with their printed numbers
+python -m pytest tests/test_box3d_conditioning.py tests/test_box3d_gpu.py tests/test_demo_pair.py -q -s -k "spread or well_conditioned or full_flow" > $O/box3d_conditioning_${TAG}.txt 2>&1
+python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -q -s -k "dynamic_range or activation_scales or range_guard" > $O/split16_dynamic_range_${TAG}.txt 2>&1
+python -m pytest tests/test_pipeline_gpu.py -q -s -k soak > $O/three_in_flight_soak_${TAG}.txt 2>&1
 python tools/nms_bench.py > $O/nms_microbench_${TAG}.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 # one pair at a time and pre-tuned plans: every conv launch in this trace is a steady-state launch, alone on the chip
@@ -51,4 +61,11 @@ rm -rf $O/pmc
 cp $O/pmc_${TAG}_traffic.json $R/profiles/pmc_${TAG}_traffic.json
 cd $R
 python bench.py --plans /tmp/plans_${TAG}.json > $O/bench_${TAG}_f16x3.json 2>> $O/bench_err.log
+ls -la $O
+# PMC of the dominant kernel: the 256x256 / 8-wave tile on the RPN conv at P2 (both eyes in one launch), separate --pmc passes
+bash $R/tools/pmc_passes.sh $O/pmc_dom -- python $R/tools/one_conv.py f16s 4 4 8 2 1 rpn
+( echo "PMC of conv_f16s_kernel<2,4,true,4,2> (256x256 tile, 8 waves of 64x128, 2-stage ring, in-place B fragments) on the RPN conv at P2";
+  echo "(M = 149100, N = 512, K = 2304: 352 GFLOP algorithmic per launch), per-launch averages of 10 launches, separate rocprofv3 --pmc passes:";
+  python $R/tools/pmc_kernel_sum.py $O/pmc_dom conv_f16s ) > $O/pmc_${TAG}_dominant_kernel_256x256.txt 2>&1
+rm -rf $O/pmc_dom
 ls -la $O
