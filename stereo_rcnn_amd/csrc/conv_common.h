@@ -20,6 +20,7 @@ struct ConvArgs {
     int OH, OW, Cout;
     int KH, KW, stride, pad;
     int ycs, yco, rcs, relu, mode;
+    int tap_inner;                // SPLIT16 engine, KH*KW > 1: K runs (channel tile, tap) instead of (tap, channel tile)
     int M, K;
     int ctiles;       // Cin / 32
     int nkt;          // K tiles in total

@@ -164,14 +164,20 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
     //      the image / the row is past M; re-derived only when the tap changes (every Cin/32 K tiles).  The channel tile
     //      inside the tap and B's K position are scalar offsets: one s_add per K tile.
     int a_voff[AG], b_voff[BG];
+    // K order.  p.tap_inner = 0: (tap, channel tile) as K runs in memory -- a tap's data is touched Cin/32 K tiles apart.
+    // p.tap_inner = 1 (3x3 layers): (channel tile, tap) -- consecutive K tiles read the SAME input pixels shifted by one
+    // tap, i.e. the cache lines the workgroup fetched one K tile earlier: the L2 serves the 3 taps of a row instead of the
+    // fabric (profiles/k_order_r03.txt); the weights' K offset then jumps by Cin per K tile, on the scalar unit.
     int ld_kh, ld_kw, ld_c0, soff_b;
     {
-        const int tap = kt_begin / p.ctiles;
+        const int ntaps = p.KH * p.KW;
+        const int tap = p.tap_inner ? kt_begin % ntaps : kt_begin / p.ctiles;
+        const int ct = p.tap_inner ? kt_begin / ntaps : kt_begin - tap * p.ctiles;
         const int kh = tap / p.KW;
-        ld_c0 = __builtin_amdgcn_readfirstlane((kt_begin - tap * p.ctiles) * BK);   // keep the tap state scalar
+        ld_c0 = __builtin_amdgcn_readfirstlane(ct * BK);                            // keep the tap state scalar
         ld_kh = __builtin_amdgcn_readfirstlane(kh);
         ld_kw = __builtin_amdgcn_readfirstlane(tap - kh * p.KW);
-        soff_b = __builtin_amdgcn_readfirstlane(kt_begin * BK * 2);
+        soff_b = __builtin_amdgcn_readfirstlane((tap * p.Cin + ct * BK) * 2);
     }
     auto retap = [&]() __attribute__((always_inline)) {
         const int tap_pix = ld_kh * p.W + ld_kw;                                      // wave-uniform
@@ -208,6 +214,19 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
     };
     // move the cursors to the next K tile
     auto advance = [&]() __attribute__((always_inline)) {
+        if (p.tap_inner) {                                    // next tap of the same channel tile; after the last, next tile
+            soff_b += p.Cin * 2;
+            if (++ld_kw == p.KW) {
+                ld_kw = 0;
+                if (++ld_kh == p.KH) {
+                    ld_kh = 0;
+                    ld_c0 += BK;
+                    soff_b += (BK - p.KH * p.KW * p.Cin) * 2;
+                }
+            }
+            retap();
+            return;
+        }
         ld_c0 += BK;
         soff_b += BK * 2;
         if (ld_c0 == p.Cin) {
@@ -555,18 +574,23 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         auto one_pass = [&](auto ps_c) __attribute__((always_inline)) {
             constexpr int ps = decltype(ps_c)::value;
             const int mp = m0 + ps * RPP;                    // first output row of this pass
-            uint4 res_a[NG], res_b[NG];
-#pragma unroll
-            for (int it = 0; it < NG; ++it) {
+            // residual groups put in flight BEFORE the accumulators go through the LDS: all NG of them, except for the
+            // 256x256 tile, whose 128 live accumulators leave room for 4 (the rest are loaded where they are used; a spill
+            // would cost the same trip through memory twice)
+            constexpr int PF = (MR * NR >= 8 && NG > 4) ? 4 : NG;
+            uint4 res_a[PF], res_b[PF];
+            auto load_res = [&](int it, uint4 &ra, uint4 &rb) __attribute__((always_inline)) {
                 const int row = mp + r0 + it * RSTEP;
-                res_a[it] = make_uint4(0, 0, 0, 0);
-                res_b[it] = make_uint4(0, 0, 0, 0);
+                ra = make_uint4(0, 0, 0, 0);
+                rb = make_uint4(0, 0, 0, 0);
                 if (use_res && row < p.M) {
                     const char *q = reinterpret_cast<const char *>(p.res) + ((size_t)row * p.rcs + (size_t)col) * 4;
-                    res_a[it] = *reinterpret_cast<const uint4 *>(q);
-                    res_b[it] = *reinterpret_cast<const uint4 *>(q + 16);
+                    ra = *reinterpret_cast<const uint4 *>(q);
+                    rb = *reinterpret_cast<const uint4 *>(q + 16);
                 }
-            }
+            };
+#pragma unroll
+            for (int it = 0; it < PF; ++it) load_res(it, res_a[it], res_b[it]);
             if (ps > 0) __syncthreads();                     // the previous pass has been read out of the tile
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
@@ -603,13 +627,16 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
                             for (int e = 0; e < 8; ++e) v.v[e] += bias8[e];
                         }
                         if (p.res) {
+                            uint4 ra, rb;
+                            if (it < PF) { ra = res_a[it < PF ? it : 0]; rb = res_b[it < PF ? it : 0]; }
+                            else load_res(it, ra, rb);
                             if (p.res_fmt == 0) {
-                                v.v[0] += __uint_as_float(res_a[it].x); v.v[1] += __uint_as_float(res_a[it].y);
-                                v.v[2] += __uint_as_float(res_a[it].z); v.v[3] += __uint_as_float(res_a[it].w);
-                                v.v[4] += __uint_as_float(res_b[it].x); v.v[5] += __uint_as_float(res_b[it].y);
-                                v.v[6] += __uint_as_float(res_b[it].z); v.v[7] += __uint_as_float(res_b[it].w);
+                                v.v[0] += __uint_as_float(ra.x); v.v[1] += __uint_as_float(ra.y);
+                                v.v[2] += __uint_as_float(ra.z); v.v[3] += __uint_as_float(ra.w);
+                                v.v[4] += __uint_as_float(rb.x); v.v[5] += __uint_as_float(rb.y);
+                                v.v[6] += __uint_as_float(rb.z); v.v[7] += __uint_as_float(rb.w);
                             } else {                                  // SPLIT16 group: [8 x f16 hi][8 x f16 lo]
-                                const half8 hi = __builtin_bit_cast(half8, res_a[it]), lo = __builtin_bit_cast(half8, res_b[it]);
+                                const half8 hi = __builtin_bit_cast(half8, ra), lo = __builtin_bit_cast(half8, rb);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v.v[e] += (float)hi[e] + (float)lo[e];
                             }

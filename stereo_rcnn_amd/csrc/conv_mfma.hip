@@ -26,6 +26,7 @@
 //   * epilogue fuses folded-BN bias, residual add, ReLU, channel-offset writes (concat in place)
 //     and the ConvTranspose2d(2,2) pixel scatter.
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace srcnn {
 
@@ -357,6 +358,10 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.ycs = d->y_cstride; a.yco = d->y_coffset; a.rcs = d->res_cstride; a.relu = d->relu; a.mode = d->mode;
+    {
+        static const int tap_inner_default = [] { const char *e = std::getenv("SRCNN_TAP_INNER"); return e ? std::atoi(e) : 1; }();     // A/B switch; default on
+        a.tap_inner = (tap_inner_default && d->KH * d->KW > 1 && d->Cin > BK) ? 1 : 0;
+    }
     const long long M = (long long)d->B * d->OH * d->OW;
     SRCNN_REQUIRE(M < (1LL << 31) && (long long)d->B * d->H * d->W < (1LL << 31), "tensor too large");
     a.M = (int)M;
