@@ -387,10 +387,14 @@ def _conv_ref64(x_nhwc, cw):
 
 @pytest.mark.parametrize("scale", [1e-3, 1.0, 1e3])
 @pytest.mark.parametrize("k", [1, 3])
-def test_split16_dynamic_range_trained_like_weights(dev, scale, k):
+@pytest.mark.parametrize("shifted", [False, True])
+def test_split16_dynamic_range_trained_like_weights(dev, scale, k, shifted):
     """the f16x3 / SPLIT16 engine with activations scaled x1e-3 and x1e3 and a trained-like weight
     distribution (frozen-BN per-channel gains spanning 1e-2 .. 16 folded into the weights) against float64 convolution,
-    through two chained layers so that the re-split SPLIT16 intermediate is exercised.  The range guard stays clear."""
+    through two chained layers so that the re-split SPLIT16 intermediate is exercised.  The range guard stays clear.
+    shifted: every tensor stored x 2^k with the k a calibration would choose (in_shift / out_shift of
+    engine.conv2d, exact power-of-two bookkeeping) -- the x1e-3 case then has the x1 case's 2e-7, not the 2e-5 of f16
+    subnormal `lo` halves."""
     from stereo_rcnn_amd import _lib, engine
     g = torch.Generator().manual_seed(int(k * 10 + abs(torch.log10(torch.tensor(scale)).item())))
     C = 128
@@ -405,17 +409,23 @@ def test_split16_dynamic_range_trained_like_weights(dev, scale, k):
     x = (torch.randn(B, H, W, C, generator=g) * scale).to(dev)
     S = _lib.FMT_SPLIT16
     engine.range_flag(reset=True)
-    xs = engine.act_convert(x, 0, S)
+    ref_mid = _conv_ref64(x, c1).float()
+    ref = _conv_ref64(ref_mid, c2)
+    import math
+    pick = lambda t: int(round(math.log2(2048.0 / float(t.abs().max())))) if shifted else 0      # plan.calibrate's rule
+    kx, km, ko = pick(x), pick(ref_mid), pick(ref)
+    xs = engine.act_convert(x * 2.0 ** kx, 0, S)
     mid, out = torch.empty_like(xs), torch.empty_like(xs)
-    engine.conv2d(c1, xs, B, H, W, mid, H, W, precision='f16x3', x_fmt=S, y_fmt=S, name='range.c1')
-    engine.conv2d(c2, mid, B, H, W, out, H, W, precision='f16x3', x_fmt=S, y_fmt=S, name='range.c2')
-    got = engine.act_convert(out, S, 0).double()
-    ref = _conv_ref64(_conv_ref64(x, c1).float(), c2)
+    engine.conv2d(c1, xs, B, H, W, mid, H, W, precision='f16x3', x_fmt=S, y_fmt=S, name='range.c1', in_shift=kx, out_shift=km)
+    engine.conv2d(c2, mid, B, H, W, out, H, W, precision='f16x3', x_fmt=S, y_fmt=S, name='range.c2', in_shift=km, out_shift=ko)
+    got = engine.act_convert(out, S, 0).double() * 2.0 ** -ko
     flag, name = engine.range_flag(reset=True)
     assert flag == 0, name
     err = float((got - ref).abs().max() / ref.abs().max())
-    print('scale %g k=%d: max |err| / max |ref| = %.2e (max |ref| %.3g)' % (scale, k, err, float(ref.abs().max())))
-    assert err < (2e-6 if scale >= 1.0 else 1e-4), err       # below ~6e-5 the f16 halves are subnormal: absolute floor 3e-8
+    print('scale %g k=%d %s: max |err| / max |ref| = %.2e (max |ref| %.3g)'
+          % (scale, k, 'tensor shifts %d/%d/%d' % (kx, km, ko) if shifted else 'unshifted', err, float(ref.abs().max())))
+    # unshifted, below ~6e-5 the f16 halves are subnormal (absolute floor 3e-8); with the tensors' scales every case is the x1 case
+    assert err < (2e-6 if (scale >= 1.0 or shifted) else 1e-4), err
 
 
 def test_split16_range_guard_trips_and_names_the_layer(dev):
