@@ -141,28 +141,32 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
     const size_t base_bytes = (((size_t)b0 * p.H + row0) * p.W) * p.xcs * 4;
     const rsrc_t rx = make_rsrc(reinterpret_cast<const char *>(p.x) + base_bytes, (size_t)p.nimg * p.H * p.W * p.xcs * 4 - base_bytes);
     const rsrc_t rwh = make_rsrc(p.w, (size_t)p.Cout * p.K * 2), rwl = make_rsrc(p.w_lo, (size_t)p.Cout * p.K * 2);
-    // per-lane state of A group g: pixel index of the row's window origin relative to (image b0, row row0) (negative
-    // inside the padding) and the origin (ih0, iw0) packed as two 16-bit fields for the border test; rows past M never match
-    int a_pix[AG], a_hw[AG];
+    // per-lane state of A group g: byte offset of the row's window origin relative to (image b0, row row0) plus the lane's
+    // chunk (negative inside the padding: never used there), and the taps that fall inside the image as two bit fields --
+    // bit kh: row ih0 + kh exists, bit 8 + kw: column iw0 + kw exists (KH, KW <= 7) -- so that a tap change costs a shift,
+    // an and, an add and a select per group.  Rows past M have no valid tap.
+    int a_org[AG], a_vm[AG];
 #pragma unroll
     for (int g = 0; g < AG; ++g) {
         const int m = m0 + wave * 16 * AG + g * 16 + drow;
+        a_org[g] = 0;
+        a_vm[g] = 0;
         if (m < p.M) {
             const int b = m / ohw;
             const int rem = m - b * ohw;
             const int oh = rem / p.OW;
             const int ow = rem - oh * p.OW;
             const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-            a_pix[g] = ((b - b0) * p.H + ih0 - row0) * p.W + iw0;
-            a_hw[g] = (ih0 << 16) | (iw0 & 0xffff);
-        } else {
-            a_pix[g] = 0;
-            a_hw[g] = (int)0x80008000u;                       // (-32768, -32768): outside every image for every tap
+            a_org[g] = (((b - b0) * p.H + ih0 - row0) * p.W + iw0) * (p.xcs * 4) + dchunk * 32;
+            int vm = 0;
+            for (int k = 0; k < p.KH; ++k) vm |= ((unsigned)(ih0 + k) < (unsigned)p.H ? 1 : 0) << k;
+            for (int k = 0; k < p.KW; ++k) vm |= ((unsigned)(iw0 + k) < (unsigned)p.W ? 1 : 0) << (8 + k);
+            a_vm[g] = vm;
         }
     }
     // ---- DMA source cursors.  A: lane offset of the current tap's (row, chunk) run, or OOB when the tap falls outside
-    //      the image / the row is past M; re-derived only when the tap changes (every Cin/32 K tiles).  The channel tile
-    //      inside the tap and B's K position are scalar offsets: one s_add per K tile.
+    //      the image / the row is past M; re-derived when the tap changes.  The channel tile inside the tap and B's K
+    //      position are scalar offsets.
     int a_voff[AG], b_voff[BG];
     // K order.  p.tap_inner = 0: (tap, channel tile) as K runs in memory -- a tap's data is touched Cin/32 K tiles apart.
     // p.tap_inner = 1 (3x3 layers): (channel tile, tap) -- consecutive K tiles read the SAME input pixels shifted by one
@@ -180,12 +184,11 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         soff_b = __builtin_amdgcn_readfirstlane((tap * p.Cin + ct * BK) * 2);
     }
     auto retap = [&]() __attribute__((always_inline)) {
-        const int tap_pix = ld_kh * p.W + ld_kw;                                      // wave-uniform
+        const int tap_off = (ld_kh * p.W + ld_kw) * (p.xcs * 4);                      // wave-uniform
 #pragma unroll
         for (int g = 0; g < AG; ++g) {
-            const int ih = (a_hw[g] >> 16) + ld_kh, iw = (int)(short)(a_hw[g] & 0xffff) + ld_kw;
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            a_voff[g] = ok ? (a_pix[g] + tap_pix) * (p.xcs * 4) + dchunk * 32 : OOB;
+            const bool ok = ((a_vm[g] >> ld_kh) & (a_vm[g] >> (8 + ld_kw)) & 1) != 0;
+            a_voff[g] = ok ? a_org[g] + tap_off : OOB;
         }
     };
     retap();

@@ -351,6 +351,8 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     // tile (<= 256 output pixels: a few rows, also across an image boundary) -- any tensor size, but one tile's rows must
     // span < 2 GB
     if (d->precision == 1 && a.x_fmt == 1)
+        SRCNN_REQUIRE(d->KH <= 8 && d->KW <= 8, "SPLIT16 engine: kernel sizes up to 8 (tap validity is kept as two 8-bit fields)");
+    if (d->precision == 1 && a.x_fmt == 1)
         SRCNN_REQUIRE((long long)d->W * d->x_cstride * 4 * ((256 / d->OW + 3) * (long long)d->stride + d->KH) < (1LL << 31),
                       "SPLIT16 engine: the input rows under one 256-pixel tile must span < 2 GB");
     a.nimg = d->B;
