@@ -143,3 +143,68 @@ def test_tuned_plans_round_trip(tmp_path):
     finally:
         engine._TUNED.clear()
         engine._TUNED.update(saved)
+
+
+def test_layer_table_bounds_grouping_and_ranking():
+    """stereo_rcnn_amd/layer_table.py (bench.py's roofline.layers): own bound = max(issued MFMA flops / peak, bytes / HBM rate),
+    launches of one layer shape pooled, groups ranked by the time they lose -- on hand-made rows, no GPU."""
+    from stereo_rcnn_amd import layer_table as lt
+    rows = []
+    for i in range(3):          # an MFMA-bound layer, three blocks: 10 GFLOP, 10 MB each, 100 us measured
+        rows.append({'name': 'layer3.%d.conv2' % i, 'M': 9500, 'N': 256, 'K': 2304, 'flops': 10e9, 'bytes': 10e6, 'plan': (2, 2, 8, 4, 1),
+                     'us': 100.0, 'wgs': 150})
+    rows.append({'name': 'layer1.0.conv3', 'M': 149100, 'N': 256, 'K': 64, 'flops': 1e9, 'bytes': 630e6, 'plan': (2, 2, 8, 2, 1),
+                 'us': 125.0, 'wgs': 2330})
+    for r in rows:              # what measure() derives per row
+        r['mfma_us'] = 3.0 * r['flops'] / 2.5e15 * 1e6
+        r['hbm_us'] = r['bytes'] / 6.3e12 * 1e6
+        r['bound_us'] = max(r['mfma_us'], r['hbm_us'])
+        r['bound'] = 'mfma' if r['mfma_us'] >= r['hbm_us'] else 'hbm'
+        r['frac_of_own_bound'] = r['bound_us'] / r['us']
+        r['lost_us'] = r['us'] - r['bound_us']
+        r['tflops'] = r['flops'] / r['us'] / 1e6
+    assert abs(rows[0]['bound_us'] - 12.0) < 1e-9 and rows[0]['bound'] == 'mfma'
+    assert abs(rows[3]['bound_us'] - 100.0) < 1e-9 and rows[3]['bound'] == 'hbm'
+    g = lt.grouped(rows)
+    assert [x['name'] for x in g] == ['layer3.*.conv2', 'layer1.*.conv3']          # 3 x 88 us lost ranks above 25 us lost
+    assert g[0]['launches'] == 3 and abs(g[0]['us'] - 300.0) < 1e-9 and abs(g[0]['lost_us'] - 264.0) < 1e-9
+    s = lt.summary(rows)
+    assert s['launches'] == 4 and s['mfma_bound_launches'] == 3 and s['hbm_bound_launches'] == 1
+    assert abs(s['frac_of_own_bounds'] - (36.0 + 100.0) / 425.0) < 1e-3
+    top = lt.top_for_json(rows, 1)
+    assert len(top) == 1 and top[0]['layer'] == 'layer3.*.conv2' and top[0]['workgroups'] == 150
+    txt = lt.format_table(rows, 'title')
+    assert 'layer3.*.conv2' in txt and 'every launch, in launch order' in txt
+
+
+def test_rank_host_budget_and_numa_pinning(tmp_path, monkeypatch):
+    """distributed.py: a rank's share of the host cores for its Newton-CG threads and the CPU list of its GPU's NUMA node read
+    from sysfs (here: a fake tree)."""
+    import os
+    from stereo_rcnn_amd import distributed as sdist
+    assert sdist._parse_cpulist('0-3,8,10-11\\n') == {0, 1, 2, 3, 8, 10, 11}
+    ncpu = len(os.sched_getaffinity(0))
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert sdist.local_world_size() == 8 and sdist.host_solver_threads() == max(1, min(16, ncpu // 8))
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '1')
+    assert sdist.host_solver_threads(4) == min(4, ncpu)
+    # fake sysfs: GPU at 0000:c1:00.0 on NUMA node 1 whose cpulist is this process's own first CPU
+    mine = sorted(os.sched_getaffinity(0))
+    dev = tmp_path / 'bus' / 'pci' / 'devices' / '0000:c1:00.0'
+    dev.mkdir(parents=True)
+    (dev / 'numa_node').write_text('1\\n')
+    node = tmp_path / 'devices' / 'system' / 'node' / 'node1'
+    node.mkdir(parents=True)
+    (node / 'cpulist').write_text('%d\\n' % mine[0])
+
+    class Props(object):
+        pci_domain_id, pci_bus_id, pci_device_id = 0, 0xc1, 0
+    import torch
+    monkeypatch.setattr(torch.cuda, 'get_device_properties', lambda i: Props())
+    assert sdist.gpu_numa_cpus(0, sysfs=str(tmp_path)) == (1, {mine[0]})
+    try:
+        got = sdist.pin_to_gpu_numa(0, cpus={mine[0]})
+        assert got == {'numa_node': None, 'cpus': 1} and os.sched_getaffinity(0) == {mine[0]}
+        assert sdist.pin_to_gpu_numa(0, cpus={10 ** 6}) is None           # nothing of the mask left: unchanged
+    finally:
+        os.sched_setaffinity(0, mine)
