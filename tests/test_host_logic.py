@@ -182,7 +182,7 @@ def test_rank_host_budget_and_numa_pinning(tmp_path, monkeypatch):
     from sysfs (here: a fake tree)."""
     import os
     from stereo_rcnn_amd import distributed as sdist
-    assert sdist._parse_cpulist('0-3,8,10-11\\n') == {0, 1, 2, 3, 8, 10, 11}
+    assert sdist._parse_cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
     ncpu = len(os.sched_getaffinity(0))
     monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
     assert sdist.local_world_size() == 8 and sdist.host_solver_threads() == max(1, min(16, ncpu // 8))
@@ -192,10 +192,10 @@ def test_rank_host_budget_and_numa_pinning(tmp_path, monkeypatch):
     mine = sorted(os.sched_getaffinity(0))
     dev = tmp_path / 'bus' / 'pci' / 'devices' / '0000:c1:00.0'
     dev.mkdir(parents=True)
-    (dev / 'numa_node').write_text('1\\n')
+    (dev / 'numa_node').write_text('1\n')
     node = tmp_path / 'devices' / 'system' / 'node' / 'node1'
     node.mkdir(parents=True)
-    (node / 'cpulist').write_text('%d\\n' % mine[0])
+    (node / 'cpulist').write_text('%d\n' % mine[0])
 
     class Props(object):
         pci_domain_id, pci_bus_id, pci_device_id = 0, 0xc1, 0
