@@ -79,6 +79,11 @@ def parse():
     ap.add_argument('--layers-out', default='',
                     help='write the full per-layer roofline table (every conv launch: shape, bytes, time, own bound) to this file; '
                          'the JSON line always carries the 15 layer groups that lose most time as roofline.layers')
+    ap.add_argument('--no-pmc', action='store_true',
+                    help='do not measure roofline.traffic in this run (default at N = 1, --config 1: two short child runs of '
+                         'this script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE`, about a minute); '
+                         'the committed profiles/pmc_*_traffic.json is then quoted if it matches the kernel sources')
+    ap.add_argument('--pmc-child', type=int, default=0, help=argparse.SUPPRESS)     # internal: N forwards, one stream, exit
     ap.add_argument('--height', type=int, default=375)
     ap.add_argument('--width', type=int, default=1242)
     return ap.parse_args()
@@ -125,6 +130,48 @@ def csrc_hash():
         with open(f, 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def measure_traffic_live(plans_path, steps=3, timeout_s=240):
+    """HBM-side bytes of the conv engine per step, measured in THIS run on THIS box: two child processes of this script
+    (`--pmc-child`: plans preloaded, `steps` forwards one at a time, nothing else) under rocprofv3's counter collection, one
+    pass per counter as the MI355X guide prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Returns
+    (fetch_kb_per_step, write_kb_per_step, conv_launches_per_step) or None when rocprofv3 is unavailable or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None
+    out = {}
+    launches = None
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='srcnn_pmc_', dir='/tmp')
+        try:
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'p', '--', sys.executable,
+                   os.path.abspath(__file__), '--pmc-child', str(steps), '--plans', plans_path]
+            env = dict(os.environ, TMPDIR='/tmp')
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            total, seen = 0.0, set()
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    name = row['Kernel_Name']
+                    if row['Counter_Name'] == counter and ('conv_f16s_kernel' in name or 'conv_f16x3_kernel' in name):
+                        total += float(row['Counter_Value'])
+                        seen.add(row['Dispatch_Id'])
+            # the child runs one untimed forward first (workspace sizing); every forward has the same launches
+            out[counter] = total / (steps + 1)
+            launches = len(seen) // (steps + 1)
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out['FETCH_SIZE'], out['WRITE_SIZE'], launches
 
 
 def relaunch_under_torchrun(args):
@@ -311,6 +358,14 @@ def main():
 
     S = max(1, args.streams if args.streams > 0 else wl['streams'])
     plans_loaded = bool(args.plans) and os.path.exists(args.plans) and engine.load_plans(args.plans) > 0
+    if args.pmc_child:              # counter-collection child of measure_traffic_live(): forwards only, one at a time
+        assert plans_loaded, "--pmc-child needs the parent's tuned plans"
+        model.use_program = False
+        with torch.no_grad():
+            for _ in range(args.pmc_child + 1):
+                model(im_l, im_r, im_info)
+                torch.cuda.synchronize()
+        return
     streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [None]
 
     # detections of G consecutive steps (B images each) are packed into one buffer and gathered by ONE RCCL all_gather
@@ -512,7 +567,23 @@ def main():
             traffic, traffic_note = None, 'no profiles/pmc_*_traffic.json next to bench.py'
             import glob
             tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_*_traffic.json')))
-            if args.config != 1:
+            live = None
+            if args.config == 1 and world == 1 and not args.no_pmc and args.precision == 'f16x3':
+                import tempfile
+                pf = args.plans if plans_loaded else os.path.join(tempfile.gettempdir(), 'srcnn_bench_plans_%d.json' % os.getpid())
+                if not plans_loaded:
+                    engine.save_plans(pf)
+                torch.cuda.synchronize()
+                live = measure_traffic_live(pf)
+            if live is not None and live[2] == launches:
+                traffic = round((2.0 * live[0] + live[1]) * 1024.0 / max(launches, 1))
+                traffic_note = ('bytes per conv launch, HBM side, MEASURED IN THIS RUN on these sources: (2 x FETCH_SIZE + WRITE_SIZE) of '
+                                'the conv-engine launches of one step / launches, two child runs of this script under rocprofv3 '
+                                '--kernel-trace --pmc (one counter per pass; FETCH_SIZE doubled as the gfx950 note prescribes -- '
+                                'uncorrected it is %.1f MB); compulsory bytes of the same launches (every operand element read once, '
+                                'every result written once, 4 B each): `algorithmic_bytes_per_launch`'
+                                % ((live[0] + live[1]) * 1024.0 / max(launches, 1) / 1e6))
+            elif args.config != 1:
                 traffic_note = 'PMC traffic is collected for the headline workload (--config 1) only'
             elif tj and args.precision == 'f16x3':
                 with open(tj[-1]) as f:

@@ -36,6 +36,12 @@ def test_bench_single_process_line(dev):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check(out.stdout.strip().splitlines()[-1], 4, 1)
+    # roofline.traffic is measured in this very run (child runs under rocprofv3 --pmc) wherever rocprofv3 exists
+    import shutil
+    if shutil.which('rocprofv3'):
+        r = d['roofline']
+        assert r['traffic'] and 'MEASURED IN THIS RUN' in r['traffic_note'], r['traffic_note']
+        assert 0.9 < r['traffic_over_algorithmic'] < 2.0, r['traffic_over_algorithmic']
 
 
 
@@ -44,7 +50,7 @@ def test_bench_under_torch_distributed_run(dev):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
                           '127.0.0.1', '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5',
-                          '--warmup', '1', '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+                          '--warmup', '1', '--no-cpu-baseline', '--no-pmc'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')][-1], 5, 1)
     assert 'all_gather' in d['config']['parallelism']
