@@ -34,6 +34,8 @@ class Weights(object):
         # Plan.calibrate() has seen one input (then fixed for the life of these weights, for every plan / slot)
         self.shifts = {}
         self.calibrated = False
+        self.calibration_max = {}      # group -> largest |value| seen by the calibration forwards
+        self.calib_epoch = 0           # bumped whenever the shifts change: plans drop their recorded programs / graphs
         self.stem = engine.prep_stem(sd['RCNN_layer0.0.weight'], _bn_dict(sd, 'RCNN_layer0.1'), device)
         self.layers = []
         for li in (1, 2, 3, 4):
@@ -156,6 +158,7 @@ class Plan(object):
         # sets or clears it, and it lives on the plan's device
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self._calib = None      # group -> max |value| while calibrate() runs
+        self._epoch = weights.calib_epoch
         self._buf_shift = {}    # data_ptr -> shift of the tensor the buffer holds after the last run (as_f32 undoes it)
         self.graphs = {}
         self.programs = {}      # precision -> (native launch program handle, buffers it keeps alive); run(use_program=True)
@@ -190,8 +193,9 @@ class Plan(object):
     def _note(self, group, t):
         self._calib[group] = max(self._calib.get(group, 0.0), float(t.abs().max()))
 
-    def calibrate(self):
-        """Choose the power-of-two scale of every SPLIT16 tensor group from ONE forward of the inputs now in this plan, run on
+    def calibrate(self, merge=False):
+        """Choose the power-of-two scale of every SPLIT16 tensor group from ONE forward of the inputs now in this plan (merge:
+        together with what earlier calibration forwards saw -- _StereoRCNN.calibrate_activation_scales), run on
         the exact fp32 engine: k = round(log2(2^11 / max|v|)), so that the group's largest value sits 32x below the f16
         overflow threshold (the range guard still watches it) and its `lo` halves stay normal down to values 2^13 times
         smaller than the largest.  Power-of-two factors are exact: they travel in the weights' epilogue rescale and the
@@ -208,10 +212,16 @@ class Plan(object):
         finally:
             calib, self._calib = self._calib, None
             self.fmt, engine.PRECISION, self.overlap = saved
-        w.shifts = {}
+        if merge:
+            for g, mx in w.calibration_max.items():
+                calib[g] = max(calib.get(g, 0.0), mx)
+        shifts = {}
         for g, mx in calib.items():
             if mx > 0 and math.isfinite(mx):
-                w.shifts[g] = int(max(-24, min(24, round(math.log2(2048.0 / mx)))))
+                shifts[g] = int(max(-24, min(24, round(math.log2(2048.0 / mx)))))
+        if shifts != w.shifts:
+            w.shifts = shifts
+            w.calib_epoch += 1             # launch programs / graphs recorded with the old scales are stale (every plan checks)
         w.calibrated = True
         w.calibration_max = calib
         self.packed_fmt = -1
@@ -496,6 +506,10 @@ class Plan(object):
         self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
         if self.fmt and engine.ACT_SCALES and not self.w.calibrated:
             self.calibrate()               # once per weights: the scales of every SPLIT16 tensor group, from this first input
+        if self._epoch != self.w.calib_epoch:      # the scales changed since this plan recorded its launch lists
+            for prog, _ in self.programs.values():
+                _lib.lib().srcnn_program_destroy(prog)
+            self.programs, self.graphs, self._epoch = {}, {}, self.w.calib_epoch
         try:
             if use_program and not use_graph:
                 self.packed_fmt = -1                  # the recorded list always contains the stem_pack launches

@@ -160,6 +160,22 @@ class _StereoRCNN(nn.Module):
         plan.set_images(img_left_u8, img_right_u8, self.precision, short)
         return self._run(plan), plan.im_left, plan.im_right, plan.im_info
 
+    def calibrate_activation_scales(self, frames, slot=0):
+        """Extension: choose the SPLIT16 engine's per-tensor power-of-two activation scales (plan.Plan.calibrate) from SEVERAL
+        representative inputs instead of from the first forward alone.  frames: iterable of (im_left_data, im_right_data,
+        im_info) as `forward` takes them; one forward each on the exact fp32 engine; every tensor group's scale covers the
+        largest value any of them produced (x32 headroom on top; the range guard watches the rest).  Returns the shifts."""
+        first = True
+        for im_left_data, im_right_data, im_info in frames:
+            B, _, H, W = im_left_data.shape
+            plan = self._get_plan(int(B), int(H), int(W), slot)
+            plan.set_inputs(im_left_data, im_right_data, im_info)
+            if first and self._weights is not None:
+                self._weights.calibration_max = {}
+            plan.calibrate(merge=not first)
+            first = False
+        return dict(self._weights.shifts) if self._weights is not None else {}
+
     def check_range(self, reset=True):
         """SPLIT16 range guard of the f16x3 engine (engine.range_flag): raises engine.Split16RangeError naming the layer if an
         activation of a forward since the last reset left the f16 range (the results are then invalid: re-run with precision

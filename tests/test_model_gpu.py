@@ -566,3 +566,35 @@ def test_split16_activation_scales_make_the_trunk_scale_invariant(dev, s):
         assert float(ok.float().mean()) >= 0.97
         assert float((b[3][0].cpu()[idx[ok]] - a[3][0].cpu()[ok]).abs().max()) < 1e-4       # bbox_pred
         assert float((b[4][0].cpu()[idx[ok]] - a[4][0].cpu()[ok]).abs().max()) < 1e-4       # dim_orien_pred
+
+
+def test_calibration_over_several_frames_and_program_invalidation(dev):
+    """_StereoRCNN.calibrate_activation_scales: the scales cover the largest activation of ANY calibration frame (here the same
+    pair at x1 and x8 intensity: every trunk shift drops by 3), launch programs recorded under the old scales are dropped and
+    re-recorded, and the x1 pair still matches the fp32 engine within the end-to-end tolerance under the wider scales."""
+    from stereo_rcnn_amd import engine, fixture
+    m, _ = _build_model(dev)
+    l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
+    with torch.no_grad():
+        ref = [t.clone() for t in m(l, r, info)[:8]]                      # fp32 engine
+        m.precision = 'f16x3'
+        m.use_program = True
+        a = [t.clone() for t in m(l, r, info)[:8]]                        # calibrated on this pair, program recorded
+        s1 = dict(m._weights.shifts)
+        plan = m._get_plan(1, l.shape[2], l.shape[3])
+        assert 'f16x3' in plan.programs
+        s8 = m.calibrate_activation_scales([(l, r, info), (l * 8.0, r * 8.0, info)])
+        assert m._weights.calib_epoch >= 2
+        b = [t.clone() for t in m(l, r, info)[:8]]                        # stale program dropped, re-recorded with the new scales
+        assert plan._epoch == m._weights.calib_epoch and 'f16x3' in plan.programs
+        c = [t.clone() for t in m(l * 8.0, r * 8.0, info)[:8]]
+    torch.cuda.synchronize()
+    assert engine.range_flag(reset=True) == (0, None)
+    for g in ('stem', 'L1', 'L2', 'L3', 'L4'):
+        assert s8[g] in (s1[g] - 3, s1[g] - 2), (g, s1[g], s8[g])          # frozen-BN biases keep x8 from being exactly 2^3 everywhere
+    for out in (a, b):
+        idx = _match_rois(out[0][0].cpu(), ref[0][0].cpu(), 5e-2)
+        ok = idx >= 0
+        assert float(ok.float().mean()) >= 0.97
+        assert float((out[3][0].cpu()[idx[ok]] - ref[3][0].cpu()[ok]).abs().max()) < 1e-4
+    assert torch.isfinite(c[3]).all()

@@ -1,9 +1,4 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c16
-( time python bench.py --steps 30 ) > gpurun_out/c16/bench.json 2> gpurun_out/c16/bench.err; echo rc=$?
-tail -3 gpurun_out/c16/bench.err
-python - <<PY
-import json
-d=json.loads(open('gpurun_out/c16/bench.json').read().strip().splitlines()[0])
-r=d['roofline']; print(d['value'], r['traffic'], r['traffic_over_algorithmic'], r['traffic_note'][:160])
-PY
+mkdir -p gpurun_out/c17
+timeout 900 python -m pytest tests/test_model_gpu.py -x -q -m gpu -k "calibration or activation_scales or program" > gpurun_out/c17/t.log 2>&1; echo rc=$?
+tail -12 gpurun_out/c17/t.log
