@@ -137,6 +137,12 @@ typedef struct srcnn_conv_desc {
     int x_format, y_format, res_format;
     int tile_waves, tile_stages;
     int layer_tag;         /* caller's id of this layer (> 0) for srcnn_range_flag_read; 0 = untagged */
+    /* Device-side row limit (SPLIT16 f16x3 engine; NULL = none): only output rows m < (*m_limit) * m_limit_mul are needed.
+     * Workgroups whose whole tile lies beyond exit at once; rows beyond the limit inside a computed tile are still written.
+     * Lets a fixed-shape launch list serve a data-dependent row count without a host read-back: the keypoint head runs on
+     * the detections that survived class NMS only (*m_limit = the device-side keep count, m_limit_mul = rows per roi). */
+    const int *m_limit;
+    int m_limit_mul;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
@@ -216,6 +222,16 @@ SRCNN_API int srcnn_softmax_rows(const float *x, int rows, int cols, int x_strid
 SRCNN_API int srcnn_kpts_tail(const float *logits, int n, int G, float *kpts_prob, float *left_prob, float *right_prob,
                     srcnn_stream_t stream);
 /* detection decode (demo.py:144-218, bbox_transform.py:133-155) for B == 1 blocks of n rois. */
+/* Keypoint head on the kept detections only ("lazy" form of stereo_rcnn.py:260-271 + demo.py:196-209: the reference computes the
+ * keypoint branch for all 300 rois and its scripts then read the rows that survive score threshold + NMS; every roi's
+ * keypoint computation is independent of the others).
+ * srcnn_gather_rows: dst[r] = src[max(idx[r], 0)] for r < n_idx (rows of `cols` floats; -1 padded index lists repeat row 0).
+ * srcnn_decode_kept_kpts: for r < *num_keep, i = keep_idx[r]: kpts[i] (5 floats, as srcnn_decode_detections writes them)
+ *   from row r of the kept-order probability arrays and roi i of rois_left; other rows of `kpts` are left alone. */
+SRCNN_API int srcnn_gather_rows(const float *src, const int *idx, int n_idx, int cols, float *dst, srcnn_stream_t stream);
+SRCNN_API int srcnn_decode_kept_kpts(const float *rois_left, const float *kpts_prob, const float *left_prob,
+                                     const float *right_prob, const int *keep_idx, const int *num_keep, const float *im_info,
+                                     int n, int G, float *kpts, srcnn_stream_t stream);
 SRCNN_API int srcnn_decode_detections(const float *rois_left, const float *rois_right, const float *bbox_pred,
                             const float *dim_orien_pred, const float *kpts_prob, const float *left_prob,
                             const float *right_prob, const float *im_info, int n, int n_cls, int G,

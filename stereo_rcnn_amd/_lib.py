@@ -31,7 +31,8 @@ class ConvDesc(ctypes.Structure):
                 ("precision", c_int), ("w_lo", c_void_p), ("w_inv_scale", c_float),
                 ("tile_mr", c_int), ("tile_nr", c_int), ("splits", c_int),
                 ("x_format", c_int), ("y_format", c_int), ("res_format", c_int),
-                ("tile_waves", c_int), ("tile_stages", c_int), ("layer_tag", c_int)]
+                ("tile_waves", c_int), ("tile_stages", c_int), ("layer_tag", c_int),
+                ("m_limit", c_void_p), ("m_limit_mul", c_int)]
 
 
 _SIGNATURES = {
@@ -50,6 +51,9 @@ _SIGNATURES = {
                                         c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p]),
     "srcnn_act_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
+    "srcnn_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "srcnn_decode_kept_kpts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                       c_void_p]),
     "srcnn_conv2d_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "srcnn_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_size_t, c_void_p]),
     "srcnn_range_flag_read": (c_int, [c_int]),

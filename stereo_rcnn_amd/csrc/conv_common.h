@@ -29,6 +29,8 @@ struct ConvArgs {
     unsigned long long *stamp;   // debug: per-workgroup phase timestamps (conv_f16s only), normally nullptr
     unsigned *range_flag;        // SPLIT16 range guard (see split16_guard); never null for SPLIT16 outputs
     int tag;                     // caller's layer tag (>= 0): the flag keeps the largest tag + 1 that tripped
+    const int *m_limit;          // device-side row limit (rows m >= *m_limit * m_limit_mul are not needed) or nullptr
+    int m_limit_mul;
 };
 
 

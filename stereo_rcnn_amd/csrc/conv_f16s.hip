@@ -118,8 +118,18 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         st0 = __builtin_readcyclecounter();
         rt0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz, common to the whole chip
     }
-    const int nblk = p.mtiles * p.ntiles;
+    int nblk = p.mtiles * p.ntiles;
     const int bid = blockIdx.x;
+    int m_rows = p.M;                                         // rows whose INPUT is read: beyond, the A operand is zeros
+    if (p.m_limit) {
+        // device-side row limit: tiles beyond it are not needed, and rows beyond it inside a computed tile never read their
+        // (possibly stale, possibly other-format) input.  The XCD mapping below is taken over the tiles that DO run: over
+        // the whole grid, the limited rows (the first logical tiles) would all be XCD 0's share and run on 32 CUs.
+        const int lim = max(__builtin_amdgcn_readfirstlane(*p.m_limit), 0) * p.m_limit_mul;
+        m_rows = min(m_rows, lim);
+        nblk = ((m_rows + BM - 1) / BM) * p.ntiles;
+        if (bid >= nblk) return;
+    }
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, slot = bid >> 3;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         const int m = m0 + wave * 16 * AG + g * 16 + drow;
         a_org[g] = 0;
         a_vm[g] = 0;
-        if (m < p.M) {
+        if (m < m_rows) {
             const int b = m / ohw;
             const int rem = m - b * ohw;
             const int oh = rem / p.OW;

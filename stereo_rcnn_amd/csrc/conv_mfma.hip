@@ -196,6 +196,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p)
 // deterministic split-K reduction + epilogue (modes 0 and 2)
 __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
 {
+    // rows beyond the device-side limit were not computed by the conv launch: leave them alone (their partials are stale)
+    const size_t row_limit = p.m_limit ? (size_t)max(*p.m_limit, 0) * (size_t)p.m_limit_mul : (size_t)p.M;
     const size_t total = (size_t)p.M * p.Cout;
     if ((p.Cout & 7) == 0 && (p.ycs & 7) == 0 && (p.yco & 7) == 0 && (!p.res || (p.rcs & 7) == 0)) {
         // 8 channels per thread: 32-byte reads of every slab, vector residual / store in either format
@@ -205,6 +207,7 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
              gi += (size_t)gridDim.x * blockDim.x) {
             const size_t row = gi / G;
             const int g = (int)(gi - row * G);
+            if (row >= row_limit) continue;
             float8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] = 0.f;
@@ -245,6 +248,7 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(idx / p.Cout), col = (int)(idx - (size_t)row * p.Cout);
+        if ((size_t)row >= row_limit) continue;
         float v = 0.f;
         for (int s = 0; s < splits; ++s) v += p.partial[(size_t)s * total + idx];
         if (p.bias) v += p.bias[col];
@@ -343,6 +347,9 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     a.stamp = debug_stamp_buffer();
     a.range_flag = nullptr;
     a.tag = d->layer_tag > 0 ? d->layer_tag : 0;
+    a.m_limit = d->m_limit;
+    a.m_limit_mul = d->m_limit_mul;
+    if (a.m_limit) SRCNN_REQUIRE(d->precision == 1 && d->x_format == 1 && d->m_limit_mul > 0, "m_limit: SPLIT16 f16x3 engine, m_limit_mul > 0");
     if (a.y_fmt == 1) {
         a.range_flag = range_flag_word();
         SRCNN_REQUIRE(a.range_flag != nullptr, "range flag allocation failed");

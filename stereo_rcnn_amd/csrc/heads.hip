@@ -126,6 +126,45 @@ __global__ void decode_detections_kernel(const float *__restrict__ rois_l, const
     o[4] = ((float)rd * widths / g + rl[0]) / scale;
 }
 
+// ------------------------------------------------------------------ keypoint head on the kept detections only
+__global__ void gather_rows_kernel(const float *__restrict__ src, const int *__restrict__ idx, int n_idx, int cols,
+                                   float *__restrict__ dst)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_idx * cols) return;
+    const int r = t / cols, c = t - r * cols;
+    const int i = max(idx[r], 0);                 // -1 padded keep lists: repeat row 0 (never read back)
+    dst[t] = src[(size_t)i * cols + c];
+}
+
+// the keypoint part of decode_detections_kernel for the rows of a keep list: probabilities in KEPT order (row r belongs to
+// roi keep_idx[r]), result written to the roi's own row of `kpts`
+__global__ void decode_kept_kpts_kernel(const float *__restrict__ rois_l, const float *__restrict__ kpts_prob,
+                                        const float *__restrict__ left_prob, const float *__restrict__ right_prob,
+                                        const int *__restrict__ keep_idx, const int *__restrict__ num,
+                                        const float *__restrict__ im_info, int n, int G, float *__restrict__ kpts)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || r >= *num) return;
+    const int i = keep_idx[r];
+    if (i < 0) return;
+    const float scale = im_info[2];
+    const float *rl = rois_l + (size_t)i * 5 + 1;
+    float pmax;
+    const int kd = argmax_first(kpts_prob + (size_t)r * 4 * G, 4 * G, &pmax);
+    const int ld = argmax_first(left_prob + (size_t)r * G, G, nullptr);
+    const int rd = argmax_first(right_prob + (size_t)r * G, G, nullptr);
+    const float widths = rl[2] - rl[0] + 1.0f;    // proposal width (bbox_transform.py:135,149)
+    const float g = (float)G;
+    const float dk = (float)kd;
+    float *o = kpts + (size_t)i * 5;
+    o[0] = ((float)(kd % G) * widths / g + rl[0]) / scale;   // :141 then demo.py:208
+    o[1] = dk / g;                                           // kpts_type stays a float (:139)
+    o[2] = pmax;
+    o[3] = ((float)ld * widths / g + rl[0]) / scale;
+    o[4] = ((float)rd * widths / g + rl[0]) / scale;
+}
+
 // ------------------------------------------------------------------ per-class filter + sort
 __device__ __forceinline__ unsigned score_key32(float f)
 {
@@ -269,6 +308,28 @@ int srcnn_kpts_tail(const float *logits, int n, int G, float *kpts_prob, float *
     SRCNN_LAUNCH(kpts_tail_kernel, dim3(n), dim3(256), 0, as_stream(stream), logits, G, kpts_prob, left_prob,
                        right_prob);
     return check_launch("srcnn_kpts_tail");
+}
+
+int srcnn_gather_rows(const float *src, const int *idx, int n_idx, int cols, float *dst, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(src && idx && dst && n_idx >= 0 && cols > 0, "bad args");
+    if (n_idx == 0) return SRCNN_OK;
+    SRCNN_LAUNCH(gather_rows_kernel, dim3(cdiv(n_idx * cols, 256)), dim3(256), 0, as_stream(stream), src, idx, n_idx, cols, dst);
+    return check_launch("srcnn_gather_rows");
+}
+
+int srcnn_decode_kept_kpts(const float *rois_left, const float *kpts_prob, const float *left_prob, const float *right_prob,
+                           const int *keep_idx, const int *num_keep, const float *im_info, int n, int G, float *kpts,
+                           srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(rois_left && kpts_prob && left_prob && right_prob && keep_idx && num_keep && im_info && kpts && G > 0 && G <= 32,
+                  "bad args");
+    if (n == 0) return SRCNN_OK;
+    SRCNN_LAUNCH(decode_kept_kpts_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), rois_left, kpts_prob, left_prob,
+                 right_prob, keep_idx, num_keep, im_info, n, G, kpts);
+    return check_launch("srcnn_decode_kept_kpts");
 }
 
 int srcnn_decode_detections(const float *rois_left, const float *rois_right, const float *bbox_pred,

@@ -150,6 +150,7 @@ MAX_LDS_KB = int(_os.environ.get('SRCNN_MAX_LDS_KB', '160'))
 
 
 ACT_SCALES = _os.environ.get('SRCNN_ACT_SCALES', '1') != '0'    # per-tensor power-of-two SPLIT16 activation scales (plan.calibrate)
+LIMIT_TUNE_ROIS = 64          # row-limited launches (the lazy keypoint head) are tuned for this many units below the limit
 RPN_PAIR_LAUNCH = _os.environ.get('SRCNN_RPN_PAIR', '1') != '0'     # A/B switch of the one-launch stereo RPN conv (conv mode 2)
 
 
@@ -211,6 +212,23 @@ def _tune(d, key, device):
     log = _TUNE_LOG.setdefault(key, [])
     del log[:]
     st = _lib.stream()
+    # the trial launches may run on whatever the buffers hold (a tensor last written in the other activation format reads as
+    # NaNs): their range-guard reports go to a scratch word, not to the forward's
+    global _tune_flag
+    if _tune_flag is None or _tune_flag.device != device:
+        _tune_flag = torch.zeros(1, dtype=torch.int32, device=device)
+    bound = L.srcnn_range_flag_device_word()
+    L.srcnn_range_flag_bind(_tune_flag.data_ptr())
+    try:
+        return _tune_candidates(d, key, device, cands, log, L, st)
+    finally:
+        L.srcnn_range_flag_bind(bound)
+
+
+_tune_flag = None
+
+
+def _tune_candidates(d, key, device, cands, log, L, st):
 
     def timed(plan, launches):
         _set_plan(d, plan)
@@ -246,13 +264,14 @@ def _tune(d, key, device):
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
            res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None,
-           in_shift=0, out_shift=0):
+           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
     *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h).
     in_shift / out_shift (f16x3 engine): the input tensor holds its values x 2^in_shift, the output (and the residual, which
     must carry the output's scale) is to be stored x 2^out_shift -- per-tensor power-of-two activation scales that keep
     SPLIT16 tensors in the middle of the f16 range (model/stereo_rcnn/plan.py: calibrate).  Exact: the factor goes into the
-    epilogue's power-of-two rescale and a pre-scaled copy of the bias; ReLU commutes with it."""
+    epilogue's power-of-two rescale and a pre-scaled copy of the bias; ReLU commutes with it.
+    m_limit (device int32 tensor) / m_limit_mul: only rows m < m_limit[0] * m_limit_mul are needed (srcnn_conv_desc.m_limit)."""
     L = _lib.lib()
     d = _lib.ConvDesc()
     d.x = x.data_ptr() + 4 * x_offset_elems
@@ -296,16 +315,25 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     if plan is not None:                   # explicit (tile_mr, tile_nr, waves, stages, splits): tests and tools
         _set_plan(d, plan)
     elif AUTOTUNE:
-        key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt))
+        # a launch with a device-side row limit is tuned WITH a typical limit (LIMIT_TUNE_ROIS of its units): what is fastest for
+        # the whole shape (the biggest tile, one round of CUs) is not what is fastest for a fifth of it
+        key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt) + (('lim', m_limit_mul) if m_limit is not None else ()))
         plan = _TUNED.get(key)
         if plan is None:
             if torch.cuda.is_current_stream_capturing() or _lib.lib().srcnn_program_recording():
                 plan = (0, 0, 0, 0, 0)    # never time inside a graph capture / program recording; warm-up runs tune first
             else:
+                if m_limit is not None:
+                    typical = torch.tensor([LIMIT_TUNE_ROIS], dtype=torch.int32, device=x.device)
+                    d.m_limit, d.m_limit_mul = typical.data_ptr(), int(m_limit_mul)
                 plan = _tune(d, key, x.device)
+                d.m_limit, d.m_limit_mul = None, 0
         _set_plan(d, plan)
     if FlopCounter.enabled and FlopCounter.rows is not None:
         FlopCounter.rows[-1]['plan'] = (d.tile_mr, d.tile_nr, d.tile_waves, d.tile_stages, d.splits)
+    if m_limit is not None:
+        assert m_limit.is_cuda and m_limit.dtype == torch.int32 and m_limit_mul > 0
+        d.m_limit, d.m_limit_mul = m_limit.data_ptr(), int(m_limit_mul)
     need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _lib.workspace(need, x.device, "conv")
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")

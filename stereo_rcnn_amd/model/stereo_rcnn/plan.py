@@ -145,12 +145,19 @@ class Plan(object):
         self.h2 = e(R, 2048)
         self.fc = e(R, weights.fc.cout)
         self.cls_prob = e(R, weights.n_cls)
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         self.kp_in = e(R, 2 * P, 2 * P, 256)
-        self.kp_a = e(R, 2 * P, 2 * P, 256)
-        self.kp_b = e(R, 2 * P, 2 * P, 256)
+        # zero-initialised: the lazy keypoint head (kpts_for_kept) computes the leading rows only, and the rows behind them
+        # inside the last computed tile must hold finite numbers (stale results of earlier frames), never allocator garbage
+        self.kp_a = z(R, 2 * P, 2 * P, 256)
+        self.kp_b = z(R, 2 * P, 2 * P, 256)
         G = cfg.KPTS_GRID
-        self.kp_up = e(R, G, G, 256)
-        self.kp_logits = e(R, G, G, 6)
+        self.kp_up = z(R, G, G, 256)
+        self.kp_logits = z(R, G, G, 6)
+        self.kp_rois = z(self.post, 5)                    # the kept detections' rois, in keep order (lazy keypoint head)
+        self.kp_prob = e(self.post, 4 * G)                # its outputs, kept order (the full head writes kpts_prob / left_prob / ...)
+        self.kp_left = e(self.post, G)
+        self.kp_right = e(self.post, G)
         self.kpts_prob = e(R, 4 * G)
         self.left_prob = e(R, G)
         self.right_prob = e(R, G)
@@ -384,7 +391,7 @@ class Plan(object):
                                           self.num_valid.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
                    "srcnn_proposal_layer")
 
-    def _pyramid(self, right, rois, A, out, cstride, coffset):
+    def _pyramid(self, right, rois, A, out, cstride, coffset, n_rois=None):
         maps = [self.p2, self.p3, self.p4, self.p5]
         hw = self.rpn_shapes[:4]
         ptrs = (ctypes.c_void_p * 4)()
@@ -393,7 +400,7 @@ class Plan(object):
             ptrs[l] = maps[l].data_ptr() + (4 * self.B * h * w_ * 256 if right else 0)
         mh = (ctypes.c_int * 4)(*[h for h, _ in hw])
         mw = (ctypes.c_int * 4)(*[w_ for _, w_ in hw])
-        _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, 256, float(self.H), rois.data_ptr(), self.R, A,
+        _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, 256, float(self.H), rois.data_ptr(), self.R if n_rois is None else n_rois, A,
                                                       out.data_ptr(), cstride, coffset, self.fmt, self.fmt,
                                                       _lib.stream()), "srcnn_pyramid_roi_align")
 
@@ -408,27 +415,60 @@ class Plan(object):
         _lib.check(_lib.lib().srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, w.fc.cout,
                                                  self.cls_prob.data_ptr(), _lib.stream()), "srcnn_softmax_rows")
 
-    def kpts_head(self):
-        w, R, f = self.w, self.R, self.fmt
+    def kpts_head(self, rois=None, n_rois=None, limit=None, outs=None):
+        """Keypoint branch (stereo_rcnn.py:260-271).  Default: all R rois of the forward.  rois / n_rois / limit: the lazy form
+        -- `rois` holds n_rois rois of which only the first limit[0] (device int32) matter: every conv of the tower gets the
+        device-side row limit, so the launch list is fixed and no host read-back is needed."""
+        w, f = self.w, self.fmt
+        R = self.R if n_rois is None else n_rois
         P = cfg.POOLING_SIZE
-        self._pyramid(False, self.rois_left, 2 * P, self.kp_in, 256, 0)   # stereo_rcnn.py:260
+        lim = lambda mul: {} if limit is None else {'m_limit': limit, 'm_limit_mul': mul}
+        self._pyramid(False, self.rois_left if rois is None else rois, 2 * P, self.kp_in, 256, 0, n_rois=R)   # stereo_rcnn.py:260
         x = self.kp_in
         s = 2 * P
         g = 'P'                                         # ROIAlign averages pyramid values: the pooled map keeps the pyramid's scale
         for i, cw in enumerate(w.kpts):
             y = self.kp_a if i % 2 == 0 else self.kp_b
-            self._conv(cw, x, R, s, s, y, s, s, g, 'k%d' % i, x_fmt=f, y_fmt=f, name='kpts.%d' % (2 * i))
+            self._conv(cw, x, R, s, s, y, s, s, g, 'k%d' % i, x_fmt=f, y_fmt=f, name='kpts.%d' % (2 * i), **lim(s * s))
             x, g = y, 'k%d' % i
-        self._conv(w.kpts_up, x, R, s, s, self.kp_up, s, s, g, 'kup', x_fmt=f, y_fmt=f, name='kpts.deconv')
+        self._conv(w.kpts_up, x, R, s, s, self.kp_up, s, s, g, 'kup', x_fmt=f, y_fmt=f, name='kpts.deconv', **lim(s * s))
         G = cfg.KPTS_GRID
-        self._conv(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, 'kup', None, x_fmt=f, name='kpts.class')
-        _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, self.kpts_prob.data_ptr(),
-                                              self.left_prob.data_ptr(), self.right_prob.data_ptr(), _lib.stream()),
-                   "srcnn_kpts_tail")
+        self._conv(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, 'kup', None, x_fmt=f, name='kpts.class', **lim(G * G))
+        kp, lp, rp = (self.kpts_prob, self.left_prob, self.right_prob) if outs is None else outs
+        _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, kp.data_ptr(), lp.data_ptr(), rp.data_ptr(),
+                                              _lib.stream()), "srcnn_kpts_tail")
 
-    def heads(self):
-        """Box head (M=300 GEMMs, poor chip fill on their own) runs beside the keypoint tower."""
-        if self.overlap:
+    def kpts_for_kept(self, rois_left_b, keep_idx, num, im_info_b, det_kpts, precision):
+        """The keypoint head for the detections of ONE image that survived class NMS (postprocess.class_nms_device: keep_idx
+        (n) int32, -1 padded; num (1) int32 -- both stay on the device): gathers their rois in keep order, runs the tower with
+        the device-side row limit `num` and writes their decoded keypoints (demo.py:196-209) into their own rows of
+        `det_kpts` (n, 5).  Every roi's keypoint computation is independent of the other rois, so the kept detections get the
+        values the full head gives them up to the engine's own plan-to-plan rounding (the row-limited launches are tuned to
+        other tile / split-K plans, which add the K products in another order: probabilities within ~1e-5 relative, like any
+        two tunings of one layer); rows of the 300 that the reference's scripts never read are skipped."""
+        L = _lib.lib()
+        n = int(keep_idx.shape[0])
+        assert n == self.post and rois_left_b.is_contiguous()
+        prev, engine.PRECISION = engine.PRECISION, precision
+        self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
+        try:
+            _lib.check(L.srcnn_gather_rows(rois_left_b.data_ptr(), keep_idx.data_ptr(), n, 5, self.kp_rois.data_ptr(), _lib.stream()),
+                       "srcnn_gather_rows")
+            self.kpts_head(rois=self.kp_rois, n_rois=n, limit=num if self.fmt else None, outs=(self.kp_prob, self.kp_left, self.kp_right))
+            G = cfg.KPTS_GRID
+            _lib.check(L.srcnn_decode_kept_kpts(rois_left_b.data_ptr(), self.kp_prob.data_ptr(), self.kp_left.data_ptr(),
+                                                self.kp_right.data_ptr(), keep_idx.data_ptr(), num.data_ptr(),
+                                                im_info_b.data_ptr(), n, G, det_kpts.data_ptr(), _lib.stream()),
+                       "srcnn_decode_kept_kpts")
+        finally:
+            engine.PRECISION = prev
+
+    def heads(self, kpts=True):
+        """Box head (M=300 GEMMs, poor chip fill on their own) runs beside the keypoint tower (kpts=False: box head only --
+        the keypoints then come from kpts_for_kept after class NMS)."""
+        if not kpts:
+            self.box_head()
+        elif self.overlap:
             side = self.side[0]
             self._fork(side)
             with torch.cuda.stream(side):
@@ -439,11 +479,11 @@ class Plan(object):
             self.box_head()
             self.kpts_head()
 
-    def launch_all(self):
+    def launch_all(self, kpts=True):
         self.trunk()
         self.fpn_rpn()
         self.proposals()
-        self.heads()
+        self.heads(kpts)
 
     # ------------------------------------------------------------------ driver
     def set_inputs(self, im_left, im_right, im_info):
@@ -472,11 +512,11 @@ class Plan(object):
         self.packed_fmt = fmt
         return scale
 
-    def _record_program(self, precision):
+    def _record_program(self, precision, kpts=True):
         """One pass through launch_all() with the library in record mode: nothing is launched, every kernel launch / memset /
         stream dependency lands in a native list that srcnn_program_run re-issues (include/srcnn_hip.h)."""
         L = _lib.lib()
-        self.launch_all()                     # warm-up: tunes the plans, sizes every workspace, splits the weights
+        self.launch_all(kpts)                 # warm-up: tunes the plans, sizes every workspace, splits the weights
         torch.cuda.synchronize()
         prog = L.srcnn_program_create()
         refs = []
@@ -484,15 +524,15 @@ class Plan(object):
         _lib.check(L.srcnn_program_begin(prog, torch.cuda.current_stream().cuda_stream), "srcnn_program_begin")
         self._rec = prog
         try:
-            self.launch_all()
+            self.launch_all(kpts)
         finally:
             self._rec = None
             _lib._recording_refs = None
             _lib.check(L.srcnn_program_end(prog), "srcnn_program_end")
-        self.programs[precision] = (prog, refs)
+        self.programs[(precision, kpts) if not kpts else precision] = (prog, refs)
         return prog
 
-    def run(self, use_graph=False, precision='f32', use_program=False):
+    def run(self, use_graph=False, precision='f32', use_program=False, kpts=True):
         """precision: 'f32' (exact fp32 MFMA engine) or 'f16x3' (3-term split on the f16 MFMA).
         use_program: replay the forward from the native launch list (recorded on first use) instead of walking the Python
         launch code -- same launches, same streams, same results."""
@@ -513,12 +553,12 @@ class Plan(object):
         try:
             if use_program and not use_graph:
                 self.packed_fmt = -1                  # the recorded list always contains the stem_pack launches
-                ent = self.programs.get(precision)
-                prog = ent[0] if ent else self._record_program(precision)
+                ent = self.programs.get((precision, kpts) if not kpts else precision)
+                prog = ent[0] if ent else self._record_program(precision, kpts)
                 _lib.check(_lib.lib().srcnn_program_run(prog, torch.cuda.current_stream().cuda_stream), "srcnn_program_run")
                 return
-            if not use_graph:
-                self.launch_all()
+            if not use_graph or not kpts:
+                self.launch_all(kpts)
                 return
             self.packed_fmt = -1                  # a captured graph always contains the stem_pack launches
             if precision not in self.graphs:
@@ -540,7 +580,7 @@ class Plan(object):
         k = self._buf_shift.get(buf.data_ptr(), 0)
         return y * (2.0 ** -k) if k else y
 
-    def outputs(self):
+    def outputs(self, kpts=True):
         """The forward's results as tensors the caller owns.  After an eager run the result buffers themselves are
         handed over and replaced by fresh allocations (no copy kernels); a captured graph writes to fixed addresses,
         so once a graph exists the results are cloned instead."""
@@ -548,6 +588,11 @@ class Plan(object):
         fc = self.fc.view(B, self.post, -1)
         bbox_pred = fc[:, :, :w.n_bbox].contiguous()
         dim_orien = fc[:, :, w.n_bbox:w.n_bbox + w.n_dim].contiguous()
+        if not kpts:        # lazy keypoint head: the three keypoint outputs do not exist for this forward
+            res = {'rois_left': self.rois_left.clone(), 'rois_right': self.rois_right.clone(),
+                   'cls_prob': self.cls_prob.view(B, self.post, -1).clone(), 'bbox_pred': bbox_pred, 'dim_orien_pred': dim_orien,
+                   'kpts_prob': None, 'left_border_prob': None, 'right_border_prob': None}
+            return res
         if self.graphs or self.programs:
             return {
                 'rois_left': self.rois_left.clone(), 'rois_right': self.rois_right.clone(),

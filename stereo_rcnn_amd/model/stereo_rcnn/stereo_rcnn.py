@@ -134,19 +134,22 @@ class _StereoRCNN(nn.Module):
         return engine.nhwc_to_nchw(out)
 
     def forward(self, im_left_data, im_right_data, im_info, gt_boxes_left=None, gt_boxes_right=None,
-                gt_boxes_merge=None, gt_dim_orien=None, gt_kpts=None, num_boxes=None, slot=0):
+                gt_boxes_merge=None, gt_dim_orien=None, gt_kpts=None, num_boxes=None, slot=0, kpts=True):
         """Reference signature and 15-tuple return (stereo_rcnn.py:141-142,322-324).
         The gt_* / num_boxes arguments are accepted and ignored exactly as in eval mode.
         `slot` (extension): independent buffer set, so that several pairs can be in flight on different HIP
-        streams (each stream uses its own slot)."""
+        streams (each stream uses its own slot).
+        `kpts=False` (extension, stereo_rcnn_amd.pipeline): leave the keypoint branch out of the forward -- the three keypoint
+        outputs are None -- because the caller will run it on the detections that survive class NMS only
+        (plan.Plan.kpts_for_kept; the reference's scripts read no other row: demo.py:196-257)."""
         if self.training:
             raise NotImplementedError("training forward is out of scope; call .eval()")
         B, _, H, W = im_left_data.shape
         plan = self._get_plan(int(B), int(H), int(W), slot)
         plan.set_inputs(im_left_data, im_right_data, im_info)
-        return self._run(plan)
+        return self._run(plan, kpts)
 
-    def forward_images(self, img_left_u8, img_right_u8, target_short=None, slot=0):
+    def forward_images(self, img_left_u8, img_right_u8, target_short=None, slot=0, kpts=True):
         """Extension: the reference's preprocessing (demo.py:103-129) fused in front of the forward.  uint8 RGB
         (H, W, 3) DEVICE images -> (the forward's 15-tuple, im_left_data, im_right_data, im_info); the network-input planes
         and the stem's packed input are produced in one pass per eye, the float32 planes are returned because the dense
@@ -158,7 +161,7 @@ class _StereoRCNN(nn.Module):
         OH, OW, _ = engine.preprocess_size(H0, W0, short)
         plan = self._get_plan(1, OH, OW, slot)
         plan.set_images(img_left_u8, img_right_u8, self.precision, short)
-        return self._run(plan), plan.im_left, plan.im_right, plan.im_info
+        return self._run(plan, kpts), plan.im_left, plan.im_right, plan.im_info
 
     def calibrate_activation_scales(self, frames, slot=0):
         """Extension: choose the SPLIT16 engine's per-tensor power-of-two activation scales (plan.Plan.calibrate) from SEVERAL
@@ -184,9 +187,9 @@ class _StereoRCNN(nn.Module):
         if flag:
             raise engine.Split16RangeError('SPLIT16 range exceeded in %s' % name)
 
-    def _run(self, plan):
-        plan.run(self.use_graph, self.precision, getattr(self, 'use_program', False))
-        o = plan.outputs()
+    def _run(self, plan, kpts=True):
+        plan.run(self.use_graph, self.precision, getattr(self, 'use_program', False), kpts=kpts)
+        o = plan.outputs(kpts)
         self.RCNN_loss_cls = 0
         self.RCNN_loss_bbox = 0
         rpn_loss_cls, rpn_loss_bbox_left_right = 0, 0

@@ -16,7 +16,6 @@ Newton-CG restated in double precision (csrc/box_solver.h), one source built for
   solver='scipy'           the reference's own arrangement (host numpy `infer_boundary`, scipy solves, optionally fanned
                            out to a process pool) as the comparison path: model/utils/box_estimator.py, kitti_utils.py."""
 import collections
-import ctypes
 import math as m
 
 import numpy as np
@@ -156,17 +155,34 @@ def _stage(n, dev, slot):
     return _stages[key]
 
 
+# Keypoint branch on the detections that survive class NMS only (Plan.kpts_for_kept) instead of on all 300 rois inside the
+# forward: the flows below read no other row (nor do the reference's scripts, demo.py:196-257), every roi's keypoints are
+# computed independently of the other rois, and the device-side keep count bounds the tower's launches without a host
+# read-back.  The kept detections get the full head's values up to the engine's plan-to-plan rounding (~1e-5 relative on
+# the probabilities: the row-limited launches are tuned to their own tile / split-K plans).  Off: the forward computes the
+# branch for every roi, as `_StereoRCNN.forward` does by default.
+import os as _os
+LAZY_KPTS = _os.environ.get('SRCNN_LAZY_KPTS', '1') != '0'
+
+
+def _lazy(model):
+    return LAZY_KPTS and model.precision == 'f16x3' and not model.use_graph
+
+
 def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape, eval_thresh=0.05, class_index=1,
-              dense_align=True, slot=0, solver='device'):
+              dense_align=True, slot=0, solver='device', lazy=None):
     """Everything after the forward, asynchronously on the current stream.  out: the forward's tuple; scale: im_info[0, 2] as a
     Python float (passing it spares a device read).  Returns a handle for collect_3d().
     solver='host': only class NMS, record and borders are launched here; the two Newton-CG solves then run on the HOST (the
     same row functions built for the host, bit-identical to the reference's scipy path) in step_3d() / collect_3d(), with
-    the dense alignment on the device in between."""
+    the dense alignment on the device in between.
+    lazy=(plan, precision): `out` comes from forward(kpts=False); the keypoint branch runs here, on the kept detections."""
     L = _lib.lib()
     det = postprocess.decode_detections(*out[:8], im_info)
     keep_idx, num = postprocess.class_nms_device(det, class_index, eval_thresh, cfg.TEST.NMS)
     n = int(keep_idx.shape[0])
+    if lazy is not None:
+        lazy[0].kpts_for_kept(out[0][0].contiguous(), keep_idx, num, im_info.view(-1, 3)[0:1].contiguous().float(), det['kpts'], lazy[1])
     assert int(im_shape[1]) <= 4095, "image wider than the 3-D stage's column buffer"
     st = _stage(n, keep_idx.device, slot)
     from . import distributed as sdist
@@ -288,8 +304,13 @@ def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shap
                      native=False):
     k4, k3 = (14, 13) if native else (4, 3)
     with torch.no_grad():
-        out = model(im_left_data, im_right_data, im_info)
+        lazy = _lazy(model)                   # the same form of the keypoint branch as the record flows (see LAZY_KPTS)
+        out = model(im_left_data, im_right_data, im_info, kpts=not lazy)
         det = postprocess.decode_detections(*out[:8], im_info)
+        if lazy:
+            keep_idx, num = postprocess.class_nms_device(det, class_index, eval_thresh, cfg.TEST.NMS)
+            plan, precision = _plan_of(model, im_left_data, 0)
+            plan.kpts_for_kept(out[0][0].contiguous(), keep_idx, num, im_info.view(-1, 3)[0:1].contiguous(), det['kpts'], precision)
         cls = postprocess.class_detections(det, class_index, eval_thresh, cfg.TEST.NMS)
     dets_left = cls['dets_left'].cpu().numpy()
     if dets_left.shape[0] == 0:
@@ -355,9 +376,10 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
                                 dense_align, pool if solver == 'scipy' else None, native=(solver == 'host_py'))
     from . import engine
     with torch.no_grad():
-        out = model(im_left_data, im_right_data, im_info, slot=slot)
+        lazy = _lazy(model)
+        out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy)
         st = launch_3d(out, im_left_data, im_right_data, im_info, _scale32(im_info), calib, im_shape, eval_thresh,
-                       class_index, dense_align, slot, solver)
+                       class_index, dense_align, slot, solver, lazy=_plan_of(model, im_left_data, slot) if lazy else None)
     try:
         return collect_3d(st)
     except engine.Split16RangeError:
@@ -372,17 +394,23 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
             model.precision = prev
 
 
+def _plan_of(model, im_left_data, slot):
+    B, _, H, W = im_left_data.shape
+    return model._get_plan(int(B), int(H), int(W), slot), model.precision
+
+
 def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, class_index=1, dense_align=True, slot=0,
                      wait=True, solver='host'):
     """The same from the decoded uint8 RGB images on the device: preprocessing fused in front of the forward
     (model.forward_images), then the device 3-D flow.  wait=False returns the handle for collect_3d()."""
     with torch.no_grad():
-        out, iml, imr, info = model.forward_images(img_left_u8, img_right_u8, slot=slot)
+        lazy = _lazy(model)
+        out, iml, imr, info = model.forward_images(img_left_u8, img_right_u8, slot=slot, kpts=not lazy)
         from . import engine
         scale = float(np.float32(engine.preprocess_size(int(img_left_u8.shape[0]), int(img_left_u8.shape[1]),
                                                         cfg.TEST.SCALES[0])[2]))
         st = launch_3d(out, iml, imr, info, scale, calib, tuple(img_left_u8.shape), eval_thresh, class_index, dense_align, slot,
-                       solver)
+                       solver, lazy=_plan_of(model, iml, slot) if lazy else None)
     return collect_3d(st) if wait else st
 
 
@@ -390,6 +418,8 @@ def image_outputs(out, b):
     """The forward's outputs of image b of a batch as a batch of one (what launch_3d / decode take): the roi-major head
     outputs (kpts / border probabilities) are rows [b * n, (b + 1) * n)."""
     n = int(out[0].shape[1])
+    if out[5] is None:          # forward(kpts=False)
+        return (out[0][b:b + 1], out[1][b:b + 1], out[2][b:b + 1], out[3][b:b + 1], out[4][b:b + 1], None, None, None)
     return (out[0][b:b + 1], out[1][b:b + 1], out[2][b:b + 1], out[3][b:b + 1], out[4][b:b + 1],
             out[5][b * n:(b + 1) * n], out[6][b * n:(b + 1) * n], out[7][b * n:(b + 1) * n])
 
@@ -401,13 +431,15 @@ def launch_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shap
     current stream, each with its own stage buffers.  Returns the handles for collect_3d_batch()."""
     B = int(im_left_data.shape[0])
     with torch.no_grad():
-        out = model(im_left_data, im_right_data, im_info, slot=slot)
+        lazy = _lazy(model)
+        out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy)
+        pl = _plan_of(model, im_left_data, slot) if lazy else None
         handles = []
         for b in range(B):
             info_b = im_info.view(-1, 3)[b:b + 1]
             handles.append(launch_3d(image_outputs(out, b), im_left_data[b:b + 1], im_right_data[b:b + 1], info_b,
                                      _scale32(info_b), calibs[b], im_shapes[b], eval_thresh, class_index, dense_align,
-                                     (slot, b), solver))
+                                     (slot, b), solver, lazy=pl))
     return handles
 
 
@@ -499,8 +531,10 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
             else:
                 l, r, info, calib, im_shape = frame[:5]
                 scale = float(np.float32(frame[5])) if len(frame) > 5 else _scale32(info)
-                out = model(l, r, info, slot=slot)
-                st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot, solver)
+                lazy = _lazy(model)
+                out = model(l, r, info, slot=slot, kpts=not lazy)
+                st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot, solver,
+                               lazy=_plan_of(model, l, slot) if lazy else None)
         for older, _ in inflight:                              # solver='host': one host phase of every pair already in flight
             step_3d(older)
         inflight.append((st, frame))

@@ -22,7 +22,10 @@ def decode_detections(rois_left, rois_right, cls_prob, bbox_pred, dim_orien_pred
     G = cfg.KPTS_GRID
     f = lambda t: t.contiguous().float()
     rl, rr, bp, dp = f(rois_left[0]), f(rois_right[0]), f(bbox_pred[0]), f(dim_orien_pred[0])
-    kp, lp, rp = f(kpts_prob), f(left_border_prob), f(right_border_prob)
+    if kpts_prob is None:      # lazy keypoint head (pipeline): the `kpts` rows of the kept detections are filled in after class NMS
+        kp, lp, rp = _zero_probs(n, G, dev)
+    else:
+        kp, lp, rp = f(kpts_prob), f(left_border_prob), f(right_border_prob)
     info = f(im_info.view(-1, 3)[0].to(dev))
     boxes_l = torch.empty((n, 4 * n_cls), device=dev)
     boxes_r = torch.empty((n, 4 * n_cls), device=dev)
@@ -34,6 +37,16 @@ def decode_detections(rois_left, rois_right, cls_prob, bbox_pred, dim_orien_pred
                                                   dim.data_ptr(), kpts.data_ptr(), _lib.stream()),
                "srcnn_decode_detections")
     return {'scores': f(cls_prob[0]), 'boxes_left': boxes_l, 'boxes_right': boxes_r, 'dim_orien': dim, 'kpts': kpts}
+
+
+_zeros = {}
+
+
+def _zero_probs(n, G, dev):
+    key = (n, G, str(dev))
+    if key not in _zeros:
+        _zeros[key] = (torch.zeros((n, 4 * G), device=dev), torch.zeros((n, G), device=dev), torch.zeros((n, G), device=dev))
+    return _zeros[key]
 
 
 def class_nms_device(det, j=1, thresh=0.05, nms_thresh=None):

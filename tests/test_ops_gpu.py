@@ -218,6 +218,36 @@ def test_conv_f16s_every_plan(dev, plan, case):
         engine._TUNED, engine.AUTOTUNE = saved_tuned, saved_flag
 
 
+@pytest.mark.parametrize("plans", [
+    [(2, 2, 4, 2, 1), (4, 2, 8, 3, 1), (4, 4, 8, 2, 1)],                       # per-wave tile >= 2x2: one accumulator chain
+    [(2, 1, 4, 2, 1), (2, 1, 4, 3, 1), (1, 2, 4, 3, 1), (2, 2, 8, 2, 1), (2, 2, 8, 4, 1)],   # two chains
+    [(1, 1, 4, 2, 1), (1, 1, 4, 4, 1)],                                         # three chains
+])
+def test_conv_f16s_plans_of_one_order_class_give_the_same_bits(dev, plans):
+    """Without split-K, the tile plans of the SPLIT16 kernel whose waves keep the three split products of a K step in the
+    same number of accumulator chains add a row's products in the same order: such a plan changes WHICH workgroup computes
+    a row, not its bits -- and a device-side row limit never changes the bits of the rows it leaves.  (Across classes, and
+    with split-K, results differ in the last bits: the plan-to-plan rounding the lazy keypoint head's tolerance refers to.)"""
+    from stereo_rcnn_amd import engine
+    g = torch.Generator().manual_seed(5)
+    B, H, W, cin, cout = 3, 14, 28, 256, 256
+    x = torch.randn(B, H, W, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 48.0
+    cw = engine.prep_conv(w, torch.randn(cout, generator=g), 1, 1, True, device=dev)
+    xs = engine.act_convert(x, 0, 1)
+    lim = torch.tensor([1], dtype=torch.int32, device=dev)
+    first = None
+    for plan in plans:
+        y = torch.zeros((B, H, W, cout), device=dev)
+        engine.conv2d(cw, xs, B, H, W, y, H, W, precision='f16x3', x_fmt=1, y_fmt=1, plan=plan)
+        z = torch.zeros((B, H, W, cout), device=dev)
+        engine.conv2d(cw, xs, B, H, W, z, H, W, precision='f16x3', x_fmt=1, y_fmt=1, plan=plan, m_limit=lim, m_limit_mul=H * W)
+        y, z = y.view(torch.int32).cpu(), z.view(torch.int32).cpu()
+        assert torch.equal(z[0], y[0]), plan                 # the row-limited launch: same bits for the rows it computes
+        first = y if first is None else first
+        assert torch.equal(y, first), plan
+
+
 @pytest.mark.parametrize("precision,W", [('f32', 131), ('f16x3', 131), ('f16x3+split16', 131), ('f16x3+split16', 130)])
 def test_conv_stem_vs_torch_cpu(dev, precision, W):
     """7x7/2 stem through the packed NHWC4 image; '+split16' = the packed image in SPLIT16 form read by the DMA engine
@@ -498,3 +528,95 @@ def test_conv_mode2_pair_concat_equals_two_launches(dev, plan, B, H, W):
     torch.cuda.synchronize()
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
     assert float(engine.act_convert(got, S, 0)[..., :2 * N].abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("plan", [(2, 2, 4, 2, 1), (4, 4, 8, 2, 1), (1, 1, 4, 4, 3), (2, 1, 4, 3, 2)])
+@pytest.mark.parametrize("keep", [0, 1, 5, 37])
+def test_conv_device_side_row_limit(dev, plan, keep):
+    """srcnn_conv_desc.m_limit: only rows m < *m_limit * m_limit_mul are needed.  The rows below the limit equal the unlimited
+    launch bit for bit; tiles that lie wholly beyond it are not touched (sentinel survives), also through the split-K
+    reduction; a limit of 0 launches nothing but exits."""
+    from stereo_rcnn_amd import _lib, engine
+    g = torch.Generator().manual_seed(3)
+    S = _lib.FMT_SPLIT16
+    R, s, C = 64, 14, 64
+    cw = engine.prep_conv(torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5, torch.randn(C, generator=g), 1, 1, True, None, dev)
+    x = engine.act_convert(torch.randn(R, s, s, C, generator=g).to(dev), 0, S)
+    full = torch.empty(R, s, s, C, device=dev)
+    engine.conv2d(cw, x, R, s, s, full, s, s, precision='f16x3', x_fmt=S, y_fmt=S, plan=plan)
+    sentinel = 12345.0
+    lim = torch.tensor([keep], dtype=torch.int32, device=dev)
+    got = engine.act_convert(torch.full((R, s, s, C), sentinel, device=dev), 0, S)
+    engine.conv2d(cw, x, R, s, s, got, s, s, precision='f16x3', x_fmt=S, y_fmt=S, plan=plan, m_limit=lim, m_limit_mul=s * s)
+    torch.cuda.synchronize()
+    rows = keep * s * s
+    a, b = got.view(-1, C).view(torch.int32), full.view(-1, C).view(torch.int32)
+    assert torch.equal(a[:rows], b[:rows])
+    bm = 64 * plan[0]
+    first_untouched = -(-rows // bm) * bm if rows else 0
+    tail = engine.act_convert(got, S, 0).view(-1, C)[first_untouched:]
+    assert tail.numel() == 0 or bool((tail == sentinel).all())
+
+
+def test_gather_rows_and_decode_kept_kpts_vs_full_decode(dev):
+    """srcnn_gather_rows / srcnn_decode_kept_kpts: the keypoint part of the decode for a keep list, fed with probabilities in
+    KEPT order, writes exactly the rows the full decode writes for those rois and leaves the other rows alone."""
+    from stereo_rcnn_amd import _lib
+    from stereo_rcnn_amd import postprocess as hpost
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    n, G = 300, 28
+    rois = torch.rand(1, n, 5, generator=g) * 300
+    rois[:, :, 3:] += rois[:, :, 1:3] + 8
+    rois[:, :, 0] = 0
+    rois_r = rois.clone()
+    cls = torch.rand(1, n, 2, generator=g)
+    bp, dp = torch.randn(1, n, 12, generator=g) * 0.1, torch.randn(1, n, 10, generator=g)
+    kp, lp, rp = torch.rand(n, 4 * G, generator=g), torch.rand(n, G, generator=g), torch.rand(n, G, generator=g)
+    info = torch.tensor([[192.0, 640.0, 1.6]])
+    t = lambda v: v.to(dev)
+    det = hpost.decode_detections(t(rois), t(rois_r), t(cls), t(bp), t(dp), t(kp), t(lp), t(rp), t(info))
+    keep = torch.tensor([7, 299, 0, 42, 13] + [-1] * (n - 5), dtype=torch.int32, device=dev)
+    num = torch.tensor([5], dtype=torch.int32, device=dev)
+    gathered = torch.empty(n, 5, device=dev)
+    _lib.check(L.srcnn_gather_rows(t(rois)[0].contiguous().data_ptr(), keep.data_ptr(), n, 5, gathered.data_ptr(), _lib.stream()))
+    assert torch.equal(gathered[:5].cpu(), rois[0][[7, 299, 0, 42, 13]]) and torch.equal(gathered[5:].cpu(), rois[0][[0] * (n - 5)])
+    idx = keep[:5].long()
+    out = torch.full((n, 5), -7.0, device=dev)
+    kk, ll, rr = torch.zeros(n, 4 * G, device=dev), torch.zeros(n, G, device=dev), torch.zeros(n, G, device=dev)
+    kk[:5], ll[:5], rr[:5] = t(kp)[idx], t(lp)[idx], t(rp)[idx]
+    rl = t(rois)[0].contiguous()
+    _lib.check(L.srcnn_decode_kept_kpts(rl.data_ptr(), kk.data_ptr(), ll.data_ptr(), rr.data_ptr(), keep.data_ptr(), num.data_ptr(),
+                                        t(info).data_ptr(), n, G, out.data_ptr(), _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out[idx], det['kpts'][idx])
+    mask = torch.ones(n, dtype=torch.bool, device=dev)
+    mask[idx] = False
+    assert bool((out[mask] == -7.0).all())
+
+
+def test_conv_row_limit_never_reads_rows_beyond_it(dev):
+    """Rows beyond the device-side limit inside the last computed tile must not be READ: they may hold another format's bits
+    (a buffer last written by the fp32 engine) -- NaNs here.  The rows below the limit still equal the unlimited launch on clean
+    input and the range guard stays clear."""
+    from stereo_rcnn_amd import _lib, engine
+    g = torch.Generator().manual_seed(4)
+    S = _lib.FMT_SPLIT16
+    R, s, C, keep = 8, 14, 64, 3
+    cw = engine.prep_conv(torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5, torch.randn(C, generator=g), 1, 1, True, None, dev)
+    clean = torch.randn(R, s, s, C, generator=g).to(dev)
+    xs = engine.act_convert(clean, 0, S)
+    want = torch.empty(R, s, s, C, device=dev)
+    engine.conv2d(cw, xs, R, s, s, want, s, s, precision='f16x3', x_fmt=S, y_fmt=S, plan=(4, 2, 8, 3, 1))
+    poisoned = xs.clone()
+    poisoned.view(R, -1)[keep:] = float('nan')                    # NaN bit patterns in every 16-bit half of the rows beyond
+    got = torch.zeros(R, s, s, C, device=dev)
+    lim = torch.tensor([keep], dtype=torch.int32, device=dev)
+    engine.range_flag(reset=True)
+    engine.conv2d(cw, poisoned, R, s, s, got, s, s, precision='f16x3', x_fmt=S, y_fmt=S, plan=(4, 2, 8, 3, 1), m_limit=lim,
+                  m_limit_mul=s * s, name='limit.poison')
+    torch.cuda.synchronize()
+    assert engine.range_flag(reset=True) == (0, None)
+    rows = keep * s * s
+    assert torch.equal(got.view(-1, C).view(torch.int32)[:rows], want.view(-1, C).view(torch.int32)[:rows])
+    assert torch.isfinite(engine.act_convert(got, S, 0)).all()
