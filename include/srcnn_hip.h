@@ -85,11 +85,12 @@ SRCNN_API int roi_align_forward_cuda(int aligned_height, int aligned_width, floa
 /* Fused PyramidRoI_Feat (stereo_rcnn.py:110-139) = level routing (natural log, round half away)
  * + RoIAlignAvg (modules/roi_align.py:26-29: (A+1)^2 lattice, then 2x2/s1 avg-pool), NHWC maps.
  * maps[l] is the level-(l+2) map (B, mh[l], mw[l], C) NHWC.  out is (n, A, A, out_cstride) NHWC and
- * channels [out_coffset, out_coffset+C) are written (lets left|right be concatenated in place). */
+ * channels [out_coffset, out_coffset+C) are written (lets left|right be concatenated in place).
+ * roi_limit: NULL, or a device int -- only rois [0, *roi_limit) are pooled (the keypoint head on the kept detections). */
 SRCNN_API int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, const int *mw_host,
                             int channels, float im_height, const float *rois, int num_rois, int A,
                             float *out, int out_cstride, int out_coffset, int maps_format, int out_format,
-                            srcnn_stream_t stream);
+                            const int *roi_limit, srcnn_stream_t stream);
 /* format conversion of an NHWC activation tensor (pixels x C): F32 <-> SPLIT16 (API edge / tests) */
 SRCNN_API int srcnn_act_convert(const void *x, int x_format, void *y, int y_format, long long pixels, int C,
                       srcnn_stream_t stream);
@@ -218,9 +219,9 @@ SRCNN_API int srcnn_proposal_layer(const float *probs, const float *deltas, int 
  * cls softmax over n_cls logits (stereo_rcnn.py:257). */
 SRCNN_API int srcnn_softmax_rows(const float *x, int rows, int cols, int x_stride, float *y, srcnn_stream_t stream);
 /* keypoint tail (stereo_rcnn.py:262-271): logits (n, G, G, 6) NHWC from kpts_class ->
- * sum over H, softmax over 4*G (kpts) and G (left/right borders). */
+ * sum over H, softmax over 4*G (kpts) and G (left/right borders).  roi_limit: NULL, or a device int -- rows [0, *roi_limit) only. */
 SRCNN_API int srcnn_kpts_tail(const float *logits, int n, int G, float *kpts_prob, float *left_prob, float *right_prob,
-                    srcnn_stream_t stream);
+                    const int *roi_limit, srcnn_stream_t stream);
 /* detection decode (demo.py:144-218, bbox_transform.py:133-155) for B == 1 blocks of n rois. */
 /* Keypoint head on the kept detections only ("lazy" form of stereo_rcnn.py:260-271 + demo.py:196-209: the reference computes the
  * keypoint branch for all 300 rois and its scripts then read the rows that survive score threshold + NMS; every roi's

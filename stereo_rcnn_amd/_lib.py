@@ -49,7 +49,7 @@ _SIGNATURES = {
                                        c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_pyramid_roi_align": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                         c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
-                                        c_void_p]),
+                                        c_void_p, c_void_p]),
     "srcnn_act_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
     "srcnn_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_decode_kept_kpts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
@@ -73,7 +73,7 @@ _SIGNATURES = {
                                      c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
     "srcnn_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "srcnn_kpts_tail": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srcnn_kpts_tail": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srcnn_decode_detections": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
     "srcnn_class_nms_workspace_bytes": (c_size_t, [c_int]),
     "srcnn_class_nms": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p,

@@ -21,6 +21,7 @@ struct ConvArgs {
     int KH, KW, stride, pad;
     int ycs, yco, rcs, relu, mode;
     int tap_inner;                // SPLIT16 engine, KH*KW > 1: K runs (channel tile, tap) instead of (tap, channel tile)
+    int m_fast;                   // SPLIT16 engine: consecutive workgroups walk the M tiles of one N tile (weights > activations)
     int M, K;
     int ctiles;       // Cin / 32
     int nkt;          // K tiles in total

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         st0 = __builtin_readcyclecounter();
         rt0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz, common to the whole chip
     }
-    int nblk = p.mtiles * p.ntiles;
+    int mtiles = p.mtiles, nblk = p.mtiles * p.ntiles;
     const int bid = blockIdx.x;
     int m_rows = p.M;                                         // rows whose INPUT is read: beyond, the A operand is zeros
     if (p.m_limit) {
@@ -127,13 +127,17 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         // the whole grid, the limited rows (the first logical tiles) would all be XCD 0's share and run on 32 CUs.
         const int lim = max(__builtin_amdgcn_readfirstlane(*p.m_limit), 0) * p.m_limit_mul;
         m_rows = min(m_rows, lim);
-        nblk = ((m_rows + BM - 1) / BM) * p.ntiles;
+        mtiles = (m_rows + BM - 1) / BM;
+        nblk = mtiles * p.ntiles;
         if (bid >= nblk) return;
     }
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, slot = bid >> 3;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int mt = logical / p.ntiles, nt = logical - mt * p.ntiles;
+    // consecutive logical tiles (one XCD's share) walk N inside an M tile -- they share the activation rows -- or, for the
+    // fully connected shapes, M inside an N tile: they share the weight slab
+    const int mt = p.m_fast ? logical % mtiles : logical / p.ntiles;
+    const int nt = p.m_fast ? logical / mtiles : logical - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int kt_begin = blockIdx.y * p.kt_per_split;
     const int kt_end = min(p.nkt, kt_begin + p.kt_per_split);

@@ -374,6 +374,12 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     const long long M = (long long)d->B * d->OH * d->OW;
     SRCNN_REQUIRE(M < (1LL << 31) && (long long)d->B * d->H * d->W < (1LL << 31), "tensor too large");
     a.M = (int)M;
+    {
+        // fully connected shapes (fewer rows than output channels): the weights are the big operand, so consecutive workgroups
+        // -- one XCD's share, running at the same time -- take the few M tiles of ONE weight slab, which then comes from HBM once
+        static const int m_fast_default = [] { const char *e = std::getenv("SRCNN_M_FAST"); return e ? std::atoi(e) : 1; }();   // A/B switch
+        a.m_fast = (m_fast_default && a.M < d->Cout) ? 1 : 0;
+    }
     a.K = d->KH * d->KW * d->Cin;
     a.ctiles = d->Cin / BK;
     a.nkt = a.K / BK;

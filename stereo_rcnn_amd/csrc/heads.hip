@@ -24,11 +24,12 @@ __global__ void softmax_rows_kernel(const float *__restrict__ x, int rows, int c
 // one block per roi; logits (n, G, G, 6) NHWC.  G <= 32.
 __global__ __launch_bounds__(256) void kpts_tail_kernel(const float *__restrict__ logits, int G,
                                                         float *__restrict__ kpts_prob, float *__restrict__ left_prob,
-                                                        float *__restrict__ right_prob)
+                                                        float *__restrict__ right_prob, const int *__restrict__ roi_limit)
 {
     __shared__ float col[6][32];
     __shared__ float red[3][2];   // {max, sum} for kpts / left / right
     const int n = blockIdx.x, tid = threadIdx.x;
+    if (roi_limit && n >= *roi_limit) return;
     const float *lg = logits + (size_t)n * G * G * 6;
     if (tid < G * 6) {
         const int w = tid / 6, ch = tid - w * 6;
@@ -300,13 +301,13 @@ int srcnn_softmax_rows(const float *x, int rows, int cols, int x_stride, float *
 }
 
 int srcnn_kpts_tail(const float *logits, int n, int G, float *kpts_prob, float *left_prob, float *right_prob,
-                    srcnn_stream_t stream)
+                    const int *roi_limit, srcnn_stream_t stream)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(logits && kpts_prob && left_prob && right_prob && G > 0 && G <= 32, "bad args");
     if (n == 0) return SRCNN_OK;
     SRCNN_LAUNCH(kpts_tail_kernel, dim3(n), dim3(256), 0, as_stream(stream), logits, G, kpts_prob, left_prob,
-                       right_prob);
+                       right_prob, roi_limit);
     return check_launch("srcnn_kpts_tail");
 }
 

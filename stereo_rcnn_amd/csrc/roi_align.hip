@@ -85,6 +85,7 @@ struct PyramidArgs {
     const float *maps[4];
     int mh[4], mw[4];
     float scale[4];
+    const int *roi_limit;        // device-side count of the rois that matter (blocks of later rois exit) or nullptr
 };
 
 // grid (A, n); block = C threads (C multiple of 64, <= 1024). One output row per block.
@@ -93,6 +94,7 @@ __global__ void pyramid_roi_align_kernel(PyramidArgs pa, int channels, const flo
                                          float *__restrict__ out, int out_cstride, int out_coffset, int mfmt, int ofmt)
 {
     const int n = blockIdx.y, py = blockIdx.x, c = threadIdx.x;
+    if (pa.roi_limit && n >= *pa.roi_limit) return;
     const float *r = rois + (size_t)n * 5;
     // level routing, stereo_rcnn.py:113-119 (natural log; round half away from zero; clamp 2..5)
     float bh = r[4] - r[2] + 1.0f;
@@ -162,7 +164,7 @@ __global__ void pyramid_roi_align8_kernel(PyramidArgs pa, int channels, const fl
                                           float *__restrict__ out, int out_cstride, int out_coffset, int mfmt, int ofmt)
 {
     const int n = blockIdx.y, py = blockIdx.x * blockDim.y + threadIdx.y, g = threadIdx.x;
-    if (py >= A) return;
+    if (py >= A || (pa.roi_limit && n >= *pa.roi_limit)) return;
     const float *r = rois + (size_t)n * 5;
     // level routing, stereo_rcnn.py:113-119 (natural log; round half away from zero; clamp 2..5)
     float bh = r[4] - r[2] + 1.0f;
@@ -228,7 +230,7 @@ int roi_align_forward_cuda(int aligned_height, int aligned_width, float spatial_
 
 int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, const int *mw_host, int channels,
                             float im_height, const float *rois, int num_rois, int A, float *out, int out_cstride,
-                            int out_coffset, int maps_format, int out_format, srcnn_stream_t stream)
+                            int out_coffset, int maps_format, int out_format, const int *roi_limit, srcnn_stream_t stream)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(channels % 64 == 0 && channels <= 1024, "channels must be a multiple of 64, <= 1024");
@@ -237,6 +239,7 @@ int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, c
     if (out_format == 1) SRCNN_REQUIRE(out_cstride % 8 == 0 && out_coffset % 8 == 0, "SPLIT16 output alignment");
     if (num_rois == 0) return SRCNN_OK;
     PyramidArgs pa;
+    pa.roi_limit = roi_limit;
     for (int l = 0; l < 4; ++l) {
         pa.maps[l] = maps_host[l];
         pa.mh[l] = mh_host[l];

@@ -391,7 +391,7 @@ class Plan(object):
                                           self.num_valid.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
                    "srcnn_proposal_layer")
 
-    def _pyramid(self, right, rois, A, out, cstride, coffset, n_rois=None):
+    def _pyramid(self, right, rois, A, out, cstride, coffset, n_rois=None, limit=None):
         maps = [self.p2, self.p3, self.p4, self.p5]
         hw = self.rpn_shapes[:4]
         ptrs = (ctypes.c_void_p * 4)()
@@ -402,7 +402,7 @@ class Plan(object):
         mw = (ctypes.c_int * 4)(*[w_ for _, w_ in hw])
         _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, 256, float(self.H), rois.data_ptr(), self.R if n_rois is None else n_rois, A,
                                                       out.data_ptr(), cstride, coffset, self.fmt, self.fmt,
-                                                      _lib.stream()), "srcnn_pyramid_roi_align")
+                                                      None if limit is None else limit.data_ptr(), _lib.stream()), "srcnn_pyramid_roi_align")
 
     def box_head(self):
         w, R, f = self.w, self.R, self.fmt
@@ -423,7 +423,7 @@ class Plan(object):
         R = self.R if n_rois is None else n_rois
         P = cfg.POOLING_SIZE
         lim = lambda mul: {} if limit is None else {'m_limit': limit, 'm_limit_mul': mul}
-        self._pyramid(False, self.rois_left if rois is None else rois, 2 * P, self.kp_in, 256, 0, n_rois=R)   # stereo_rcnn.py:260
+        self._pyramid(False, self.rois_left if rois is None else rois, 2 * P, self.kp_in, 256, 0, n_rois=R, limit=limit)   # stereo_rcnn.py:260
         x = self.kp_in
         s = 2 * P
         g = 'P'                                         # ROIAlign averages pyramid values: the pooled map keeps the pyramid's scale
@@ -436,7 +436,7 @@ class Plan(object):
         self._conv(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, 'kup', None, x_fmt=f, name='kpts.class', **lim(G * G))
         kp, lp, rp = (self.kpts_prob, self.left_prob, self.right_prob) if outs is None else outs
         _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, kp.data_ptr(), lp.data_ptr(), rp.data_ptr(),
-                                              _lib.stream()), "srcnn_kpts_tail")
+                                              None if limit is None else limit.data_ptr(), _lib.stream()), "srcnn_kpts_tail")
 
     def kpts_for_kept(self, rois_left_b, keep_idx, num, im_info_b, det_kpts, precision):
         """The keypoint head for the detections of ONE image that survived class NMS (postprocess.class_nms_device: keep_idx
@@ -451,6 +451,8 @@ class Plan(object):
         assert n == self.post and rois_left_b.is_contiguous()
         prev, engine.PRECISION = engine.PRECISION, precision
         self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
+        # the tower's range-guard reports belong to this plan's forward (the record packed after this call carries the word)
+        _lib.check(L.srcnn_range_flag_bind(self.range_flag.data_ptr()), "srcnn_range_flag_bind")
         try:
             _lib.check(L.srcnn_gather_rows(rois_left_b.data_ptr(), keep_idx.data_ptr(), n, 5, self.kp_rois.data_ptr(), _lib.stream()),
                        "srcnn_gather_rows")

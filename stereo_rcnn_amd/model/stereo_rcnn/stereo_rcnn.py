@@ -129,7 +129,7 @@ class _StereoRCNN(nn.Module):
         mh = (ctypes.c_int * 4)(*[int(m.shape[1]) for m in maps])
         mw = (ctypes.c_int * 4)(*[int(m.shape[2]) for m in maps])
         _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, C, float(im_info[0][0]), rois.data_ptr(), n, A,
-                                                      out.data_ptr(), C, 0, _lib.FMT_F32, _lib.FMT_F32,
+                                                      out.data_ptr(), C, 0, _lib.FMT_F32, _lib.FMT_F32, None,
                                                       _lib.stream()), "srcnn_pyramid_roi_align")
         return engine.nhwc_to_nchw(out)
 

@@ -131,11 +131,17 @@ def test_pyramid_roi_align_fused(dev, A, pad_c):
     mh = (ctypes.c_int * 4)(*[h for h, _ in hw]); mw = (ctypes.c_int * 4)(*[w for _, w in hw])
     tr = torch.from_numpy(rois).to(dev)
     _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, C, 600.0, tr.data_ptr(), n, A, out.data_ptr(), CS, CO,
-                                                  0, 0, _lib.stream()))
+                                                  0, 0, None, _lib.stream()))
     got = out[:, :, :, CO:].permute(0, 3, 1, 2).cpu().numpy()
     lv_dev = onet.roi_levels(torch.from_numpy(rois))
     assert float(out[:, :, :, :CO].abs().sum()) == 0.0         # other channel slice untouched
     assert np.array_equal(got, ref.numpy()), float(np.abs(got - ref.numpy()).max())
+    # device-side roi limit (the keypoint head on the kept detections): the first rois as before, later ones not touched
+    lim = torch.tensor([37], dtype=torch.int32, device=dev)
+    out2 = torch.zeros((n, A, A, CS), device=dev)
+    _lib.check(_lib.lib().srcnn_pyramid_roi_align(ptrs, mh, mw, C, 600.0, tr.data_ptr(), n, A, out2.data_ptr(), CS, CO,
+                                                  0, 0, lim.data_ptr(), _lib.stream()))
+    assert torch.equal(out2[:37], out[:37]) and float(out2[37:].abs().sum()) == 0.0
 
 
 def _conv_case(dev, B, H, W, cin, cout, k, stride, pad, relu, res, bn, seed, precision='f32'):

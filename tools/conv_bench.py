@@ -30,7 +30,10 @@ if SPLIT:
     PREC = 'f16x3'
 engine.PRECISION = PREC
 print('precision', PREC, 'split16 activations' if SPLIT else '')
+ONLY = os.environ.get('ONLY')          # substring filter of the shape names
 for name, B, H, W, cin, cout, k, s, p in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
     x = torch.randn(B, H, W, cin, device=dev)
     w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
     cw = engine.prep_conv(w, torch.zeros(cout), s, p, True, device=dev)
