@@ -24,6 +24,11 @@ python tools/gemm_ceiling.py > $O/gemm_ceiling_${TAG}.txt 2>&1
 ( for cap in 160 128 96 64; do SRCNN_MAX_LDS_KB=$cap python bench.py --no-pmc --no-cpu-baseline --no-f32-leg --no-3d-leg --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('tuner LDS cap $cap KB per workgroup: %.1f pairs/s with 3 pairs in flight, %.1f one at a time, conv %.3f ms/step' % (d['value'], d['config']['one_pair_at_a_time']['value'], d['roofline']['conv_ms_per_step']))"; done ) > $O/lds_cap_${TAG}.txt 2>&1
 # same-box A/B of the one-launch stereo RPN conv (conv mode 2)
 ( for i in 1 2 3; do for v in 0 1; do SRCNN_RPN_PAIR=$v python bench.py --no-pmc --no-cpu-baseline --no-f32-leg --no-3d-leg --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('stereo RPN conv as one launch = $v: %.1f pairs/s (3 in flight), %d conv launches per step' % (d['value'], d['roofline']['launches_per_step']))"; done; done ) > $O/rpn_pair_launch_${TAG}.txt 2>&1
+# keypoint head on the kept detections (pipeline.LAZY_KPTS): same-box A/B of the step, duration of the tower's launches against
+# the device-side row limit, and the M-fast tile order of the fully connected shapes
+python tools/lazy_probe.py 2>&1 | grep -v amdgpu.ids > $O/lazy_keypoint_head_${TAG}.txt
+python tools/limit_probe.py 2>&1 | grep -v amdgpu.ids > $O/row_limit_${TAG}.txt
+( for mf in 0 1; do echo "SRCNN_M_FAST=$mf"; SRCNN_M_FAST=$mf ONLY=box. SWEEP=1 python tools/conv_bench.py f16s 2>&1 | grep -v amdgpu.ids; done ) > $O/m_fast_${TAG}.txt
 # the 3-D-box metric's yardstick and the SPLIT16 range / scale tests, with their printed numbers
 python -m pytest tests/test_box3d_conditioning.py tests/test_box3d_gpu.py tests/test_demo_pair.py -q -s -k "spread or well_conditioned or full_flow" > $O/box3d_conditioning_${TAG}.txt 2>&1
 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -q -s -k "dynamic_range or activation_scales or range_guard" > $O/split16_dynamic_range_${TAG}.txt 2>&1
