@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrcnn_hip.so")
+LIB_PATH = os.environ.get("SRCNN_LIB_PATH") or os.path.join(_HERE, "libsrcnn_hip.so")   # override: A/B builds of the library (dev)
 
 FMT_F32, FMT_SPLIT16 = 0, 1     # SRCNN_FMT_* (include/srcnn_hip.h)
 REC_COLS = 32                   # SRCNN_REC_COLS: detection record row (include/srcnn_hip.h lists the columns)
