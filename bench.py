@@ -91,7 +91,7 @@ def parse():
 
 def cpu_baseline(cfg_id, height, width):
     """The CPU oracle (a port of the reference path; the reference itself cannot be imported or built on the GPU box) timed on
-    the host cores on a bounded sample of the workload: ONE stereo pair of the batch, full forward + decode + class NMS
+    the host cores on a bounded sample of the workload: three stereo pairs of the batch one after the other (one for configs[4]), full forward + decode + class NMS
     (det_time, demo.py:137-220); for --config 2 the sample leaves the 3-D stage out and says so."""
     from oracle import net as onet
     from oracle import postprocess as opost
@@ -109,14 +109,17 @@ def cpu_baseline(cfg_id, height, width):
     else:
         sd = fixture.make_state_dict(3)
         l, r, info = fixture.make_inputs(3, height, width)
+    n = 1 if cfg_id == 4 else 3             # ~10 s of wall time on the host cores either way
     t0 = time.time()
-    out = onet.forward(sd, l, r, info)
-    det = opost.decode_detections(out, info)
-    opost.class_detections(det)
+    for _ in range(n):
+        out = onet.forward(sd, l, r, info)
+        det = opost.decode_detections(out, info)
+        opost.class_detections(det)
     dt = time.time() - t0
-    return {'value': 1.0 / dt, 'unit': 'stereo pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 stereo pair %dx%d of the batch (network input %dx%d), batch 1: full forward + decode + class NMS%s, %.1f s'
-                      % (width, height, l.shape[3], l.shape[2], ' (3-D stage not in the sample)' if cfg_id == 2 else '', dt)}
+    return {'value': n / dt, 'unit': 'stereo pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d stereo pair(s) %dx%d of the batch (network input %dx%d), batch 1, one after the other: full forward + decode + '
+                      'class NMS%s, %.1f s' % (n, width, height, l.shape[3], l.shape[2],
+                                               ' (3-D stage not in the sample)' if cfg_id == 2 else '', dt)}
 
 
 def csrc_hash():
