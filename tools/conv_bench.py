@@ -23,6 +23,10 @@ SHAPES = [
     ('box.top0 GEMM 300x25088x2048', 300, 1, 1, 25088, 2048, 1, 1, 0),
     ('box.top3 GEMM 300x2048x2048', 300, 1, 1, 2048, 2048, 1, 1, 0),
     ('kpts 3x3 256 (300x14x14)', 300, 14, 14, 256, 256, 3, 1, 1),
+    ('hbm fpn.lateral3 1x1 256->256 P2', 2, 150, 497, 256, 256, 1, 1, 0),
+    ('hbm fpn.lateral2 1x1 512->256 P3', 2, 75, 249, 512, 256, 1, 1, 0),
+    ('hbm l2.downsample 1x1/2 256->512', 2, 150, 497, 256, 512, 1, 2, 0),
+    ('hbm l1.downsample 1x1 64->256', 2, 150, 497, 64, 256, 1, 1, 0),
 ]
 PREC = sys.argv[1] if len(sys.argv) > 1 else 'f32'
 SPLIT = PREC == 'f16s'          # f16x3 arithmetic with SPLIT16 activations (DMA-to-LDS kernel)
