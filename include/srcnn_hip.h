@@ -144,6 +144,13 @@ typedef struct srcnn_conv_desc {
      * the detections that survived class NMS only (*m_limit = the device-side keep count, m_limit_mul = rows per roi). */
     const int *m_limit;
     int m_limit_mul;
+    /* Second input (SPLIT16 f16x3 engine, KH = KW = 1, pad 0, mode 0; NULL = none): y = act(W[:, :Cin] . x + W[:, Cin:] . x2' + bias)
+     * with x2' = the (B, H2, W2, x2_cstride) SPLIT16 tensor x2 sampled at (oh * stride2, ow * stride2), Cin2 channels -- the
+     * ResNet projection shortcut (resnet.py:86-100: out = bn3(conv3(.)) + downsample(x)) computed inside the block's last 1x1
+     * conv as one GEMM over K = Cin + Cin2 instead of a launch of its own whose result is written and read back as the residual.
+     * w / w_lo are (Cout, Cin + Cin2); both inputs must carry the same activation scale; no split-K. */
+    const void *x2;
+    int Cin2, H2, W2, x2_cstride, stride2;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);

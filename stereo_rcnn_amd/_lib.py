@@ -32,7 +32,8 @@ class ConvDesc(ctypes.Structure):
                 ("tile_mr", c_int), ("tile_nr", c_int), ("splits", c_int),
                 ("x_format", c_int), ("y_format", c_int), ("res_format", c_int),
                 ("tile_waves", c_int), ("tile_stages", c_int), ("layer_tag", c_int),
-                ("m_limit", c_void_p), ("m_limit_mul", c_int)]
+                ("m_limit", c_void_p), ("m_limit_mul", c_int),
+                ("x2", c_void_p), ("Cin2", c_int), ("H2", c_int), ("W2", c_int), ("x2_cstride", c_int), ("stride2", c_int)]
 
 
 _SIGNATURES = {

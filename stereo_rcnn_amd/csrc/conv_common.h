@@ -32,6 +32,10 @@ struct ConvArgs {
     int tag;                     // caller's layer tag (>= 0): the flag keeps the largest tag + 1 that tripped
     const int *m_limit;          // device-side row limit (rows m >= *m_limit * m_limit_mul are not needed) or nullptr
     int m_limit_mul;
+    // SPLIT16 engine, 1x1 convs: a second input whose 1x1 / stride2 projection is K-concatenated (weights (Cout, Cin + Cin2)):
+    // the ResNet projection shortcut computed by the block's last conv itself.  nullptr = none.
+    const float *x2;
+    int Cin2, H2, W2, xcs2, stride2;
 };
 
 

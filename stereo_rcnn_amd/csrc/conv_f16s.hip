@@ -153,7 +153,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
     const int b0 = m0 / ohw;                                   // first image of this tile (workgroup-uniform)
     const int row0 = max(((m0 - b0 * ohw) / p.OW) * p.stride - p.pad, 0);   // its first input row that a valid tap can touch
     const size_t base_bytes = (((size_t)b0 * p.H + row0) * p.W) * p.xcs * 4;
-    const rsrc_t rx = make_rsrc(reinterpret_cast<const char *>(p.x) + base_bytes, (size_t)p.nimg * p.H * p.W * p.xcs * 4 - base_bytes);
+    rsrc_t rx = make_rsrc(reinterpret_cast<const char *>(p.x) + base_bytes, (size_t)p.nimg * p.H * p.W * p.xcs * 4 - base_bytes);
     const rsrc_t rwh = make_rsrc(p.w, (size_t)p.Cout * p.K * 2), rwl = make_rsrc(p.w_lo, (size_t)p.Cout * p.K * 2);
     // per-lane state of A group g: byte offset of the row's window origin relative to (image b0, row row0) plus the lane's
     // chunk (negative inside the padding: never used there), and the taps that fall inside the image as two bit fields --
@@ -176,6 +176,33 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
             for (int k = 0; k < p.KH; ++k) vm |= ((unsigned)(ih0 + k) < (unsigned)p.H ? 1 : 0) << k;
             for (int k = 0; k < p.KW; ++k) vm |= ((unsigned)(iw0 + k) < (unsigned)p.W ? 1 : 0) << (8 + k);
             a_vm[g] = vm;
+        }
+    }
+    // ---- second input (p.x2: the projection shortcut, K-concatenated behind the Cin channels of a 1x1 conv): its own
+    //      descriptor and one lane offset per group -- pixel (oh * stride2, ow * stride2) of the row's image, or OOB past M.
+    //      advance() switches the A stream over when the first input's channels are through.
+    constexpr bool DUAL_OK = !(MR == 2 && NR == 4 && WM == 4 && NS == 2);     // not in the 256x256 tile (register budget)
+    rsrc_t rx2 = rx;
+    int a_off2[AG];
+    int cin_cur = p.Cin;                                      // channels of the input the A stream is on (scalar)
+    bool on_x2 = false;
+    if constexpr (DUAL_OK) {
+        if (p.x2) {
+            const int row0_2 = ((m0 - b0 * ohw) / p.OW) * p.stride2;
+            const size_t base2 = (((size_t)b0 * p.H2 + row0_2) * p.W2) * p.xcs2 * 4;
+            rx2 = make_rsrc(reinterpret_cast<const char *>(p.x2) + base2, (size_t)p.nimg * p.H2 * p.W2 * p.xcs2 * 4 - base2);
+#pragma unroll
+            for (int g = 0; g < AG; ++g) {
+                const int m = m0 + wave * 16 * AG + g * 16 + drow;
+                a_off2[g] = OOB;
+                if (m < m_rows) {
+                    const int b = m / ohw;
+                    const int rem = m - b * ohw;
+                    const int oh = rem / p.OW;
+                    const int ow = rem - oh * p.OW;
+                    a_off2[g] = (((b - b0) * p.H2 + oh * p.stride2 - row0_2) * p.W2 + ow * p.stride2) * (p.xcs2 * 4) + dchunk * 32;
+                }
+            }
         }
     }
     // ---- DMA source cursors.  A: lane offset of the current tap's (row, chunk) run, or OOB when the tap falls outside
@@ -246,7 +273,18 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         }
         ld_c0 += BK;
         soff_b += BK * 2;
-        if (ld_c0 == p.Cin) {
+        if constexpr (DUAL_OK) {
+            if (p.x2 && !on_x2 && ld_c0 == cin_cur) {         // first input through: the A stream moves to the second one
+                on_x2 = true;
+                cin_cur = p.Cin2;
+                ld_c0 = 0;
+                rx = rx2;
+#pragma unroll
+                for (int g = 0; g < AG; ++g) a_voff[g] = a_off2[g];
+                return;
+            }
+        }
+        if (ld_c0 == cin_cur) {
             ld_c0 = 0;
             if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
             retap();
@@ -778,7 +816,7 @@ bool conv_f16s_plan_ok(const Plan &pl, const ConvArgs &a)
     case 428: return pl.stages == 3;
     case 448: {                               // 256x256 on 8 waves of 64x128 (two waves per SIMD, 256 registers each):
         const int cq = a.mode == 1 ? (a.Cout >> 2) : a.Cout;      // vector epilogue only (see the kernel's general path)
-        return pl.stages == 2 && (cq & 7) == 0 && (a.ycs & 7) == 0 && (a.yco & 7) == 0 && (!a.res || (a.rcs & 7) == 0);
+        return pl.stages == 2 && !a.x2 && (cq & 7) == 0 && (a.ycs & 7) == 0 && (a.yco & 7) == 0 && (!a.res || (a.rcs & 7) == 0);
     }
     default: return false;
     }

@@ -299,6 +299,10 @@ static Plan make_plan(int M, int N, int nkt, int mode, int precision)
 static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
 {
     Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
+    if (a.x2) {                    // the K walk of a second input has no mid-K entry points: never split
+        pl.splits = 1;
+        pl.kt_per_split = a.nkt;
+    }
     if (d->tile_mr <= 0 || d->tile_nr <= 0) return pl;
     Plan req = pl;
     req.mr = d->tile_mr;
@@ -311,7 +315,7 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
                          : (req.mr <= 2 && req.nr <= 2 && req.waves == 4 && req.stages == 2);
     if (!ok) return pl;            // unknown override: fall back to the heuristic plan (never an error)
     int s = d->splits >= 1 ? d->splits : 1;
-    if (a.mode == 1) s = 1;
+    if (a.mode == 1 || a.x2) s = 1;
     s = min(s, a.nkt);
     req.kt_per_split = cdiv(a.nkt, s);
     req.splits = cdiv(a.nkt, req.kt_per_split);
@@ -350,6 +354,18 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     a.m_limit = d->m_limit;
     a.m_limit_mul = d->m_limit_mul;
     if (a.m_limit) SRCNN_REQUIRE(d->precision == 1 && d->x_format == 1 && d->m_limit_mul > 0, "m_limit: SPLIT16 f16x3 engine, m_limit_mul > 0");
+    a.x2 = static_cast<const float *>(d->x2);
+    a.Cin2 = a.H2 = a.W2 = a.xcs2 = a.stride2 = 0;
+    if (a.x2) {
+        SRCNN_REQUIRE(d->precision == 1 && d->x_format == 1 && d->KH == 1 && d->KW == 1 && d->pad == 0 && d->mode == 0,
+                      "x2: SPLIT16 f16x3 engine, 1x1 conv, mode 0");
+        SRCNN_REQUIRE(d->Cin2 > 0 && d->Cin2 % BK == 0 && d->x2_cstride % 8 == 0 && d->x2_cstride >= d->Cin2 && d->stride2 >= 1,
+                      "x2: Cin2 must be a positive multiple of 32, x2_cstride a multiple of 8");
+        SRCNN_REQUIRE((d->OH - 1) * d->stride2 < d->H2 && (d->OW - 1) * d->stride2 < d->W2, "x2: output grid exceeds the second input");
+        SRCNN_REQUIRE((long long)d->W2 * d->x2_cstride * 4 * ((256 / d->OW + 3) * (long long)d->stride2 + 1) < (1LL << 31),
+                      "x2: the input rows under one 256-pixel tile must span < 2 GB");
+        a.Cin2 = d->Cin2; a.H2 = d->H2; a.W2 = d->W2; a.xcs2 = d->x2_cstride; a.stride2 = d->stride2;
+    }
     if (a.y_fmt == 1) {
         a.range_flag = range_flag_word();
         SRCNN_REQUIRE(a.range_flag != nullptr, "range flag allocation failed");
@@ -380,7 +396,7 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
         static const int m_fast_default = [] { const char *e = std::getenv("SRCNN_M_FAST"); return e ? std::atoi(e) : 1; }();   // A/B switch
         a.m_fast = (m_fast_default && a.M < d->Cout) ? 1 : 0;
     }
-    a.K = d->KH * d->KW * d->Cin;
+    a.K = d->KH * d->KW * d->Cin + a.Cin2;
     a.ctiles = d->Cin / BK;
     a.nkt = a.K / BK;
     return SRCNN_OK;

@@ -14,13 +14,15 @@ from . import _lib
 class ConvW(object):
     """A convolution prepared for the engine: weight (Cout, KH, KW, Cin) K-contiguous, bias."""
 
-    def __init__(self, weight, bias, kh, kw, stride, pad, relu, mode=0):
+    def __init__(self, weight, bias, kh, kw, stride, pad, relu, mode=0, cin2=0, stride2=1):
         self.weight = weight.contiguous()
         self.bias = None if bias is None else bias.contiguous()
         self.cout = int(weight.shape[0])
-        self.cin = int(weight.numel() // (weight.shape[0] * kh * kw))
+        # cin2 > 0 (1x1 only): the last cin2 columns of K belong to a SECOND input sampled with stride2 (prep_conv_shortcut)
+        self.cin2, self.stride2 = int(cin2), int(stride2)
+        self.cin = int(weight.numel() // (weight.shape[0] * kh * kw)) - self.cin2
         self.kh, self.kw, self.stride, self.pad, self.relu, self.mode = kh, kw, stride, pad, int(relu), mode
-        self.alg_k = self.cin * kh * kw      # algorithmic K (the stem pads 147 -> 224; see prep_stem)
+        self.alg_k = self.cin * kh * kw + self.cin2      # algorithmic K (the stem pads 147 -> 224; see prep_stem)
         self.w_hi = self.w_lo = None         # f16x3 engine operands (see split_f16x3)
         self.inv_scale = 1.0
 
@@ -56,6 +58,18 @@ def prep_conv(w, b, stride=1, pad=0, relu=False, bn=None, device='cuda'):
     kh, kw = int(w.shape[2]), int(w.shape[3])
     wt = w.permute(0, 2, 3, 1).contiguous().to(device)
     return ConvW(wt, None if b is None else b.to(device), kh, kw, stride, pad, relu)
+
+
+def prep_conv_shortcut(w3, bn3, wd, bnd, stride2, device='cuda'):
+    """The last 1x1 conv of a bottleneck block and the block's projection shortcut (resnet.py:86-100:
+    out = relu(bn3(conv3(t)) + bn_d(downsample(x)))) as ONE GEMM over K = [channels of t | channels of x]: both frozen BNs
+    folded, weights concatenated along K, biases added.  The shortcut's result is then never written nor read back as a
+    residual, and its launch is gone (srcnn_conv_desc.x2)."""
+    w3f, b3 = fold_bn(w3, bn3)
+    wdf, bd = fold_bn(wd, bnd)
+    assert w3f.shape[2:] == (1, 1) and wdf.shape[2:] == (1, 1) and w3f.shape[0] == wdf.shape[0]
+    wt = torch.cat((w3f[:, :, 0, 0], wdf[:, :, 0, 0]), 1).contiguous().view(w3f.shape[0], 1, 1, -1).to(device)
+    return ConvW(wt, (b3.double() + bd.double()).float().to(device), 1, 1, 1, 0, True, cin2=int(wdf.shape[1]), stride2=stride2)
 
 
 def prep_stem(w, bn, device='cuda'):
@@ -152,6 +166,8 @@ MAX_LDS_KB = int(_os.environ.get('SRCNN_MAX_LDS_KB', '160'))
 ACT_SCALES = _os.environ.get('SRCNN_ACT_SCALES', '1') != '0'    # per-tensor power-of-two SPLIT16 activation scales (plan.calibrate)
 LIMIT_TUNE_ROIS = 64          # row-limited launches (the lazy keypoint head) are tuned for this many units below the limit
 RPN_PAIR_LAUNCH = _os.environ.get('SRCNN_RPN_PAIR', '1') != '0'     # A/B switch of the one-launch stereo RPN conv (conv mode 2)
+# A/B switch: the projection shortcut of a layer's first block computed inside that block's conv3 (prep_conv_shortcut)
+SHORTCUT_FUSION = _os.environ.get('SRCNN_SHORTCUT_FUSION', '1') != '0'
 
 
 def plan_lds_kb(mr, nr, waves, stages):
@@ -187,7 +203,7 @@ def _tune(d, key, device):
     """Times each candidate plan with HIP events on the current stream: three interleaved passes, then a play-off."""
     L = _lib.lib()
     M = d.B * d.OH * d.OW
-    nkt = d.KH * d.KW * d.Cin // 32
+    nkt = (d.KH * d.KW * d.Cin + d.Cin2) // 32
     cands = []
     tiles = list(_CANDIDATES)
     if d.precision == 1 and d.x_format == 1:
@@ -197,13 +213,13 @@ def _tune(d, key, device):
             continue
         if nr == 2 and d.Cout <= 64:
             continue
-        if nr == 4 and (d.Cout <= 128 or M < 256 * 64):       # the 256x256 tile: only where it still fills the chip
-            continue
+        if nr == 4 and (d.Cout <= 128 or M < 256 * 64 or d.x2):   # the 256x256 tile: only where it still fills the chip (and no
+            continue                                              # second input: register budget)
         if mr >= 2 and M <= 64 * (mr // 2):
             continue
         blocks = -(-M // (64 * mr)) * -(-d.Cout // (64 * nr))
         splits = [1]
-        if d.mode != 1:
+        if d.mode != 1 and not d.x2:
             for s in (2, 3, 4, 6, 8, 12, 16):
                 if blocks * s <= 4096 and nkt // s >= 4 and blocks < 1024:
                     splits.append(s)
@@ -264,14 +280,15 @@ def _tune_candidates(d, key, device, cands, log, L, st):
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
            res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None,
-           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0):
+           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
     *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h).
     in_shift / out_shift (f16x3 engine): the input tensor holds its values x 2^in_shift, the output (and the residual, which
     must carry the output's scale) is to be stored x 2^out_shift -- per-tensor power-of-two activation scales that keep
     SPLIT16 tensors in the middle of the f16 range (model/stereo_rcnn/plan.py: calibrate).  Exact: the factor goes into the
     epilogue's power-of-two rescale and a pre-scaled copy of the bias; ReLU commutes with it.
-    m_limit (device int32 tensor) / m_limit_mul: only rows m < m_limit[0] * m_limit_mul are needed (srcnn_conv_desc.m_limit)."""
+    m_limit (device int32 tensor) / m_limit_mul: only rows m < m_limit[0] * m_limit_mul are needed (srcnn_conv_desc.m_limit).
+    x2 / H2 / W2 (weights from prep_conv_shortcut): the second input (B, H2, W2, cin2) SPLIT16, stored with the SAME scale as x."""
     L = _lib.lib()
     d = _lib.ConvDesc()
     d.x = x.data_ptr() + 4 * x_offset_elems
@@ -303,11 +320,16 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     d.mode = cw.mode
     d.x_format, d.y_format, d.res_format = x_fmt, y_fmt, res_fmt
     d.layer_tag = layer_tag(name)
+    assert (x2 is not None) == (cw.cin2 > 0), "weights from prep_conv_shortcut need the second input, and only they take one"
+    if x2 is not None:
+        assert precision == 'f16x3' and x_fmt == _lib.FMT_SPLIT16, "the second input belongs to the SPLIT16 engine"
+        d.x2, d.Cin2, d.H2, d.W2, d.stride2 = x2.data_ptr(), cw.cin2, H2, W2, cw.stride2
+        d.x2_cstride = cw.cin2 if x2_cstride is None else x2_cstride
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
         px_in = B * OH * OW if (cw.kh == 1 and cw.kw == 1) else B * H * W
-        nbytes = 4.0 * (px_in * cw.cin + cw.cout * cw.alg_k + B * OH * OW * cw.cout * (2 if residual is not None else 1))
+        nbytes = 4.0 * (px_in * cw.cin + B * OH * OW * cw.cin2 + cw.cout * cw.alg_k + B * OH * OW * cw.cout * (2 if residual is not None else 1))
         FlopCounter.bytes += nbytes
         if FlopCounter.rows is not None:
             FlopCounter.rows.append({'name': name or 'conv %dx%d %d->%d' % (cw.kh, cw.kw, cw.cin, cw.cout), 'M': B * OH * OW,
@@ -317,7 +339,8 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     elif AUTOTUNE:
         # a launch with a device-side row limit is tuned WITH a typical limit (LIMIT_TUNE_ROIS of its units): what is fastest for
         # the whole shape (the biggest tile, one round of CUs) is not what is fastest for a fifth of it
-        key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt) + (('lim', m_limit_mul) if m_limit is not None else ()))
+        key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt) + (('lim', m_limit_mul) if m_limit is not None else ())
+                         + (('x2', cw.cin2, cw.stride2, H2, W2) if x2 is not None else ()))
         plan = _TUNED.get(key)
         if plan is None:
             if torch.cuda.is_current_stream_capturing() or _lib.lib().srcnn_program_recording():

@@ -36,6 +36,8 @@ class Weights(object):
         self.calibrated = False
         self.calibration_max = {}      # group -> largest |value| seen by the calibration forwards
         self.calib_epoch = 0           # bumped whenever the shifts change: plans drop their recorded programs / graphs
+        # per layer: may the first block's conv3 take the block input as its second operand (both must carry one scale)
+        self.fuse_shortcut = [True, True, True, True]
         self.stem = engine.prep_stem(sd['RCNN_layer0.0.weight'], _bn_dict(sd, 'RCNN_layer0.1'), device)
         self.layers = []
         for li in (1, 2, 3, 4):
@@ -53,6 +55,10 @@ class Weights(object):
                 if p + '.downsample.0.weight' in sd:
                     blk['down'] = engine.prep_conv(sd[p + '.downsample.0.weight'], None, stride, 0, False,
                                                    _bn_dict(sd, p + '.downsample.1'), device)
+                    # conv3 and the projection shortcut as one GEMM over [conv2's output | the block's input] (SPLIT16 engine)
+                    blk['conv3_down'] = engine.prep_conv_shortcut(sd[p + '.conv3.weight'], _bn_dict(sd, p + '.bn3'),
+                                                                  sd[p + '.downsample.0.weight'], _bn_dict(sd, p + '.downsample.1'),
+                                                                  stride, device)
                 blocks.append(blk)
                 b += 1
             self.layers.append(blocks)
@@ -226,7 +232,18 @@ class Plan(object):
         for g, mx in calib.items():
             if mx > 0 and math.isfinite(mx):
                 shifts[g] = int(max(-24, min(24, round(math.log2(2048.0 / mx)))))
-        if shifts != w.shifts:
+        # conv3 of a layer's first block reads conv2's output AND the block's input in one GEMM (prep_conv_shortcut): one scale
+        # for both.  conv2's output is private to the block, so it takes the input stream's scale -- when that costs at most 4
+        # bits of its headroom below the f16 range (of 5) or 6 bits of its low end; otherwise that block keeps two launches.
+        fuse = []
+        for li in range(1, 5):
+            gm, gx = 'L%d.0.m2' % li, ('stem' if li == 1 else 'L%d' % (li - 1))
+            ok = gm in shifts and gx in shifts and -6 <= shifts[gx] - shifts[gm] <= 4
+            if ok:
+                shifts[gm] = shifts[gx]
+            fuse.append(bool(ok))
+        if shifts != w.shifts or fuse != w.fuse_shortcut:
+            w.fuse_shortcut = fuse
             w.shifts = shifts
             w.calib_epoch += 1             # launch programs / graphs recorded with the old scales are stale (every plan checks)
         w.calibrated = True
@@ -258,6 +275,13 @@ class Plan(object):
                 g1, g2 = lg + '.%d.m1' % bi, lg + '.%d.m2' % bi
                 self._conv(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, xg, g1, x_fmt=f, y_fmt=f, name=nm + 'conv1')
                 self._conv(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, g1, g2, x_fmt=f, y_fmt=f, name=nm + 'conv2')
+                if blk['down'] is not None and f and engine.SHORTCUT_FUSION and w.fuse_shortcut[li] and self._k(g2) == self._k(xg):
+                    # the projection shortcut inside conv3: K = [conv2's output | the block's input], no residual round trip
+                    self._conv(blk['conv3_down'], bufs['m2'], N, h, w_, cur, h, w_, g2, lg, x2=x, H2=xh, W2=xw, x_fmt=f, y_fmt=f,
+                               name=nm + 'conv3+downsample')
+                    x, xh, xw, xg = cur, h, w_, lg
+                    cur, nxt = nxt, cur
+                    continue
                 if blk['down'] is not None:
                     self._conv(blk['down'], x, N, xh, xw, nxt, h, w_, xg, lg, x_fmt=f, y_fmt=f, name=nm + 'downsample')
                     res = nxt

@@ -224,6 +224,41 @@ def test_conv_f16s_every_plan(dev, plan, case):
         engine._TUNED, engine.AUTOTUNE = saved_tuned, saved_flag
 
 
+@pytest.mark.parametrize("plan", [None, (1, 1, 4, 2, 1), (1, 1, 4, 4, 1), (2, 1, 4, 3, 1), (1, 2, 4, 2, 1), (2, 2, 4, 2, 1), (2, 2, 8, 4, 1),
+                                  (4, 2, 8, 3, 1), (2, 2, 8, 2, 3), (4, 4, 8, 2, 1)])
+@pytest.mark.parametrize("case", [
+    # B, OH, OW, cin (conv3 input), cin2 (block input), cout, stride2
+    (2, 19, 31, 64, 64, 256, 1),         # layer1.0: same grid, ragged M (1178)
+    (2, 12, 21, 128, 256, 512, 2),       # layer2.0 .. layer4.0: the block input at twice the resolution (odd sizes)
+    (1, 7, 9, 32, 32, 200, 2),           # one K tile per input, ragged N
+])
+def test_conv_with_projection_shortcut_as_second_operand(dev, plan, case):
+    """srcnn_conv_desc.x2 (engine.prep_conv_shortcut): relu(bn3(conv3(t)) + bn_d(downsample(x))) of a bottleneck's first block
+    (resnet.py:86-100) as ONE launch over K = [channels of t | channels of x] against torch on the CPU, both BNs folded; every
+    tile plan that may carry it (a split-K or 256x256 request falls back / is ignored: the result must still be right)."""
+    from stereo_rcnn_amd import engine
+    B, OH, OW, cin, cin2, cout, s2 = case
+    g = torch.Generator().manual_seed(cin + cout + s2)
+    H2, W2 = OH * s2 - (s2 - 1), OW * s2 - (s2 - 1)          # smallest input whose stride-s2 grid is (OH, OW)
+    t = torch.randn(B, cin, OH, OW, generator=g)
+    x = torch.randn(B, cin2, H2, W2, generator=g)
+    w3 = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    wd = torch.randn(cout, cin2, 1, 1, generator=g) / cin2 ** 0.5
+    bn = lambda: {'weight': torch.rand(cout, generator=g) + 0.5, 'bias': torch.randn(cout, generator=g),
+                  'running_mean': torch.randn(cout, generator=g) * 0.1, 'running_var': torch.rand(cout, generator=g) + 0.5}
+    bn3, bnd = bn(), bn()
+    fbn = lambda v, b: F.batch_norm(v, b['running_mean'], b['running_var'], b['weight'], b['bias'], False, 0.0, 1e-5)
+    ref = F.relu(fbn(F.conv2d(t, w3), bn3) + fbn(F.conv2d(x, wd, None, s2), bnd))
+    cw = engine.prep_conv_shortcut(w3, bn3, wd, bnd, s2, device=dev)
+    ts = engine.act_convert(t.to(dev).permute(0, 2, 3, 1).contiguous(), 0, 1)
+    xs = engine.act_convert(x.to(dev).permute(0, 2, 3, 1).contiguous(), 0, 1)
+    y = torch.empty((B, OH, OW, cout), device=dev)
+    engine.conv2d(cw, ts, B, OH, OW, y, OH, OW, precision='f16x3', x_fmt=1, y_fmt=1, x2=xs, H2=H2, W2=W2, plan=plan)
+    got = engine.act_convert(y, 1, 0).permute(0, 3, 1, 2).cpu()
+    err = float((got - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
 @pytest.mark.parametrize("plans", [
     [(2, 2, 4, 2, 1), (4, 2, 8, 3, 1), (4, 4, 8, 2, 1)],                       # per-wave tile >= 2x2: one accumulator chain
     [(2, 1, 4, 2, 1), (2, 1, 4, 3, 1), (1, 2, 4, 3, 1), (2, 2, 8, 2, 1), (2, 2, 8, 4, 1)],   # two chains
