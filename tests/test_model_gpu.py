@@ -281,6 +281,40 @@ def test_f16x3_engine_end_to_end_small(small, dev):
         assert v < 2e-3, (k, v)
 
 
+def test_projection_shortcut_inside_conv3_equals_separate_launches(dev):
+    """The trunk with each layer's projection shortcut riding its first block's conv3 as a second K-concatenated operand
+    (engine.SHORTCUT_FUSION, the default) against the same trunk with the shortcut as a launch of its own whose result is read back
+    as the residual: the same arithmetic up to fp32 summation order (one accumulator vs two + an add) -- and the fused form
+    must actually have been taken (four conv launches fewer), also after the scales were calibrated."""
+    from stereo_rcnn_amd import engine, fixture
+    m, _ = _build_model(dev)
+    m.precision = 'f16x3'
+    m.use_program = m.use_graph = False                         # eager: the launch counter sees every conv launch
+    l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
+    plan = m._get_plan(1, l.shape[2], l.shape[3])
+    maps, launches = {}, {}
+    saved = engine.SHORTCUT_FUSION
+    try:
+        for fused in (True, False):
+            engine.SHORTCUT_FUSION = fused
+            with torch.no_grad():
+                m(l, r, info)                                   # first call of the first mode also calibrates the scales
+                engine.FlopCounter.enabled, engine.FlopCounter.launches = True, 0
+                try:
+                    m(l, r, info)
+                finally:
+                    engine.FlopCounter.enabled = False
+                launches[fused] = engine.FlopCounter.launches
+            torch.cuda.synchronize()
+            maps[fused] = [plan.as_f32(plan.c[i]).clone() for i in range(4)] + [plan.as_f32(plan.p2).clone()]
+    finally:
+        engine.SHORTCUT_FUSION = saved
+    assert m._weights.fuse_shortcut == [True] * 4 and m._weights.calibrated
+    assert launches[False] - launches[True] == 4, launches
+    for a, b in zip(maps[True], maps[False]):
+        assert _relerr(a, b) < 2e-6
+
+
 def test_f16x3_engine_full_size_vs_golden(dev):
     from stereo_rcnn_amd import fixture
     g = np.load(os.path.join(GOLD, 'full_r101_seed3.npz'))
