@@ -134,11 +134,17 @@ def test_tuned_plans_round_trip(tmp_path):
         key = ('f16x3', 2, 38, 125, 38, 125, 256, 256, 3, 3, 1, 1, 0, 256, 1, 1, 0)
         engine._TUNED[key] = (2, 2, 8, 4, 1)
         engine._TUNED[('f32', 1, 8, 8, 8, 8, 32, 64, 1, 1, 1, 0, 0, 32, 0, 0, 0)] = (1, 1, 4, 2, 3)
+        # the keys of row-limited launches and of convs with a second operand, as engine.conv2d builds them: flat tuples
+        cw = engine.ConvW(torch.zeros(256, 1, 1, 64 + 64), None, 1, 1, 1, 0, True, cin2=64, stride2=2)
+        assert (cw.cin, cw.cin2, cw.alg_k) == (64, 64, 128)
+        k2 = engine._shape_key(cw, 2, 38, 125, 38, 125, 64, 'f16x3', (1, 1, 0) + ('lim', 196) + ('x2', cw.cin2, cw.stride2, 75, 249))
+        assert all(not isinstance(v, (tuple, list)) for v in k2)
+        engine._TUNED[k2] = (2, 1, 4, 2, 1)
         path = str(tmp_path / 'plans.json')
         engine.save_plans(path)
         before = dict(engine._TUNED)
         engine._TUNED.clear()
-        assert engine.load_plans(path) == 2
+        assert engine.load_plans(path) == 3
         assert engine._TUNED == before
     finally:
         engine._TUNED.clear()
