@@ -151,6 +151,27 @@ def test_tuned_plans_round_trip(tmp_path):
         engine._TUNED.update(saved)
 
 
+def test_prep_conv_shortcut_folds_and_concatenates():
+    """engine.prep_conv_shortcut (host side of srcnn_conv_desc.x2): relu(bn3(conv3(t)) + bn_d(downsample(x))) equals ONE 1x1 GEMM
+    over [channels of t | channels of x sampled with the shortcut's stride] with the concatenated folded weights and the summed
+    folded biases (resnet.py:86-100) -- checked with torch on the CPU."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(4)
+    cin, cin2, cout, s2 = 32, 64, 96, 2
+    t, x = torch.randn(2, cin, 5, 7, generator=g), torch.randn(2, cin2, 9, 13, generator=g)
+    w3, wd = torch.randn(cout, cin, 1, 1, generator=g), torch.randn(cout, cin2, 1, 1, generator=g)
+    bn = lambda: {'weight': torch.rand(cout, generator=g) + 0.5, 'bias': torch.randn(cout, generator=g),
+                  'running_mean': torch.randn(cout, generator=g) * 0.1, 'running_var': torch.rand(cout, generator=g) + 0.5}
+    bn3, bnd = bn(), bn()
+    fbn = lambda v, b: F.batch_norm(v, b['running_mean'], b['running_var'], b['weight'], b['bias'], False, 0.0, 1e-5)
+    ref = F.relu(fbn(F.conv2d(t, w3), bn3) + fbn(F.conv2d(x, wd, None, s2), bnd))
+    cw = engine.prep_conv_shortcut(w3, bn3, wd, bnd, s2, device='cpu')
+    assert (cw.cin, cw.cin2, cw.stride2, cw.cout, cw.relu, cw.alg_k) == (cin, cin2, s2, cout, 1, cin + cin2)
+    both = torch.cat((t, x[:, :, ::s2, ::s2]), 1)                          # the K-concatenated operand
+    got = F.relu(F.conv2d(both, cw.weight.view(cout, cin + cin2, 1, 1), cw.bias))
+    assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
 def test_layer_table_bounds_grouping_and_ranking():
     """stereo_rcnn_amd/layer_table.py (bench.py's roofline.layers): own bound = max(issued MFMA flops / peak, bytes / HBM rate),
     launches of one layer shape pooled, groups ranked by the time they lose -- on hand-made rows, no GPU."""
