@@ -170,6 +170,31 @@ RPN_PAIR_LAUNCH = _os.environ.get('SRCNN_RPN_PAIR', '1') != '0'     # A/B switch
 SHORTCUT_FUSION = _os.environ.get('SRCNN_SHORTCUT_FUSION', '1') != '0'
 
 
+# ---- what the tuner minimises.  'isolated': the latency of the launch alone on the chip (the right objective for one pair at a
+# time).  'concurrent': the time per launch while TUNE_STREAMS copies of the launch run on as many HIP streams -- the regime of
+# the headline benchmark and of pipeline.detect_3d_stream, where several batch-1 forwards are in flight and a plan is worth
+# what it costs in CU-time, not in latency: a 150-workgroup plan that leaves 106 CUs to the neighbours beats a split-K plan
+# that is 10 % faster alone but occupies the whole chip and needs a reduction launch (profiles/tune_objective_r04.txt).
+# The two plan sets live side by side in _TUNED (the mode is part of the key).
+TUNE_MODE = _os.environ.get('SRCNN_TUNE_MODE', 'isolated')
+TUNE_STREAMS = int(_os.environ.get('SRCNN_TUNE_STREAMS', '3'))
+_tune_side_streams = {}
+
+
+def set_tune_mode(mode, streams=None):
+    """'isolated' or 'concurrent' (see above).  Plans recorded into launch programs under the other mode are dropped by
+    Plan.run (the mode is part of its epoch)."""
+    global TUNE_MODE, TUNE_STREAMS
+    assert mode in ('isolated', 'concurrent')
+    TUNE_MODE = mode
+    if streams is not None:
+        TUNE_STREAMS = int(streams)
+
+
+def tune_mode_key():
+    return ('conc', TUNE_STREAMS) if TUNE_MODE == 'concurrent' and TUNE_STREAMS > 1 else ()
+
+
 def plan_lds_kb(mr, nr, waves, stages):
     return stages * 128 * 64 * (mr + nr) // 1024
 
@@ -245,8 +270,14 @@ _tune_flag = None
 
 
 def _tune_candidates(d, key, device, cands, log, L, st):
+    conc = tune_mode_key()
+    if conc:
+        pool = _tune_side_streams.setdefault(str(device), [])
+        while len(pool) < TUNE_STREAMS:
+            pool.append(torch.cuda.Stream(device=device))
+        side = pool[:TUNE_STREAMS]
 
-    def timed(plan, launches):
+    def timed_isolated(plan, launches):
         _set_plan(d, plan)
         ws = _lib.workspace(L.srcnn_conv2d_workspace_bytes(ctypes.byref(d)), device, "conv")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -256,6 +287,31 @@ def _tune_candidates(d, key, device, cands, log, L, st):
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1) / launches
+
+    def timed_concurrent(plan, launches):
+        """time per launch with the same launch running on TUNE_STREAMS streams at once (every stream its own split-K scratch;
+        the copies read the same operands and write the same values to the same output)"""
+        _set_plan(d, plan)
+        need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
+        wss = []
+        for s in side:
+            with torch.cuda.stream(s):
+                wss.append(_lib.workspace(need, device, "conv"))
+        cur = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for s in side:
+            s.wait_event(e0)
+        for _ in range(launches):
+            for s, ws in zip(side, wss):
+                _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), s.cuda_stream), "srcnn_conv2d(tune)")
+        for s in side:
+            cur.wait_stream(s)
+        e1.record(cur)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / (launches * len(side))
+
+    timed = timed_concurrent if conc else timed_isolated
 
     # three passes over all candidates (a transient -- clock ramp, a neighbour's kernel -- then hits every plan once, not
     # one plan always), minimum per plan; the first launch of a plan is a warm-up
@@ -340,7 +396,7 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         # a launch with a device-side row limit is tuned WITH a typical limit (LIMIT_TUNE_ROIS of its units): what is fastest for
         # the whole shape (the biggest tile, one round of CUs) is not what is fastest for a fifth of it
         key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt) + (('lim', m_limit_mul) if m_limit is not None else ())
-                         + (('x2', cw.cin2, cw.stride2, H2, W2) if x2 is not None else ()))
+                         + (('x2', cw.cin2, cw.stride2, H2, W2) if x2 is not None else ()) + tune_mode_key())
         plan = _TUNED.get(key)
         if plan is None:
             if torch.cuda.is_current_stream_capturing() or _lib.lib().srcnn_program_recording():

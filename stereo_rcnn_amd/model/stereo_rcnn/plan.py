@@ -171,7 +171,7 @@ class Plan(object):
         # sets or clears it, and it lives on the plan's device
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self._calib = None      # group -> max |value| while calibrate() runs
-        self._epoch = weights.calib_epoch
+        self._epoch = (weights.calib_epoch, engine.tune_mode_key())
         self._buf_shift = {}    # data_ptr -> shift of the tensor the buffer holds after the last run (as_f32 undoes it)
         self.graphs = {}
         self.programs = {}      # precision -> (native launch program handle, buffers it keeps alive); run(use_program=True)
@@ -473,6 +473,11 @@ class Plan(object):
         L = _lib.lib()
         n = int(keep_idx.shape[0])
         assert n == self.post and rois_left_b.is_contiguous()
+        # the decode kernel dereferences im_info: a host tensor (which forward(), decode_detections and set_inputs all accept)
+        # must be brought to the device here, not handed over as a host pointer
+        im_info_b = im_info_b.reshape(-1, 3)[0:1].to(device=self.dev, dtype=torch.float32).contiguous()
+        for name, tns in (('rois_left_b', rois_left_b), ('keep_idx', keep_idx), ('num', num), ('det_kpts', det_kpts)):
+            assert tns.is_cuda and tns.is_contiguous(), "kpts_for_kept: %s must be a contiguous device tensor" % name
         prev, engine.PRECISION = engine.PRECISION, precision
         self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
         # the tower's range-guard reports belong to this plan's forward (the record packed after this call carries the word)
@@ -488,6 +493,16 @@ class Plan(object):
                        "srcnn_decode_kept_kpts")
         finally:
             engine.PRECISION = prev
+
+    def __del__(self):
+        # run() / kpts_for_kept() leave this plan's range word bound on the thread (the decode / pack calls that follow a forward
+        # report to it); once the plan is evicted or freed that binding would dangle -- hand the thread back to the library's own word
+        try:
+            L = _lib.lib()
+            if L.srcnn_range_flag_device_word() == self.range_flag.data_ptr():
+                L.srcnn_range_flag_bind(None)
+        except Exception:          # interpreter shutdown: nothing left to protect
+            pass
 
     def heads(self, kpts=True):
         """Box head (M=300 GEMMs, poor chip fill on their own) runs beside the keypoint tower (kpts=False: box head only --
@@ -572,10 +587,11 @@ class Plan(object):
         self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
         if self.fmt and engine.ACT_SCALES and not self.w.calibrated:
             self.calibrate()               # once per weights: the scales of every SPLIT16 tensor group, from this first input
-        if self._epoch != self.w.calib_epoch:      # the scales changed since this plan recorded its launch lists
+        epoch = (self.w.calib_epoch, engine.tune_mode_key())
+        if self._epoch != epoch:      # the scales, or the tuner's objective (= the plan set), changed since this plan recorded its launch lists
             for prog, _ in self.programs.values():
                 _lib.lib().srcnn_program_destroy(prog)
-            self.programs, self.graphs, self._epoch = {}, {}, self.w.calib_epoch
+            self.programs, self.graphs, self._epoch = {}, {}, epoch
         try:
             if use_program and not use_graph:
                 self.packed_fmt = -1                  # the recorded list always contains the stem_pack launches

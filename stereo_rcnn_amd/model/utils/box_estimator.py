@@ -1,13 +1,19 @@
 """3-D box solvers - reference lib/model/utils/box_estimator.py:169-385 (4-DoF) and :387-545 (3-DoF).
 
-These stay on the HOST, on scipy, exactly like the reference: both solvers hand a sum of squared
-re-projection residuals and a hand-written gradient to `scipy.optimize.minimize(method='Newton-CG')`.
-That gradient is not the gradient of the cost (the doubled keypoint residual, :264, is differentiated
-without its factor 2, :311-316), so the point scipy stops at is decided by its line search giving up,
-not by a stationarity condition: a converged Gauss-Newton on the same residuals lands up to 0.3 m away
-in depth (measured).  The only way to return the reference's 3-D boxes is to run
-the same optimiser, so no device solver is offered for this row; the per-detection cost is ~1 ms of
-host time, overlappable with the next pair's forward.
+Both reference solvers hand a sum of squared re-projection residuals and a hand-written gradient to
+`scipy.optimize.minimize(method='Newton-CG')`.  That gradient is not the gradient of the cost (the doubled keypoint
+residual, :264, is differentiated without its factor 2, :311-316), so the point scipy stops at is decided by its line
+search giving up, not by a stationarity condition; the only way to return the reference's 3-D boxes is to run the
+same iteration.  Three forms of it live here / behind this module:
+
+  * `solve_x_y_z_theta_from_kpt` / `solve_x_y_theta_from_kpt` -- the reference's own arrangement (host numpy + scipy per
+    object); `pipeline.detect_3d(solver='scipy')` uses them; they are the comparison baseline of the tests.
+  * `*_native` -- the same Newton-CG (scipy 1.15's `_minimize_newtoncg`, MINPACK-2 line search, restated once in
+    csrc/box_solver.h) called per object through the C ABI (`srcnn_solve_4dof_host` / `srcnn_solve_3dof_host`): host build,
+    BIT-IDENTICAL to the scipy path (tests/test_solvers_cpu.py, test_box3d_gpu.py).  The pipeline's DEFAULT
+    (`solver='host'`) runs that host build over the whole detection record in C threads between the device stages.
+  * the device build of the same source (`solver='device'`, csrc/box3d.hip): same iteration with ocml's libm -- numerically
+    equivalent, not reference-identical.
 
 Interface = the reference's: `solve_x_y_z_theta_from_kpt(im_shape, calib, alpha, dim, box_left,
 box_right, kpts) -> (status, state)` and `solve_x_y_theta_from_kpt(im_shape, calib, alpha, dim,

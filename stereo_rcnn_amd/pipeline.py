@@ -278,6 +278,16 @@ def collect_3d(st):
         from . import engine
         raise engine.Split16RangeError('SPLIT16 range exceeded in %s'
                                        % engine.TAG_NAMES.get(int(rec[0, 1]), 'layer tag %d' % (int(rec[0, 1]) - 1)))
+    head = getattr(st, 'batch_head', None)
+    if head is not None:
+        # image b > 0 of a batched forward: the ONE forward's flag word was copied (and cleared) by the pack of image 0 only, so
+        # this record alone would look clean whatever the shared forward did -- in whatever order the handles are collected
+        head.event.synchronize()
+        hflag = int(head.rec_host[0, 1])
+        if hflag > 0:
+            from . import engine
+            raise engine.Split16RangeError('SPLIT16 range exceeded in %s (flag of the batch\'s shared forward, carried by its first image)'
+                                           % engine.TAG_NAMES.get(hflag, 'layer tag %d' % (hflag - 1)))
     k = int(rec[0, 0])
     objs = []
     for i in range(k):
@@ -312,6 +322,10 @@ def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shap
             plan, precision = _plan_of(model, im_left_data, 0)
             plan.kpts_for_kept(out[0][0].contiguous(), keep_idx, num, im_info.view(-1, 3)[0:1].contiguous(), det['kpts'], precision)
         cls = postprocess.class_detections(det, class_index, eval_thresh, cfg.TEST.NMS)
+        # this flow packs no record, so nothing else would read (and clear) the forward's range word: a tripped flag would be
+        # charged to the next record-flow forward on this plan, and THIS result would come from out-of-range activations
+        if getattr(model, 'precision', 'f32') == 'f16x3':
+            model.check_range(reset=True)
     dets_left = cls['dets_left'].cpu().numpy()
     if dets_left.shape[0] == 0:
         return []
@@ -371,10 +385,20 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
     all, one D2H copy; its libm differs from glibc in last bits, so chaotic end points differ); 'scipy' (the
     reference's own arrangement: host numpy + scipy per object, optional `pool`); 'host_py' (that arrangement with the native
     solver called per object)."""
-    if solver in ('scipy', 'host_py'):
-        return _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
-                                dense_align, pool if solver == 'scipy' else None, native=(solver == 'host_py'))
     from . import engine
+    if solver in ('scipy', 'host_py'):
+        try:
+            return _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
+                                    dense_align, pool if solver == 'scipy' else None, native=(solver == 'host_py'))
+        except engine.Split16RangeError:
+            if model.precision == 'f32':
+                raise
+            prev, model.precision = model.precision, 'f32'       # same fallback as the record flows below
+            try:
+                return _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
+                                        dense_align, pool if solver == 'scipy' else None, native=(solver == 'host_py'))
+            finally:
+                model.precision = prev
     with torch.no_grad():
         lazy = _lazy(model)
         out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy)
@@ -440,13 +464,15 @@ def launch_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shap
             handles.append(launch_3d(image_outputs(out, b), im_left_data[b:b + 1], im_right_data[b:b + 1], info_b,
                                      _scale32(info_b), calibs[b], im_shapes[b], eval_thresh, class_index, dense_align,
                                      (slot, b), solver, lazy=pl))
+        for h in handles[1:]:
+            h.batch_head = handles[0]        # see collect_3d: the shared forward's range flag lives in image 0's record
     return handles
 
 
 def collect_3d_batch(handles):
     """Object lists of the batch, one per image.  The batch shares one forward and therefore one range flag: the record of the
-    first image carries it (the pack clears the word), and a tripped flag condemns the whole batch."""
-    # (image 0 is collected first: if the flag tripped, Split16RangeError leaves from there before any other image is used)
+    first image carries it (the pack clears the word), and a tripped flag condemns the whole batch -- every other handle of the
+    batch looks at image 0's record too (`batch_head`), so per-handle collect_3d() in any order raises as well."""
     return [collect_3d(st) for st in handles]
 
 

@@ -89,6 +89,39 @@ def net_golden_batch8(net):
     print('reference_net_small_b8_seeds3_10.npz', {k: v.shape for k, v in d.items()})
 
 
+def net_golden_full_b8(net):
+    """BASELINE configs[2] AT THE SHAPE bench.py --config 2 runs: eight different 375x1242 pairs (seeds 3..10, bench.make_batch)
+    in ONE forward at network input 600x1987 (B = 8 was pinned at 192x640 only)."""
+    parts = [fixture.make_inputs(3 + i, 375, 1242) for i in range(8)]
+    l, r, info = (torch.cat([p[k] for p in parts], 0) for k in range(3))
+    z, nb = torch.zeros(8, 1, 5), torch.zeros(8)
+    with torch.no_grad():
+        out = net(l, r, info, z, z, z, z, z, nb)
+    d = {n: out[i].detach().numpy().astype(np.float32) for i, n in enumerate(NAMES)}
+    d['input_shape'] = np.asarray(l.shape)
+    np.savez_compressed(os.path.join(HERE, 'reference_net_full_b8_seeds3_10.npz'), **d)
+    print('reference_net_full_b8_seeds3_10.npz', {k: v.shape for k, v in d.items()})
+
+
+def net_golden_r50_2x_b4(net):
+    """BASELINE configs[4] AT THE SHAPE bench.py --config 4 runs: ResNet-50, four different 750x2484 pairs (seeds 5..8) in one
+    forward at network input 1200x3974 (bench.make_batch: fixture.synthetic_pair + fixture.preprocess(short side 1200))."""
+    parts = []
+    for b in range(4):
+        lu, ru = fixture.synthetic_pair(5 + b, 750, 2484)
+        tl, sc = fixture.preprocess(lu, 1200, max_size=1 << 30)
+        tr, _ = fixture.preprocess(ru, 1200, max_size=1 << 30)
+        parts.append((tl, tr, torch.tensor([[tl.shape[2], tl.shape[3], sc]], dtype=torch.float32)))
+    l, r, info = (torch.cat([p[k] for p in parts], 0) for k in range(3))
+    z, nb = torch.zeros(4, 1, 5), torch.zeros(4)
+    with torch.no_grad():
+        out = net(l, r, info, z, z, z, z, z, nb)
+    d = {n: out[i].detach().numpy().astype(np.float32) for i, n in enumerate(NAMES)}
+    d['input_shape'] = np.asarray(l.shape)
+    np.savez_compressed(os.path.join(HERE, 'reference_net_r50_2x_b4_seeds5_8.npz'), **d)
+    print('reference_net_r50_2x_b4_seeds5_8.npz', {k: v.shape for k, v in d.items()})
+
+
 def reference_model_r50(seed):
     """BASELINE configs[4] names a ResNet-50 trunk.  The reference ships `resnet50()` (resnet.py:188-196) next to the
     `resnet101()` its `_init_modules` hard-codes (resnet.py:229): for this golden the module-level name `resnet101` is
@@ -436,6 +469,12 @@ if __name__ == '__main__':
         net_golden_batch8(reference_model(3))
     if 'r50' in which:
         net_golden(reference_model_r50(5), 5, 375, 1242, 600, 'full_r50_seed5')
+    if 'full_b8' in which:
+        net_golden_full_b8(reference_model(3))
+    if 'r50_2x' in which:
+        net_golden_r50_2x_b4(reference_model_r50(5))
+    if 'kitti370' in which:       # KITTI's other common frame size: 370x1224 -> 600x1985 (other ragged tails in every layer)
+        net_golden(reference_model(3), 4, 370, 1224, 600, 'full_370x1224_r101_seed4')
     if 'demo' in which:
         demo_pair_golden(reference_model(3, sd=fixture.demo_state_dict(3)))
     if 'misc' in which:
