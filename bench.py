@@ -84,6 +84,9 @@ def parse():
                          'this script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE`, about a minute); '
                          'the committed profiles/pmc_*_traffic.json is then quoted if it matches the kernel sources')
     ap.add_argument('--pmc-child', type=int, default=0, help=argparse.SUPPRESS)     # internal: N forwards, one stream, exit
+    ap.add_argument('--no-shipped-plans', action='store_true',
+                    help='ignore stereo_rcnn_amd/plans/mi355x.json (conv plans tuned with the multi-stream step as objective, '
+                         'tools/tune_headline.py) and tune every shape in situ, each launch alone on the chip')
     ap.add_argument('--tune', choices=['auto', 'isolated', 'concurrent'], default='auto',
                     help="objective of the conv engine's plan autotuner (engine.TUNE_MODE): 'isolated' = latency of the launch alone "
                          "on the chip, 'concurrent' = time per launch with as many copies in flight as the benchmark has batches in "
@@ -370,8 +373,14 @@ def main():
     gather_stream = torch.cuda.Stream() if use_dist else None
 
     S = max(1, args.streams if args.streams > 0 else wl['streams'])
-    tune_mode = args.tune if args.tune != 'auto' else ('concurrent' if S > 1 else 'isolated')
+    # 'auto' = isolated: timing a launch beside copies of itself picks plans that lose the real mix (profiles/tune_objective_r04.txt);
+    # the multi-stream regime is tuned by the measured step itself instead (stereo_rcnn_amd/tune.py -> the shipped plan file)
+    tune_mode = args.tune if args.tune != 'auto' else 'isolated'
     engine.set_tune_mode(tune_mode, S)
+    from stereo_rcnn_amd import tune as stune
+    shipped = 0
+    if not args.no_shipped_plans and not args.plans and tune_mode == 'isolated' and args.precision == 'f16x3':
+        shipped = stune.load_shipped_plans()
     plans_loaded = bool(args.plans) and os.path.exists(args.plans) and engine.load_plans(args.plans) > 0
     if args.pmc_child:              # counter-collection child of measure_traffic_live(): forwards only, one at a time
         assert plans_loaded, "--pmc-child needs the parent's tuned plans"
@@ -389,6 +398,7 @@ def main():
     n_rec = 300 + 1
     rec_bufs = [torch.zeros((G * B, n_rec, sdist.REC_COLS), device=dev) for _ in range(2)] if use_dist else None
     gather_done = [None, None]
+    gather_spans = []                         # (start, end) events of every all_gather on the gather stream (diagnostics)
     st = {'k': 0}
     pending = {}                              # flow '3d': slot -> handles of the batch still in flight on that slot
 
@@ -400,10 +410,13 @@ def main():
         for cs in compute_streams():
             gather_stream.wait_stream(cs)
         with torch.cuda.stream(gather_stream):          # xGMI gather overlaps the following pairs' forwards
+            g0 = torch.cuda.Event(enable_timing=True)
+            g0.record(gather_stream)
             sdist.gather_detections(rec_bufs[b])
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record(gather_stream)
             gather_done[b] = ev
+            gather_spans.append((g0, ev))
 
     def gather_rows(gather):
         """(buffer, first row) for this step's B records, or None; waits for the buffer's previous gather"""
@@ -494,7 +507,20 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        # per-rank diagnostics for the first multi-GPU run: every rank's own ms per step, and the all_gather's time on its side
+        # stream (overlapped with the forwards; its share of the step says how close it is to becoming the critical path)
+        multi_gpu = None
         if use_dist:
+            spans = gather_spans[-max(1, (args.steps + G - 1) // G):]
+            gms = sum(a.elapsed_time(b) for a, b in spans) / max(args.steps, 1) if spans else 0.0
+            mine = torch.tensor([elapsed / args.steps * 1e3, gms], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            multi_gpu = {'per_rank_ms_per_step': [round(float(t[0]), 3) for t in allr],
+                         'per_rank_gather_ms_per_step': [round(float(t[1]), 4) for t in allr],
+                         'gather_share_of_step': round(max(float(t[1]) for t in allr) / max(float(t[0]) for t in allr), 4),
+                         'note': 'each rank times its own K steps (barrier before and after); value uses the max; the all_gather of the '
+                                 'detection records runs on a side stream, one per %d steps, overlapped with the following forwards' % G}
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el[0])
 
@@ -517,6 +543,10 @@ def main():
         single = None
         if S > 1:
             engine.set_tune_mode('isolated')       # one batch at a time runs on the plans tuned for that (the first step re-tunes / re-records)
+            headline_plans = dict(engine._TUNED)
+            if shipped:                            # ... which are the in-situ tuner's own picks, not the throughput-tuned file
+                engine._TUNED.clear()
+                engine.PLAN_EPOCH += 1
             serial_step()
             torch.cuda.synchronize()
             if use_dist:
@@ -535,8 +565,14 @@ def main():
             if use_dist:
                 dist.all_reduce(e1, op=dist.ReduceOp.MAX)
             single = {'value': round(args.steps * B * world / float(e1[0]), 3), 'unit': 'stereo pairs/s',
-                      'ms_per_step': round(float(e1[0]) / args.steps * 1e3, 3), 'tuner_objective': 'isolated'}
+                      'ms_per_step': round(float(e1[0]) / args.steps * 1e3, 3), 'plans': 'in-situ tuner, every launch timed alone on the chip'}
             engine.set_tune_mode(tune_mode, S)     # back to the headline's plan set (already tuned: nothing is timed again)
+            if shipped:
+                insitu = dict(engine._TUNED)
+                engine._TUNED.clear()
+                engine._TUNED.update(insitu)       # shapes only the serial leg met keep their in-situ plan
+                engine._TUNED.update(headline_plans)
+                engine.PLAN_EPOCH += 1
 
         # ---- the product's default flow of the same step: keypoint branch after class NMS, on the kept detections only
         lazy_fig = None
@@ -684,6 +720,12 @@ def main():
                                      'frac': round(alg_step / (head_ms * 1e-3) / 1e12 / peak, 4),
                                      'issued_mfma_frac': round(alg_step / (head_ms * 1e-3) / 1e12 * issued / peak, 4),
                                      'step_ms_of_this_execution': round(head_ms, 3)},
+                        'sustained_peak': {'value': layer_table.SUSTAINED_MFMA_PEAK[args.precision] / 1e12, 'unit': 'TFLOP/s issued',
+                                           'frac_of_it': round(achieved * issued * 1e12 / layer_table.SUSTAINED_MFMA_PEAK[args.precision], 4),
+                                           'headline_frac_of_it': round(alg_step / (head_ms * 1e-3) * issued / layer_table.SUSTAINED_MFMA_PEAK[args.precision], 4),
+                                           'source': layer_table.SUSTAINED_SOURCE if args.precision == 'f16x3' else 'fp32 MFMA: the spec peak is sustained (MI355X_MICROARCH.md)',
+                                           'note': '`frac` above stays against the 2.5 PF dense peak; this is what the same instruction stream sustains on this power-limited chip'},
+                        'backbone': layer_table.backbone(rows, args.precision),
                         'layers_summary': layer_table.summary(rows),
                         'layers_note': 'per conv launch alone on the chip: own bound = max(MFMA flops issued / dense MFMA peak, compulsory '
                                        'bytes / 6.3 TB/s achievable HBM); groups pool launches of one layer shape; sorted by time lost',
@@ -774,12 +816,15 @@ def main():
                        'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
                        'host_enqueue_ms_per_step_idle_gpu': round(host_enqueue_idle_ms, 3), 'plans_preloaded': plans_loaded,
                        'conv_engine': args.precision, 'pairs_in_flight': S * B, 'batches_in_flight': S,
+                       'shipped_plans': ('%d conv plans from stereo_rcnn_amd/plans/mi355x.json: tuned on an MI355X with the measured %d-in-flight step '
+                                         'as objective (stereo_rcnn_amd/tune.py); one_pair_at_a_time runs on the in-situ tuner\'s own picks' % (shipped, S)) if shipped else None,
                        'tuner_objective': ('concurrent: every conv plan timed with %d copies of the launch in flight on %d HIP streams (the regime '
                                            '`value` is measured in)' % (S, S)) if tune_mode == 'concurrent' and S > 1 else 'isolated: every conv plan timed alone on the chip',
                        'input': 'the same synthetic pair(s) every step (resident in HBM; the forward has no data-dependent control flow on the host)',
                        'one_pair_at_a_time': single, 'engines': engines,
                        'keypoints_on_kept_detections_only': lazy_fig,
                        'full_3d_flow': full3d,
+                       'multi_gpu': multi_gpu,
                        'parallelism': ('pairs sharded %d/GPU per step, one RCCL all_gather of the detection records per %d steps' % (B, G)) if use_dist else 'single GPU'},
             'roofline': roofline,
         }

@@ -195,6 +195,19 @@ def tune_mode_key():
     return ('conc', TUNE_STREAMS) if TUNE_MODE == 'concurrent' and TUNE_STREAMS > 1 else ()
 
 
+# Bumped by whoever rewrites _TUNED under a model that already recorded launch programs (tune.tune_throughput, load_plans):
+# every Plan compares it in run() and re-records.  KEY_HITS: while a dict, conv2d counts the launches per plan key.
+PLAN_EPOCH = 0
+KEY_HITS = None
+
+
+def set_plan(key, plan):
+    """Overwrite the tuned plan of one shape key; recorded launch programs are re-recorded on their next run."""
+    global PLAN_EPOCH
+    _TUNED[tuple(key)] = tuple(plan)
+    PLAN_EPOCH += 1
+
+
 def plan_lds_kb(mr, nr, waves, stages):
     return stages * 128 * 64 * (mr + nr) // 1024
 
@@ -211,8 +224,10 @@ def load_plans(path):
     import json
     with open(path) as f:
         rows = json.load(f)
+    global PLAN_EPOCH
     for k, v in rows:
         _TUNED[tuple(k)] = tuple(v)
+    PLAN_EPOCH += 1
     return len(rows)
 
 
@@ -398,6 +413,8 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt) + (('lim', m_limit_mul) if m_limit is not None else ())
                          + (('x2', cw.cin2, cw.stride2, H2, W2) if x2 is not None else ()) + tune_mode_key())
         plan = _TUNED.get(key)
+        if KEY_HITS is not None:
+            KEY_HITS[key] = KEY_HITS.get(key, 0) + 1
         if plan is None:
             if torch.cuda.is_current_stream_capturing() or _lib.lib().srcnn_program_recording():
                 plan = (0, 0, 0, 0, 0)    # never time inside a graph capture / program recording; warm-up runs tune first

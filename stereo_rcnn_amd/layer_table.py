@@ -95,6 +95,30 @@ def summary(rows):
             'time_in_hbm_bound_launches_us': round(sum(r['us'] for r in rows if r['bound'] == 'hbm'), 1)}
 
 
+# Sustained rate of the engine's own MFMA pattern on random data with the K loop's LDS fragment reads, all 256 CUs, 2.5 s
+# (profiles/mfma_sustained_r04.txt, tools/mfma_sustained.py): the chip is power-limited there (~1.29 kW at 1.72 GHz) -- the
+# same pattern on zero data runs at 2.39 GHz / 2.2 PF.  Register-resident without the LDS reads: 1681 TF (random), 2459 (zeros).
+SUSTAINED_MFMA_PEAK = {'f16x3': 1.504e15, 'f32': 157.3e12}
+SUSTAINED_SOURCE = 'profiles/mfma_sustained_r04.txt: 3 x v_mfma_f32_32x32x16_f16 per accumulator + 8 ds_read_b128 per 12 MFMAs, random data, 256 CUs, 1.72 GHz at 1.28 kW'
+
+
+def backbone(rows, precision='f16x3'):
+    """The north star's MFMA target is stated on the backbone: the trunk's conv launches (stem + layer1..4) pooled -- their
+    algorithmic GFLOP over their summed time (each launch alone on the chip), as achieved TFLOP/s, as issued-MFMA fraction of
+    the 2.5 PF dense peak, and against the sustained peak above."""
+    tr = [r for r in rows if r['name'] == 'stem' or r['name'].startswith('layer')]
+    if not tr:
+        return None
+    us = sum(r['us'] for r in tr)
+    fl = sum(r['flops'] for r in tr)
+    ach = fl / us / 1e6
+    return {'launches': len(tr), 'algorithmic_gflop': round(fl / 1e9, 1), 'conv_us': round(us, 1), 'achieved_tflops': round(ach, 1),
+            'frac_of_peak_algorithmic': round(ach * 1e12 / MFMA_PEAK[precision], 4),
+            'issued_mfma_frac_of_peak': round(ach * 1e12 * ISSUED[precision] / MFMA_PEAK[precision], 4),
+            'issued_mfma_frac_of_sustained_peak': round(ach * 1e12 * ISSUED[precision] / SUSTAINED_MFMA_PEAK[precision], 4),
+            'note': 'trunk conv launches (stem, layer1-4), each alone on the chip; the max-pool between stem and layer1 is not a conv launch'}
+
+
 def top_for_json(rows, n=15):
     res = []
     for g in grouped(rows)[:n]:

@@ -171,7 +171,7 @@ class Plan(object):
         # sets or clears it, and it lives on the plan's device
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self._calib = None      # group -> max |value| while calibrate() runs
-        self._epoch = (weights.calib_epoch, engine.tune_mode_key())
+        self._epoch = (weights.calib_epoch, engine.tune_mode_key(), engine.PLAN_EPOCH)
         self._buf_shift = {}    # data_ptr -> shift of the tensor the buffer holds after the last run (as_f32 undoes it)
         self.graphs = {}
         self.programs = {}      # precision -> (native launch program handle, buffers it keeps alive); run(use_program=True)
@@ -587,7 +587,7 @@ class Plan(object):
         self.fmt = _lib.FMT_SPLIT16 if precision == 'f16x3' else _lib.FMT_F32
         if self.fmt and engine.ACT_SCALES and not self.w.calibrated:
             self.calibrate()               # once per weights: the scales of every SPLIT16 tensor group, from this first input
-        epoch = (self.w.calib_epoch, engine.tune_mode_key())
+        epoch = (self.w.calib_epoch, engine.tune_mode_key(), engine.PLAN_EPOCH)
         if self._epoch != epoch:      # the scales, or the tuner's objective (= the plan set), changed since this plan recorded its launch lists
             for prog, _ in self.programs.values():
                 _lib.lib().srcnn_program_destroy(prog)
