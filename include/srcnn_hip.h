@@ -152,13 +152,6 @@ typedef struct srcnn_conv_desc {
     const void *x2;
     int Cin2, H2, W2, x2_cstride, stride2;
 } srcnn_conv_desc;
-/* Workspace (splits > 1 only; srcnn_conv2d_workspace_bytes gives the size): [SRCNN_SPLITK_HEADER_BYTES of per-output-tile
- * arrival counters][splits slabs of M x Cout floats].  The SPLIT16 f16x3 engine sums the K slices of a tile INSIDE the conv
- * launch (the slice that arrives last re-reads all slabs in slice order: the same sum as the separate reduction launch the
- * other engines use, bit for bit).  Contract: the counter header must be ZERO when the first launch that uses a workspace
- * starts (zero it once, when the workspace is allocated); every launch leaves it zero.  Launches that share a workspace
- * must be ordered on one stream; concurrent streams need their own workspaces. */
-#define SRCNN_SPLITK_HEADER_BYTES 16384
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
 

@@ -161,9 +161,7 @@ def stream():
 
 
 class Workspace(object):
-    """Grow-only device scratch owned by the caller side (one per device).  Allocated ZEROED: the head of a split-K conv
-    workspace holds the per-tile arrival counters of the in-launch reduction, which every launch expects to be zero and
-    leaves zero (include/srcnn_hip.h, srcnn_conv2d)."""
+    """Grow-only device scratch owned by the caller side (one per device)."""
 
     def __init__(self):
         self.buf = None
@@ -171,7 +169,7 @@ class Workspace(object):
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self.buf
 
 

@@ -36,15 +36,7 @@ struct ConvArgs {
     // the ResNet projection shortcut computed by the block's last conv itself.  nullptr = none.
     const float *x2;
     int Cin2, H2, W2, xcs2, stride2;
-    // SPLIT16 engine, split-K: per-output-tile arrival counters (zero before the launch, left zero by it).  Non-null = the
-    // K slices of a tile are summed INSIDE the conv launch by the slice that arrives last (conv_f16s.hip); nullptr = the
-    // separate deterministic reduction launch (splitk_reduce_kernel).
-    unsigned *counters;
-    size_t partial_bytes;        // bytes of the split-K slabs behind `partial` (buffer-descriptor range of the in-launch reduction)
 };
-
-// Head of the conv workspace when splits > 1: room for the arrival counters (one u32 per output tile; <= 4096 tiles).
-constexpr size_t SPLITK_HEADER_BYTES = SRCNN_SPLITK_HEADER_BYTES;   // include/srcnn_hip.h
 
 
 // ---- "split16" activation format: per pixel, every group of 8 channels is stored as
@@ -142,6 +134,5 @@ struct Plan {
 void launch_conv_f16x3(const ConvArgs &a, const Plan &pl, hipStream_t st);   // A operand fp32 in HBM
 void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st);    // A operand split16 in HBM
 bool conv_f16s_plan_ok(const Plan &pl, const ConvArgs &a);
-bool conv_f16s_can_fuse_splitk(const Plan &pl);
 
 }  // namespace srcnn

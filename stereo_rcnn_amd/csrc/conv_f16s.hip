@@ -97,29 +97,6 @@ __device__ __forceinline__ void wait_vm_barrier_timed(unsigned long long &w_vm, 
 
 extern __shared__ __attribute__((aligned(1024))) _Float16 smem[];
 
-// 16-byte accesses to the split-K slabs with the sc1 bit (aux = 16 on gfx950): stores are written through to memory, loads are
-// never served from a (possibly stale) line of this XCD's L2 -- the placement-independent hand-off between workgroups of one
-// launch (MI355X_MICROARCH.md, inter-workgroup visibility: "16 B sc1 stores AND sc1 loads").
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 slab_load16(rsrc_t rsrc, int voff)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 16);
-#else
-    (void)rsrc; (void)voff;
-    return u32x4{0, 0, 0, 0};
-#endif
-}
-__device__ __forceinline__ void slab_store16(rsrc_t rsrc, int voff, float a, float b, float c, float d)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 16);
-#else
-    (void)rsrc; (void)voff; (void)a; (void)b; (void)c; (void)d;
-#endif
-}
-
 // MR/NR: per-WAVE tile in 32x32 MFMA tiles; WM x 2 waves per workgroup -> workgroup tile (32*MR*WM) x (64*NR).
 // WM = 2: 4 waves (256 threads).  WM = 4: 8 waves (512 threads).  NS: LDS ring stages (NS-1 K tiles in flight).
 template <int MR, int NR, bool OUT_SPLIT, int WM, int NS>
@@ -637,36 +614,20 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
         // deconv (mode 1): column = (tap ij, channel co); the 8-channel group never straddles a tap
         const int ij = p.mode == 1 ? col / cq : 0;
         const int co = col - ij * cq;
-        // split-K.  p.counters == nullptr: every slice writes its slab, a second launch (splitk_reduce_kernel) sums them.
-        // p.counters != nullptr: IN-LAUNCH reduction -- every slice publishes its slab with write-through (sc1) stores, then
-        // takes a ticket on the tile's arrival counter; the slice that arrives last re-reads ALL slabs (sc1 loads: served
-        // from memory / the Infinity Cache, never from a stale line of this XCD's L2), sums them in slice order -- the same
-        // sum in the same order as the separate launch, bit for bit -- and runs the ordinary epilogue on the total.  No
-        // fences (an agent-scope release would write back this XCD's whole L2: round 1's version of this lost to the
-        // second launch for that reason, profiles/splitk_fused_vs_separate_r01.txt), no waiting: nobody spins.
-        // (not in the 256x256 tile: its 128 accumulators leave no registers for the slab sums -- the host never gives it counters)
-        constexpr bool CAN_FUSE = !(MR == 2 && NR == 4 && WM == 4 && NS == 2);
-        const bool fused = CAN_FUSE && split && p.counters != nullptr;
-        const bool finals = !split || fused;                 // this workgroup may run the bias / residual / store path
-        const bool use_res = p.res && finals && col_ok;
+        const bool use_res = p.res && !split && col_ok;
         float bias8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-        if (p.bias && finals && col_ok) {
+        if (p.bias && !split && col_ok) {
             const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co);
             const float4 b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4);
             bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
             bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
         }
-        const rsrc_t rpart = make_rsrc(p.partial, p.partial_bytes);          // the slabs, for the sc1 accesses
-        const size_t slab_stride = (size_t)p.M * p.Cout * 4;                  // bytes per slice
         // one pass as a function of the COMPILE-TIME pass index: a run-time `ps` loop that the optimizer declines to unroll
-        // (it did, for the two-pass tiles) would index the accumulators dynamically and push all of them into scratch.
-        // MODE 0: accumulators -> final result (no split).  MODE 1: accumulators -> this slice's slab.  MODE 2 (last
-        // arriver of a fused split): sum of all slabs -> final result; the accumulators are dead by then.
-        auto one_pass = [&](auto ps_c, auto mode_c) __attribute__((always_inline)) {
+        // (it did, for the two-pass tiles) would index the accumulators dynamically and push all of them into scratch
+        auto one_pass = [&](auto ps_c) __attribute__((always_inline)) {
             constexpr int ps = decltype(ps_c)::value;
-            constexpr int MODE = decltype(mode_c)::value;
             const int mp = m0 + ps * RPP;                    // first output row of this pass
             // residual groups put in flight BEFORE the accumulators go through the LDS: all NG of them, except for the
             // 256x256 tile, whose 128 live accumulators leave room for 4 (the rest are loaded where they are used; a spill
@@ -683,92 +644,38 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
                     rb = *reinterpret_cast<const uint4 *>(q + 16);
                 }
             };
-            if (MODE != 1) {
 #pragma unroll
-                for (int it = 0; it < PF; ++it) load_res(it, res_a[it], res_b[it]);
-            }
-            // MODE 2: the slabs of this thread's NG groups, summed in slice order (depth-2 pipeline over the slices, CH groups
-            // at a time: the compiler counts these loads itself -- buffer loads with the sc1 bit, not inline asm)
-            constexpr int CH = NG < 4 ? NG : 4;
-            float8 pv[MODE == 2 ? NG : 1];
-            if constexpr (MODE == 2) {
-                const int S = (int)gridDim.y;
+            for (int it = 0; it < PF; ++it) load_res(it, res_a[it], res_b[it]);
+            if (ps > 0) __syncthreads();                     // the previous pass has been read out of the tile
 #pragma unroll
-                for (int c0 = 0; c0 < NG; c0 += CH) {
-                    u32x4 la[2][CH], lb[2][CH];
-                    auto issue = [&](int s, int buf) __attribute__((always_inline)) {
+            for (int i = 0; i < MR; ++i) {
+                const int rb = (wm * MR + i) * 32 - ps * RPP;     // this 32-row block inside the pass (wave-uniform)
+                if (PASSES == 1 || (rb >= 0 && rb < RPP)) {
 #pragma unroll
-                        for (int c = 0; c < CH; ++c) {
-                            const int row = mp + r0 + (c0 + c) * RSTEP;
-                            const int voff = (row < p.M && col_ok) ? (int)((size_t)s * slab_stride + ((size_t)row * p.Cout + col) * 4) : OOB;
-                            la[buf][c] = slab_load16(rpart, voff);
-                            lb[buf][c] = slab_load16(rpart, voff == OOB ? OOB : voff + 16);
+                    for (int j = 0; j < NR; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int r = rb + (e & 3) + 8 * (e >> 2) + 4 * lg;
+                            tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
                         }
-                    };
-                    auto add = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int c = 0; c < CH; ++c) {
-                            float8 &v = pv[c0 + c];
-                            v.v[0] += __uint_as_float(la[buf][c][0]); v.v[1] += __uint_as_float(la[buf][c][1]);
-                            v.v[2] += __uint_as_float(la[buf][c][2]); v.v[3] += __uint_as_float(la[buf][c][3]);
-                            v.v[4] += __uint_as_float(lb[buf][c][0]); v.v[5] += __uint_as_float(lb[buf][c][1]);
-                            v.v[6] += __uint_as_float(lb[buf][c][2]); v.v[7] += __uint_as_float(lb[buf][c][3]);
-                        }
-                    };
-#pragma unroll
-                    for (int c = 0; c < CH; ++c)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pv[c0 + c].v[e] = 0.f;
-                    issue(0, 0);
-                    for (int s = 0; s < S; s += 2) {
-                        if (s + 1 < S) issue(s + 1, 1);
-                        add(0);
-                        if (s + 2 < S) issue(s + 2, 0);
-                        if (s + 1 < S) add(1);
-                    }
                 }
-            } else {
-                if (ps > 0) __syncthreads();                     // the previous pass has been read out of the tile
-#pragma unroll
-                for (int i = 0; i < MR; ++i) {
-                    const int rb = (wm * MR + i) * 32 - ps * RPP;     // this 32-row block inside the pass (wave-uniform)
-                    if (PASSES == 1 || (rb >= 0 && rb < RPP)) {
-#pragma unroll
-                        for (int j = 0; j < NR; ++j)
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const int r = rb + (e & 3) + 8 * (e >> 2) + 4 * lg;
-                                tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
-                            }
-                    }
-                }
-                __syncthreads();
             }
-            if (p.stamp && ps == 0 && MODE != 2) st4 = __builtin_readcyclecounter();
+            __syncthreads();
+            if (p.stamp && ps == 0) st4 = __builtin_readcyclecounter();
 #pragma unroll
             for (int it = 0; it < NG; ++it) {
                 const int r = r0 + it * RSTEP;
                 const int row = mp + r;
                 if (row < p.M && col_ok) {
                     float8 v;
-                    if constexpr (MODE == 2) {
-                        v = pv[it];
-                    } else {
-                        const float4 a = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8);
-                        const float4 b = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8 + 4);
-                        v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
-                        v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
-                    }
-                    if constexpr (MODE == 1) {
-                        if (CAN_FUSE && fused) {                // write-through: visible to the last arriver on any XCD
-                            const int voff = (int)((size_t)blockIdx.y * slab_stride + ((size_t)row * p.Cout + col) * 4);
-                            slab_store16(rpart, voff, v.v[0], v.v[1], v.v[2], v.v[3]);
-                            slab_store16(rpart, voff + 16, v.v[4], v.v[5], v.v[6], v.v[7]);
-                        } else {
-                            float *dst = p.partial + ((size_t)blockIdx.y * p.M + row) * p.Cout + col;
-                            *reinterpret_cast<float4 *>(dst) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
-                            *reinterpret_cast<float4 *>(dst + 4) = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]);
-                        }
+                    const float4 a = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8);
+                    const float4 b = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8 + 4);
+                    v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
+                    v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+                    if (split) {
+                        float *dst = p.partial + ((size_t)blockIdx.y * p.M + row) * p.Cout + col;
+                        *reinterpret_cast<float4 *>(dst) = a;
+                        *reinterpret_cast<float4 *>(dst + 4) = b;
                     } else {
                         if (p.bias) {
 #pragma unroll
@@ -820,38 +727,9 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
                 }
             }
         };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
+        one_pass(std::integral_constant<int, 0>{});
+        if constexpr (PASSES > 1) one_pass(std::integral_constant<int, 1>{});
         static_assert(PASSES <= 2, "epilogue passes");
-        bool last = false;
-        if (!split) {
-            one_pass(I0{}, I0{});
-            if constexpr (PASSES > 1) one_pass(I1{}, I0{});
-        } else {
-            one_pass(I0{}, I1{});
-            if constexpr (PASSES > 1) one_pass(I1{}, I1{});
-            if constexpr (CAN_FUSE) if (fused) {
-                // every slab store of this workgroup has been written through before its ticket is taken (hand-written wait:
-                // the compiler may not drop it), then ONE lane arrives; the counter goes back to zero for the next launch
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (t == 0) {
-                    const unsigned old = __hip_atomic_fetch_add(p.counters + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool l = old + 1 == gridDim.y;
-                    if (l) __hip_atomic_store(p.counters + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *reinterpret_cast<volatile int *>(smem) = l ? 1 : 0;     // the transposition tile is dead (barrier above): its first word
-                }
-                __syncthreads();
-                last = *reinterpret_cast<volatile int *>(smem) != 0;
-            }
-        }
-        if constexpr (CAN_FUSE) {
-            if (last) {
-                one_pass(I0{}, I2{});
-                if constexpr (PASSES > 1) one_pass(I1{}, I2{});
-            }
-        }
         if (p.stamp && t == 0) {
             unsigned long long *o = p.stamp + 16 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
             o[8] = rt0;
@@ -943,9 +821,6 @@ bool conv_f16s_plan_ok(const Plan &pl, const ConvArgs &a)
     default: return false;
     }
 }
-
-// may the K slices of this plan be summed inside the launch (ConvArgs::counters)?  Every tile but the 256x256 one.
-bool conv_f16s_can_fuse_splitk(const Plan &pl) { return !(pl.mr == 4 && pl.nr == 4); }
 
 void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st)
 {

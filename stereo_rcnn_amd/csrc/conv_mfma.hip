@@ -211,11 +211,27 @@ __global__ void splitk_reduce_kernel(const ConvArgs p, int splits)
             float8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] = 0.f;
-            for (int s = 0; s < splits; ++s) {
-                const float *src = p.partial + (size_t)s * total + row * p.Cout + g * 8;
-                const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
-                v.v[0] += a.x; v.v[1] += a.y; v.v[2] += a.z; v.v[3] += a.w;
-                v.v[4] += b.x; v.v[5] += b.y; v.v[6] += b.z; v.v[7] += b.w;
+            // four slices' loads in flight per step (independent 32-byte reads; a one-slice-per-iteration loop serialises one memory
+            // round trip per slice), added in slice order: the sum is the same as before, bit for bit
+            for (int s0 = 0; s0 < splits; s0 += 4) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    b[j] = a[j];
+                    if (s0 + j < splits) {
+                        const float *src = p.partial + (size_t)(s0 + j) * total + row * p.Cout + g * 8;
+                        a[j] = *reinterpret_cast<const float4 *>(src);
+                        b[j] = *reinterpret_cast<const float4 *>(src + 4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (s0 + j < splits) {
+                        v.v[0] += a[j].x; v.v[1] += a[j].y; v.v[2] += a[j].z; v.v[3] += a[j].w;
+                        v.v[4] += b[j].x; v.v[5] += b[j].y; v.v[6] += b[j].z; v.v[7] += b[j].w;
+                    }
+                }
             }
             if (p.bias) {
 #pragma unroll
@@ -354,8 +370,6 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     a.m_limit = d->m_limit;
     a.m_limit_mul = d->m_limit_mul;
     if (a.m_limit) SRCNN_REQUIRE(d->precision == 1 && d->x_format == 1 && d->m_limit_mul > 0, "m_limit: SPLIT16 f16x3 engine, m_limit_mul > 0");
-    a.counters = nullptr;
-    a.partial_bytes = 0;
     a.x2 = static_cast<const float *>(d->x2);
     a.Cin2 = a.H2 = a.W2 = a.xcs2 = a.stride2 = 0;
     if (a.x2) {
@@ -404,8 +418,6 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
     return SRCNN_OK;
 }
 
-static int g_fused_splitk = -1;      // debug override of the in-launch split-K reduction (-1 = SRCNN_FUSED_SPLITK / default on)
-
 template <int MR, int NR>
 static void launch(const ConvArgs &a, int splits, hipStream_t st)
 {
@@ -416,10 +428,6 @@ static void launch(const ConvArgs &a, int splits, hipStream_t st)
 
 extern "C" {
 
-// debug hook (not part of include/srcnn_hip.h): 1 / 0 = force the in-launch split-K reduction of the SPLIT16 engine on / off
-// (off = the separate splitk_reduce_kernel launch every other engine uses), -1 = default.  The parity tests A/B the two.
-SRCNN_API void srcnn_debug_set_fused_splitk(int on) { srcnn::g_fused_splitk = on; }
-
 size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d)
 {
     using namespace srcnn;
@@ -427,7 +435,7 @@ size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d)
     if (fill_args(d, a) != SRCNN_OK) return 0;
     Plan pl = plan_for(d, a);
     if (pl.splits <= 1) return 256;
-    return align_up(SPLITK_HEADER_BYTES + (size_t)pl.splits * a.M * a.Cout * sizeof(float), 256);
+    return align_up((size_t)pl.splits * a.M * a.Cout * sizeof(float), 256);
 }
 
 int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream)
@@ -441,23 +449,12 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     a.mtiles = cdiv(a.M, 64 * pl.mr);
     a.ntiles = cdiv(a.Cout, 64 * pl.nr);
     if (pl.splits > 1) {
-        const size_t slabs = (size_t)pl.splits * a.M * a.Cout * sizeof(float);
-        const size_t need = SPLITK_HEADER_BYTES + slabs;
+        const size_t need = (size_t)pl.splits * a.M * a.Cout * sizeof(float);
         if (!workspace || workspace_bytes < need) {
             set_error("srcnn_conv2d: workspace too small (%zu < %zu)", workspace_bytes, need);
             return SRCNN_ERR_WORKSPACE;
         }
-        a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + SPLITK_HEADER_BYTES);
-        a.partial_bytes = slabs;
-        // SPLIT16 engine, vector epilogue: the slices of a tile are summed inside the conv launch by the last arriver (same
-        // sum, same order as splitk_reduce_kernel: bit-identical), counters at the head of the workspace
-        static const int fused_env = [] { const char *e = std::getenv("SRCNN_FUSED_SPLITK"); return e ? std::atoi(e) : 1; }();   // A/B switch
-        const int fused_default = g_fused_splitk >= 0 ? g_fused_splitk : fused_env;
-        const int cq = a.mode == 1 ? (a.Cout >> 2) : a.Cout;
-        const bool vec = (cq & 7) == 0 && (a.ycs & 7) == 0 && (a.yco & 7) == 0 && (!a.res || (a.rcs & 7) == 0);
-        if (fused_default && d->precision == 1 && a.x_fmt == 1 && vec && a.mode != 1 && conv_f16s_can_fuse_splitk(pl) &&
-            (size_t)a.mtiles * a.ntiles * sizeof(unsigned) <= SPLITK_HEADER_BYTES && slabs < 0x7fffffffull)
-            a.counters = static_cast<unsigned *>(workspace);
+        a.partial = static_cast<float *>(workspace);
     }
     hipStream_t st = as_stream(stream);
     const bool prof = prof_enabled();
@@ -468,7 +465,7 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     else if (pl.mr == 2 && pl.nr == 1) launch<2, 1>(a, pl.splits, st);
     else if (pl.mr == 1 && pl.nr == 2) launch<1, 2>(a, pl.splits, st);
     else launch<1, 1>(a, pl.splits, st);
-    if (pl.splits > 1 && !a.counters) {
+    if (pl.splits > 1) {
         const size_t total = (size_t)a.M * a.Cout;
         const int blocks = (int)min((size_t)2048, (total + 255) / 256);
         SRCNN_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a, pl.splits);

@@ -590,8 +590,8 @@ MIN_FRAC_NEW_SHAPES = 0.88
 
 @pytest.mark.parametrize("precision", ['f16x3', 'f32'])
 def test_hip_forward_at_kitti_370x1224_vs_reference_code_golden(dev, precision):
-    """KITTI's other common frame size, 370x1224 -> network input 600x1985: other ragged tails in every layer (odd widths at
-    every pyramid level) than 375x1242.  Against the reference code's outputs on the same frame (make_reference_golden.py
+    """KITTI's other common frame size, 370x1224 -> network input 600x1984 here (the synthetic fixture's resize; OpenCV's gives
+    1985): other ragged tails in every layer than 375x1242 -> 600x1987.  Against the reference code's outputs on the same frame (make_reference_golden.py
     kitti370), both conv engines."""
     from stereo_rcnn_amd import fixture
     g = np.load(os.path.join(GOLD, 'reference_net_full_370x1224_r101_seed4.npz'))
@@ -599,7 +599,7 @@ def test_hip_forward_at_kitti_370x1224_vs_reference_code_golden(dev, precision):
     m, _ = _build_model(dev)
     m.precision = precision
     l, r, info = fixture.make_inputs(seed, h, w, target_short=short)
-    assert list(l.shape) == list(g['input_shape']) == [1, 3, 600, 1985]
+    assert list(l.shape) == list(g['input_shape']) == [1, 3, 600, 1984]      # fixture.make_inputs' own resize (truncating) of 370x1224
     with torch.no_grad():
         out = m(l.to(dev), r.to(dev), info.to(dev))
         torch.cuda.synchronize()

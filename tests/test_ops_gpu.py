@@ -289,99 +289,6 @@ def test_conv_f16s_plans_of_one_order_class_give_the_same_bits(dev, plans):
         assert torch.equal(y, first), plan
 
 
-def _fused_splitk(on):
-    import ctypes
-    from stereo_rcnn_amd import _lib
-    fn = _lib.lib().srcnn_debug_set_fused_splitk
-    fn.argtypes, fn.restype = [ctypes.c_int], None
-    fn(on)
-
-
-@pytest.mark.parametrize("plan", [(1, 1, 4, 4, 3), (2, 1, 4, 3, 2), (1, 2, 4, 3, 5), (2, 2, 4, 2, 2), (2, 2, 8, 2, 3), (2, 2, 8, 4, 9),
-                                  (4, 2, 8, 3, 4), (4, 4, 8, 2, 3)])
-@pytest.mark.parametrize("case", [
-    # B, H, W, cin, cout, k, pad, residual, mode
-    (2, 23, 37, 96, 200, 3, 1, True, 0),        # ragged M (1702) and N (200) tails, image-border taps, SPLIT16 residual
-    (2, 38, 125, 256, 256, 3, 1, False, 0),     # layer3 conv2
-    (2, 19, 63, 1024, 512, 1, 0, False, 0),     # layer4-like 1x1, long K
-    (2, 10, 32, 256, 512, 3, 1, False, 2),      # the stereo RPN conv as one launch over both eyes (mode 2)
-])
-def test_conv_f16s_in_launch_splitk_reduction_equals_the_separate_launch_bit_for_bit(dev, plan, case):
-    """Split-K of the SPLIT16 engine: the K slices of a tile summed INSIDE the conv launch by the last-arriving slice (sc1
-    slab stores / loads, per-tile arrival counter) against the separate deterministic splitk_reduce_kernel launch -- the same
-    slabs summed in the same order: every output bit equal, and the counters at the head of the workspace back at zero.
-    ((4, 4, 8, 2, s): the 256x256 tile keeps the separate launch -- the switch must be a no-op there.)"""
-    from stereo_rcnn_amd import _lib, engine
-    B, H, W, cin, cout, k, pad, res, mode = case
-    g = torch.Generator().manual_seed(cin + cout + k + plan[4])
-    x = engine.act_convert(torch.randn(B, H, W, cin, generator=g).to(dev), 0, 1)
-    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
-    cw = engine.prep_conv(w, torch.randn(cout, generator=g), 1, pad, True, device=dev)
-    if mode == 2:
-        cw = engine.ConvW(cw.weight, cw.bias, k, k, 1, pad, True, mode=2)
-    r = engine.act_convert(torch.randn(B, H, W, cout, generator=g).to(dev), 0, 1) if res else None
-    outs = []
-    try:
-        for fused in (0, 1, 1):
-            _fused_splitk(fused)
-            y = torch.zeros((B // 2 if mode == 2 else B, H, W, cout * (2 if mode == 2 else 1)), device=dev)
-            engine.conv2d(cw, x, B, H, W, y, H, W, residual=r, precision='f16x3', x_fmt=1, y_fmt=1, res_fmt=1 if res else 0, plan=plan,
-                          y_cstride=cout * 2 if mode == 2 else None)
-            torch.cuda.synchronize()
-            outs.append(y.view(torch.int32).cpu())
-    finally:
-        _fused_splitk(-1)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), plan
-    ws = _lib.workspace(256, dev, "conv")
-    assert not bool(ws[:16384].any()), "arrival counters not back at zero"
-
-
-def test_conv_f16s_in_launch_splitk_reduction_under_uneven_concurrent_load(dev):
-    """The hand-off of the in-launch reduction under the conditions that expose a stale or early read (MI355X guide: uneven
-    load, warm caches, every word checked): the layer3 conv2 launch with 3 K slices, 40 times back to back on each of three
-    streams (own workspace and output each, DIFFERENT inputs per stream), while a fourth stream keeps the chip busy with a
-    big conv -- every output of every repetition bit-equal to the separate-launch result of its stream's input."""
-    from stereo_rcnn_amd import _lib, engine
-    g = torch.Generator().manual_seed(17)
-    B, H, W, cin, cout = 2, 38, 125, 256, 256
-    w = torch.randn(cout, cin, 3, 3, generator=g) / 48.0
-    cw = engine.prep_conv(w, torch.randn(cout, generator=g), 1, 1, True, device=dev)
-    xs = [engine.act_convert(torch.randn(B, H, W, cin, generator=g).to(dev), 0, 1) for _ in range(3)]
-    bigx = engine.act_convert(torch.randn(2, 150, 497, 256, generator=g).to(dev), 0, 1)
-    bigw = engine.prep_conv(torch.randn(256, 256, 3, 3, generator=g) / 48.0, torch.zeros(256), 1, 1, True, device=dev)
-    bigy = torch.empty((2, 150, 497, 256), device=dev)
-    plan = (2, 2, 8, 2, 3)
-    try:
-        _fused_splitk(0)
-        want = []
-        for x in xs:
-            y = torch.zeros((B, H, W, cout), device=dev)
-            engine.conv2d(cw, x, B, H, W, y, H, W, precision='f16x3', x_fmt=1, y_fmt=1, plan=plan)
-            want.append(y.view(torch.int32).clone())
-        engine.conv2d(bigw, bigx, 2, 150, 497, bigy, 150, 497, precision='f16x3', x_fmt=1, y_fmt=1, plan=(4, 4, 8, 2, 1))
-        torch.cuda.synchronize()
-        _fused_splitk(1)
-        streams = [torch.cuda.Stream() for _ in range(4)]
-        reps = 40
-        ys = [[torch.zeros((B, H, W, cout), device=dev) for _ in range(reps)] for _ in range(3)]
-        torch.cuda.synchronize()
-        for rep in range(reps):
-            for i in range(3):
-                with torch.cuda.stream(streams[i]):
-                    engine.conv2d(cw, xs[i], B, H, W, ys[i][rep], H, W, precision='f16x3', x_fmt=1, y_fmt=1, plan=plan)
-            if rep % 2 == 0:
-                with torch.cuda.stream(streams[3]):
-                    engine.conv2d(bigw, bigx, 2, 150, 497, bigy, 150, 497, precision='f16x3', x_fmt=1, y_fmt=1, plan=(4, 4, 8, 2, 1))
-        torch.cuda.synchronize()
-        bad = [(i, rep) for i in range(3) for rep in range(reps) if not torch.equal(ys[i][rep].view(torch.int32), want[i])]
-        assert not bad, bad[:10]
-        for i in range(3):
-            with torch.cuda.stream(streams[i]):
-                assert not bool(_lib.workspace(256, dev, "conv")[:16384].any())
-    finally:
-        _fused_splitk(-1)
-
-
 @pytest.mark.parametrize("precision,W", [('f32', 131), ('f16x3', 131), ('f16x3+split16', 131), ('f16x3+split16', 130)])
 def test_conv_stem_vs_torch_cpu(dev, precision, W):
     """7x7/2 stem through the packed NHWC4 image; '+split16' = the packed image in SPLIT16 form read by the DMA engine
