@@ -8,8 +8,8 @@ batch=1, 300 proposals, no dense-align  (BASELINE.json configs[1]).
     python bench.py --config 4      # BASELINE configs[4]: ResNet-50 trunk, 2x resolution (network input 1200x3974), batch = 4
 (same JSON contract; `config.workload` names the BASELINE entry; the default, --config 1, is the headline.)
 
-One step = one pass of the hot path over one synthetic stereo pair per GPU (batch = 1 per forward; by default three
-forwards are in flight per GPU on separate HIP streams, `--streams 1` = strictly sequential, also reported):
+One step = one pass of the hot path over one synthetic stereo pair per GPU (batch = 1 per forward; by default four
+forwards are in flight per GPU, each on a HIP stream with a hardware queue of its own, `--streams 1` = strictly sequential, also reported):
   _StereoRCNN.forward (trunk+FPN on both eyes, stereo RPN, proposals, ROIAlign, heads)
   + detection decode + per-class NMS  (the reference's det_time region, demo.py:137-220, plus :231-257)
   + (under torch.distributed.run) the detection record of every step packed on the device and gathered over RCCL/xGMI,
@@ -285,7 +285,7 @@ def dry_run(args, rank, world):
 
 
 WORKLOADS = {
-    1: dict(layers=101, batch=1, streams=3, flow='2d',
+    1: dict(layers=101, batch=1, streams=4, flow='2d',
             text='BASELINE configs[1]: ResNet-101 FPN, batch=1 stereo pair per GPU, %(w)dx%(h)d synthetic (network input %(nw)dx%(nh)d), '
                  '300 proposals, forward + decode + class NMS, no dense-align'),
     2: dict(layers=101, batch=8, streams=2, flow='3d',
@@ -336,6 +336,9 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
     assert world == args.gpus or not use_dist, "launched with %d ranks for --gpus %d" % (world, args.gpus)
+    # every forward in flight on a hardware queue of its own: GPU_MAX_HW_QUEUES is read once, when HIP starts (stereo_rcnn_amd/streams.py)
+    from stereo_rcnn_amd import streams as sstreams
+    sstreams.ensure_hw_queues()
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -377,6 +380,7 @@ def main():
     # the multi-stream regime is tuned by the measured step itself instead (stereo_rcnn_amd/tune.py -> the shipped plan file)
     tune_mode = args.tune if args.tune != 'auto' else 'isolated'
     engine.set_tune_mode(tune_mode, S)
+    sstreams.set_pairs_in_flight(S)        # S > 1: branches stay on the forwards' main streams (stereo_rcnn_amd/streams.py)
     from stereo_rcnn_amd import tune as stune
     shipped = 0
     if not args.no_shipped_plans and not args.plans and tune_mode == 'isolated' and args.precision == 'f16x3':
@@ -390,7 +394,7 @@ def main():
                 model(im_l, im_r, im_info)
                 torch.cuda.synchronize()
         return
-    streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [None]
+    streams = sstreams.main_streams(S) if S > 1 else [None]
 
     # detections of G consecutive steps (B images each) are packed into one buffer and gathered by ONE RCCL all_gather
     # (two buffers alternate so that a gather in flight on the side stream never races the next writes)
@@ -543,6 +547,7 @@ def main():
         single = None
         if S > 1:
             engine.set_tune_mode('isolated')       # one batch at a time runs on the plans tuned for that (the first step re-tunes / re-records)
+            sstreams.set_pairs_in_flight(1)        # ... with the independent branches on side streams (latency mode)
             headline_plans = dict(engine._TUNED)
             if shipped:                            # ... which are the in-situ tuner's own picks, not the throughput-tuned file
                 engine._TUNED.clear()
@@ -567,6 +572,7 @@ def main():
             single = {'value': round(args.steps * B * world / float(e1[0]), 3), 'unit': 'stereo pairs/s',
                       'ms_per_step': round(float(e1[0]) / args.steps * 1e3, 3), 'plans': 'in-situ tuner, every launch timed alone on the chip'}
             engine.set_tune_mode(tune_mode, S)     # back to the headline's plan set (already tuned: nothing is timed again)
+            sstreams.set_pairs_in_flight(S)
             if shipped:
                 insitu = dict(engine._TUNED)
                 engine._TUNED.clear()
@@ -732,7 +738,7 @@ def main():
                         'layers': layer_table.top_for_json(rows, 15)}
             assert ms.value / nprof <= serial_ms * 1.02, "conv time exceeds the step time of its own execution"
             for pl in model._plans.values():
-                pl.overlap = True
+                pl.overlap = None                     # back to the regime's own choice
             # ---- the exact-fp32 engine as a first-class figure of the same line (short: fewer steps, its own plans)
             engines = {args.precision: {'value': round(args.steps * B * world / elapsed, 3), 'ms_per_step': round(head_ms, 3),
                                         'pairs_in_flight': S * B}}

@@ -370,6 +370,26 @@ SRCNN_API int srcnn_program_wait_event(void *prog, srcnn_stream_t stream, int ev
 SRCNN_API int srcnn_program_size(void *prog);                       /* recorded nodes */
 SRCNN_API int srcnn_program_run(void *prog, srcnn_stream_t main_stream);
 
+/* ------------------------------------------------------------------ streams with their own hardware queue
+ * HIP folds the streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues, least-used queue first.  Streams that
+ * share a queue execute in submission order and an event wait of one of them holds up everything queued behind it -- with
+ * several forwards in flight (one main stream + two side streams each) a side stream of forward A that waits for A's trunk
+ * stalls the main stream of forward B that happens to share its queue (profiles/queue_mapping_r04.txt).  A stream created
+ * here owns a hardware queue of its own (created with an all-ones CU mask: masked streams are never pooled), so that the
+ * placement of the forwards' streams is the caller's decision, not an accident of creation order.
+ * dedicated_queue = 0 gives an ordinary non-blocking stream from the shared pool. */
+SRCNN_API int srcnn_stream_create(int dedicated_queue, srcnn_stream_t *stream);
+/* The same with a caller-chosen CU mask (bit b of word b / 32 enables compute unit b of the device's enumeration; `words`
+ * 32-bit words, at least one bit set in them): the kernels of this stream run on those CUs only.  The serving regime gives each
+ * of S forwards in flight its own 1/S of every XCD's CUs (stereo_rcnn_amd/streams.py: partition_masks) -- a forward then never
+ * shares a CU with another forward's kernels, and its launches meet a device of 256/S CUs that their tile counts fill. */
+SRCNN_API int srcnn_stream_create_cu_mask(int words, const unsigned *mask, srcnn_stream_t *stream);
+SRCNN_API int srcnn_stream_destroy(srcnn_stream_t stream);
+/* Diagnostics: launches `blocks` one-wave workgroups on `stream`; block b writes its XCC_ID register to xcc[b] and its HW_ID
+ * register (CU / shader-array / shader-engine fields) to hw_id[b] (device int arrays of `blocks` entries).  Shows where a
+ * (masked) stream's workgroups actually run. */
+SRCNN_API int srcnn_probe_placement(int blocks, int *xcc, int *hw_id, srcnn_stream_t stream);
+
 /* ------------------------------------------------------------------ profiling hooks
  * When enabled, every conv-engine launch is bracketed by hipEvents on its stream; the
  * accumulated kernel time / algorithmic flops / launch count are read back with

@@ -110,6 +110,10 @@ _SIGNATURES = {
     "srcnn_program_wait_event": (c_int, [c_void_p, c_void_p, c_int]),
     "srcnn_program_size": (c_int, [c_void_p]),
     "srcnn_program_run": (c_int, [c_void_p, c_void_p]),
+    "srcnn_stream_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    "srcnn_stream_create_cu_mask": (c_int, [c_int, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(c_void_p)]),
+    "srcnn_stream_destroy": (c_int, [c_void_p]),
+    "srcnn_probe_placement": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "srcnn_prof_enable": (c_int, [c_int]),
     "srcnn_prof_read_launches": (c_int, [ctypes.POINTER(ctypes.c_float), c_int]),
     "srcnn_prof_read": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_double),

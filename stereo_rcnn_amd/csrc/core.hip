@@ -162,6 +162,78 @@ int srcnn_range_flag_bind(void *device_word)
     return SRCNN_OK;
 }
 
+// ---- streams that own a hardware queue (include/srcnn_hip.h)
+int srcnn_stream_create(int dedicated_queue, srcnn_stream_t *stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(stream, "null stream pointer");
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (dedicated_queue) {
+        // every CU enabled: the mask restricts nothing, it only takes the stream out of the pooled queues
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SRCNN_ERR_HIP;
+        const unsigned words = ((unsigned)prop.multiProcessorCount + 31u) / 32u;
+        unsigned mask[64];
+        SRCNN_REQUIRE(words >= 1 && words <= 64, "unexpected CU count");
+        for (unsigned i = 0; i < words; ++i) mask[i] = 0xffffffffu;
+        e = hipExtStreamCreateWithCUMask(&s, words, mask);
+    } else {
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    }
+    if (e != hipSuccess) {
+        set_error("srcnn_stream_create: stream creation failed");
+        return SRCNN_ERR_HIP;
+    }
+    *stream = reinterpret_cast<srcnn_stream_t>(s);
+    return SRCNN_OK;
+}
+
+int srcnn_stream_create_cu_mask(int words, const unsigned *mask, srcnn_stream_t *stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(stream && mask && words >= 1 && words <= 64, "null pointer or bad word count");
+    unsigned any = 0;
+    for (int i = 0; i < words; ++i) any |= mask[i];
+    SRCNN_REQUIRE(any != 0, "empty CU mask");
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) != hipSuccess) {
+        set_error("srcnn_stream_create_cu_mask: hipExtStreamCreateWithCUMask failed");
+        return SRCNN_ERR_HIP;
+    }
+    *stream = reinterpret_cast<srcnn_stream_t>(s);
+    return SRCNN_OK;
+}
+
+namespace srcnn {
+__global__ void placement_probe_kernel(int *xcc, int *hw_id)
+{
+    if (threadIdx.x == 0) {
+        xcc[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));     // XCC_ID, bits 3:0
+        hw_id[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID, all 32 bits
+    }
+    // stay resident for a moment so that the blocks spread over the CUs instead of reusing the first free one
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < 20000) {
+    }
+}
+}  // namespace srcnn
+
+int srcnn_probe_placement(int blocks, int *xcc, int *hw_id, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(blocks > 0 && xcc && hw_id, "bad arguments");
+    SRCNN_LAUNCH(placement_probe_kernel, blocks, 64, 0, as_stream(stream), xcc, hw_id);
+    return check_launch("srcnn_probe_placement");
+}
+
+int srcnn_stream_destroy(srcnn_stream_t stream)
+{
+    if (!stream) return SRCNN_OK;
+    return hipStreamDestroy(srcnn::as_stream(stream)) == hipSuccess ? SRCNN_OK : SRCNN_ERR_HIP;
+}
+
 // ---- launch programs (include/srcnn_hip.h)
 void *srcnn_program_create(void) { return new srcnn::Program(); }
 

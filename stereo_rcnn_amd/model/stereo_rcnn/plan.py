@@ -14,7 +14,7 @@ import ctypes
 
 import torch
 
-from ... import _lib, engine
+from ... import _lib, engine, streams
 from ..utils.config import cfg
 
 
@@ -174,15 +174,28 @@ class Plan(object):
         self._epoch = (weights.calib_epoch, engine.tune_mode_key(), engine.PLAN_EPOCH)
         self._buf_shift = {}    # data_ptr -> shift of the tensor the buffer holds after the last run (as_f32 undoes it)
         self.graphs = {}
-        self.programs = {}      # precision -> (native launch program handle, buffers it keeps alive); run(use_program=True)
+        self.programs = {}      # (precision, kpts, branches on side streams) -> (native launch program handle, buffers it keeps alive)
         self._rec = None        # program being recorded right now
         self.packed_fmt = -1    # format `packed` currently holds for the inputs of the NEXT run (-1: none, pack in trunk())
         self.fmt = 0            # activation format of the internal buffers for the current/last run
         # independent branches of the forward (FPN laterals, small RPN levels, box head vs keypoint head) are
         # issued on side streams with event fork/join, so eager runs AND the captured hipGraph execute them
         # concurrently with the critical path instead of serialising many small launches
-        self.overlap = True
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        # -- while ONE forward is in flight.  With several in flight the other forwards fill the chip, and side streams that
+        # share hardware queues with other forwards' main streams stall them (streams.py): `overlap` None = follow
+        # streams.branch_overlap(), True / False = forced (tools, the per-layer timing of bench.py)
+        self.overlap = None
+        self._side = None
+
+    def _par(self):
+        """branches on side streams in this run?"""
+        return streams.branch_overlap() if self.overlap is None else bool(self.overlap)
+
+    @property
+    def side(self):
+        if self._side is None:
+            self._side = streams.side_streams(2, self.dev) or [None, None]
+        return self._side
 
     # ------------------------------------------------------------------ activation scales (SPLIT16 engine)
     def _k(self, group):
@@ -344,8 +357,8 @@ class Plan(object):
         w, N, f = self.w, self.N, self.fmt
         (h2, w2), (h3, w3), (h4, w4), (h5, w5) = self.layer_hw
         c2, c3, c4, c5 = self.c
-        s_lat, s_rpn = self.side
-        par = self.overlap
+        par = self._par()
+        s_lat, s_rpn = self.side if par else (None, None)
         lat_done = []
         if par:
             self._fork(s_lat)
@@ -509,7 +522,7 @@ class Plan(object):
         the keypoints then come from kpts_for_kept after class NMS)."""
         if not kpts:
             self.box_head()
-        elif self.overlap:
+        elif self._par():
             side = self.side[0]
             self._fork(side)
             with torch.cuda.stream(side):
@@ -570,7 +583,7 @@ class Plan(object):
             self._rec = None
             _lib._recording_refs = None
             _lib.check(L.srcnn_program_end(prog), "srcnn_program_end")
-        self.programs[(precision, kpts) if not kpts else precision] = (prog, refs)
+        self.programs[(precision, kpts, self._par())] = (prog, refs)
         return prog
 
     def run(self, use_graph=False, precision='f32', use_program=False, kpts=True):
@@ -595,7 +608,7 @@ class Plan(object):
         try:
             if use_program and not use_graph:
                 self.packed_fmt = -1                  # the recorded list always contains the stem_pack launches
-                ent = self.programs.get((precision, kpts) if not kpts else precision)
+                ent = self.programs.get((precision, kpts, self._par()))      # one list per (engine, branch, stream regime)
                 prog = ent[0] if ent else self._record_program(precision, kpts)
                 _lib.check(_lib.lib().srcnn_program_run(prog, torch.cuda.current_stream().cuda_stream), "srcnn_program_run")
                 return

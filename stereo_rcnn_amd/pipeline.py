@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib, postprocess
+from . import streams as _streams
 from .model.dense_align.dense_align import MAX_PIXELS, align_parallel, check_status
 from .model.utils import box_estimator, kitti_utils
 from .model.utils.config import cfg
@@ -504,7 +505,8 @@ def _slot_streams(n):
     dev = torch.cuda.current_device()
     have = _stream_cache.setdefault(dev, [])
     while len(have) < n:
-        have.append(torch.cuda.Stream())
+        have.append(_streams.new_stream(_streams.MAIN_KIND if _streams.MAIN_KIND in _streams.KINDS else 'dedicated'))
+    _streams.set_pairs_in_flight(n)           # n > 1: the plans keep their branches on the main streams (streams.py)
     return have[:n]
 
 

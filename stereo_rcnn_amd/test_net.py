@@ -127,6 +127,8 @@ def main(argv=None):
     args = ap.parse_args(argv)
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     use_dist = 'RANK' in os.environ and world > 1
+    from . import streams as _streams
+    _streams.ensure_hw_queues()          # before HIP starts: one hardware queue per pair in flight (streams.py)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

@@ -19,6 +19,7 @@ import time
 import torch
 
 from . import engine
+from . import streams as _streams
 from . import postprocess as hpost
 
 PLANS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'plans')
@@ -42,7 +43,7 @@ class StepRunner(object):
 
     def __init__(self, model, im_l, im_r, im_info, streams=3, kpts=True):
         self.model, self.inputs, self.S, self.kpts = model, (im_l, im_r, im_info), int(streams), kpts
-        self.streams = [torch.cuda.Stream() for _ in range(self.S)] if self.S > 1 else [None]
+        self.streams = _streams.main_streams(self.S) if self.S > 1 else [None]
 
     def step(self, slot):
         im_l, im_r, im_info = self.inputs
@@ -51,6 +52,7 @@ class StepRunner(object):
         hpost.class_nms_device(det, 1, 0.05)
 
     def run(self, n):
+        _streams.set_pairs_in_flight(self.S)
         for k in range(n):
             if self.S == 1:
                 self.step(0)

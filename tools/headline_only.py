@@ -14,6 +14,8 @@ ap.add_argument('--streams', type=int, default=3)
 ap.add_argument('--steps', type=int, default=40)
 ap.add_argument('--no-shipped-plans', action='store_true')
 args = ap.parse_args()
+from stereo_rcnn_amd import streams as _st
+_st.ensure_hw_queues()
 dev = torch.device('cuda:0')
 if not args.no_shipped_plans:
     print('shipped plans loaded:', tune.load_shipped_plans())

@@ -15,6 +15,8 @@ ap.add_argument('--rounds', type=int, default=2)
 ap.add_argument('--cands', type=int, default=5)
 ap.add_argument('--start', default='', help='plan file to start from (default: in-situ isolated tuning)')
 args = ap.parse_args()
+from stereo_rcnn_amd import streams as _st
+_st.ensure_hw_queues()
 dev = torch.device('cuda:0')
 m = resnet(('__background__', 'Car'), 101, pretrained=False)
 m.create_architecture()
