@@ -151,6 +151,20 @@ typedef struct srcnn_conv_desc {
      * w / w_lo are (Cout, Cin + Cin2); both inputs must carry the same activation scale; no split-K. */
     const void *x2;
     int Cin2, H2, W2, x2_cstride, stride2;
+    /* Fused narrow 1x1 head (SPLIT16 f16x3 engine; NULL = none): instead of storing y, the epilogue applies a second, 1x1
+     * convolution with head_cout (= 6) output channels to the activated output pixel and stores only that:
+     *   head_y[pixel, k] = head_scale * sum_c act(conv(x))[pixel, c] * head_w[k, c] + head_bias[k]      (float32, pixel stride 6)
+     * head_w is float32 (head_cout, Cq) with Cq the channels of an output pixel (Cout, or Cout / 4 in mode 1), which must be 256
+     * = the N extent of the 256x256 tile this form always runs on (one workgroup then owns every channel of its pixels);
+     * head_scale undoes the activation scale 2^k the caller folded into w_inv_scale / bias.  The products are float32 FMAs in
+     * a fixed order (8 channels per lane, then a DPP scan over the 32 lanes of a pixel): deterministic.  The keypoint branch
+     * uses it for ConvTranspose2d + ReLU + the 6-channel classifier (resnet.py:258-262 of the reference: RCNN_kpts[12:14],
+     * kpts_class): the (300, 28, 28, 256) upsampled tensor is neither written nor read back, one launch goes.  y may be NULL. */
+    const void *head_w;
+    const void *head_bias;
+    void *head_y;
+    int head_cout;
+    float head_scale;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);

@@ -33,7 +33,8 @@ class ConvDesc(ctypes.Structure):
                 ("x_format", c_int), ("y_format", c_int), ("res_format", c_int),
                 ("tile_waves", c_int), ("tile_stages", c_int), ("layer_tag", c_int),
                 ("m_limit", c_void_p), ("m_limit_mul", c_int),
-                ("x2", c_void_p), ("Cin2", c_int), ("H2", c_int), ("W2", c_int), ("x2_cstride", c_int), ("stride2", c_int)]
+                ("x2", c_void_p), ("Cin2", c_int), ("H2", c_int), ("W2", c_int), ("x2_cstride", c_int), ("stride2", c_int),
+                ("head_w", c_void_p), ("head_bias", c_void_p), ("head_y", c_void_p), ("head_cout", c_int), ("head_scale", c_float)]
 
 
 _SIGNATURES = {

@@ -36,6 +36,10 @@ struct ConvArgs {
     // the ResNet projection shortcut computed by the block's last conv itself.  nullptr = none.
     const float *x2;
     int Cin2, H2, W2, xcs2, stride2;
+    // SPLIT16 engine, 256x256 tile: fused 6-channel 1x1 head on the activated output pixel (srcnn_conv_desc.head_w); nullptr = none
+    const float *head_w, *head_b;
+    float *head_y;
+    float head_scale;
 };
 
 

@@ -99,9 +99,12 @@ extern __shared__ __attribute__((aligned(1024))) _Float16 smem[];
 
 // MR/NR: per-WAVE tile in 32x32 MFMA tiles; WM x 2 waves per workgroup -> workgroup tile (32*MR*WM) x (64*NR).
 // WM = 2: 4 waves (256 threads).  WM = 4: 8 waves (512 threads).  NS: LDS ring stages (NS-1 K tiles in flight).
-template <int MR, int NR, bool OUT_SPLIT, int WM, int NS>
+// HEAD6 (256x256 tile only): the epilogue applies a 6-channel 1x1 head to the activated pixels and stores that instead of y
+// (srcnn_conv_desc.head_w).
+template <int MR, int NR, bool OUT_SPLIT, int WM, int NS, bool HEAD6 = false>
 __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_kernel(const ConvArgs p)
 {
+    static_assert(!HEAD6 || (MR == 2 && NR == 4 && WM == 4 && NS == 2 && !OUT_SPLIT), "the fused head lives in the 256x256 tile");
     constexpr int NWAVES = 2 * WM, NTHREADS = 64 * NWAVES;
     constexpr int BM = 32 * MR * WM, BN = 64 * NR;
     constexpr int AG = BM / (16 * NWAVES), BG = BN / (16 * NWAVES);   // 16-row DMA groups per wave (A, B)
@@ -662,6 +665,75 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
             }
             __syncthreads();
             if (p.stamp && ps == 0) st4 = __builtin_readcyclecounter();
+            if constexpr (HEAD6) {
+                // Fused 6-channel head (srcnn_conv_desc.head_w) instead of the y store.  GROUPS == 32 lanes hold the 256 channels
+                // of a pixel (lanes 0-31 / 32-63 of a wave: two pixels): 8 channels per lane in order, then a DPP scan over the
+                // half-wave -- a fixed summation order.  Three filters per sweep over the pass's rows: their 24 weights are
+                // fetched AFTER the pass's accumulators have left the registers (128 accumulators + 48 weights + the unrolled
+                // row loop do not fit the 256 registers of a wave); the second sweep re-reads the tile from LDS.
+                static_assert(!HEAD6 || GROUPS == 32, "one half-wave per pixel");
+#pragma unroll
+                for (int kk = 0; kk < 6; kk += 3) {
+                    float hw[3][8], hb[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float4 w0 = *reinterpret_cast<const float4 *>(p.head_w + (kk + k) * cq + co);
+                        const float4 w1 = *reinterpret_cast<const float4 *>(p.head_w + (kk + k) * cq + co + 4);
+                        hw[k][0] = w0.x; hw[k][1] = w0.y; hw[k][2] = w0.z; hw[k][3] = w0.w;
+                        hw[k][4] = w1.x; hw[k][5] = w1.y; hw[k][6] = w1.z; hw[k][7] = w1.w;
+                        hb[k] = p.head_b[kk + k];
+                    }
+#pragma unroll
+                    for (int it = 0; it < NG; ++it) {
+                        const int r = r0 + it * RSTEP;
+                        const int row = mp + r;
+                        if (row < p.M) {                          // uniform per half-wave (one pixel)
+                            const float4 a = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8);
+                            const float4 b = *reinterpret_cast<const float4 *>(tile + r * BN + g * 8 + 4);
+                            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                if (p.bias) v[e] += bias8[e];
+                                if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            float hs[3];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                float acc1 = v[0] * hw[k][0];
+#pragma unroll
+                                for (int e = 1; e < 8; ++e) acc1 = fmaf(v[e], hw[k][e], acc1);
+                                hs[k] = acc1;
+                            }
+                            // sum over the 32 lanes of the pixel on the VALU (DPP), not through the LDS crossbar: inclusive scan
+                            // inside each 16-lane row (row_shr 1, 2, 4, 8; lanes shifted in from outside read 0), then lane 15 of
+                            // rows 0 / 2 added into rows 1 / 3 (row_bcast:15): lane 31 of each half-wave holds the pixel's sum
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                float x = hs[k];
+                                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+                                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));
+                                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));
+                                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));
+                                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, true));
+                                hs[k] = x;
+                            }
+                            if (g == 31) {
+                                size_t opix = (size_t)row;
+                                if (p.mode == 1) {                   // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j)
+                                    const int ohw2 = p.OH * p.OW;
+                                    const int bb = row / ohw2, rem = row - bb * ohw2;
+                                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                                    opix = ((size_t)bb * 2 * p.OH + 2 * oh + (ij >> 1)) * (2 * p.OW) + 2 * ow + (ij & 1);
+                                }
+                                float *dst = p.head_y + opix * 6 + kk;
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) dst[k] = fmaf(hs[k], p.head_scale, hb[k]);
+                            }
+                        }
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int it = 0; it < NG; ++it) {
                 const int r = r0 + it * RSTEP;
@@ -799,6 +871,18 @@ static void launch(const ConvArgs &a, int splits, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
+    }
+    if constexpr (MR == 2 && NR == 4 && WM == 4 && NS == 2) {
+        if (a.head_w) {                        // fused 6-channel head instead of the y store
+            auto *kh = conv_f16s_kernel<MR, NR, false, WM, NS, true>;
+            static bool head_configured = false;
+            if (!head_configured) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                head_configured = true;
+            }
+            SRCNN_LAUNCH(kh, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);
+            return;
+        }
     }
     if (a.y_fmt == 1) SRCNN_LAUNCH(k1, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);
     else SRCNN_LAUNCH(k0, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds, st, a);

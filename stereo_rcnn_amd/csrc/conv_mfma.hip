@@ -319,6 +319,11 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
         pl.splits = 1;
         pl.kt_per_split = a.nkt;
     }
+    if (a.head_w) {                // the fused head exists for the 256x256 tile only (a workgroup owns all 256 channels of its pixels)
+        Plan h = pl;
+        h.mr = 4; h.nr = 4; h.waves = 8; h.stages = 2; h.splits = 1; h.kt_per_split = a.nkt;
+        return h;
+    }
     if (d->tile_mr <= 0 || d->tile_nr <= 0) return pl;
     Plan req = pl;
     req.mr = d->tile_mr;
@@ -340,7 +345,7 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
 
 static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
 {
-    SRCNN_REQUIRE(d && d->x && d->w && d->y, "null pointer");
+    SRCNN_REQUIRE(d && d->x && d->w && (d->y || d->head_w), "null pointer");
     SRCNN_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, "Cin must be a positive multiple of 32");
     SRCNN_REQUIRE(d->x_cstride % 4 == 0, "x_cstride must be a multiple of 4 floats (16-B loads)");
     SRCNN_REQUIRE(d->B > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "bad output shape");
@@ -381,6 +386,16 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
         SRCNN_REQUIRE((long long)d->W2 * d->x2_cstride * 4 * ((256 / d->OW + 3) * (long long)d->stride2 + 1) < (1LL << 31),
                       "x2: the input rows under one 256-pixel tile must span < 2 GB");
         a.Cin2 = d->Cin2; a.H2 = d->H2; a.W2 = d->W2; a.xcs2 = d->x2_cstride; a.stride2 = d->stride2;
+    }
+    a.head_w = static_cast<const float *>(d->head_w);
+    a.head_b = static_cast<const float *>(d->head_bias);
+    a.head_y = static_cast<float *>(d->head_y);
+    a.head_scale = d->head_scale;
+    if (a.head_w) {
+        const int cq = d->mode == 1 ? d->Cout / 4 : d->Cout;
+        SRCNN_REQUIRE(d->precision == 1 && d->x_format == 1 && a.head_y && a.head_b && d->head_cout == 6 && cq == 256 && !d->x2 &&
+                          !d->residual && d->mode != 2,
+                      "fused head: SPLIT16 f16x3 engine, 6 head channels over 256-channel pixels, no residual / second input / mode 2");
     }
     if (a.y_fmt == 1) {
         a.range_flag = range_flag_word();

@@ -168,6 +168,8 @@ LIMIT_TUNE_ROIS = 64          # row-limited launches (the lazy keypoint head) ar
 RPN_PAIR_LAUNCH = _os.environ.get('SRCNN_RPN_PAIR', '1') != '0'     # A/B switch of the one-launch stereo RPN conv (conv mode 2)
 # A/B switch: the projection shortcut of a layer's first block computed inside that block's conv3 (prep_conv_shortcut)
 SHORTCUT_FUSION = _os.environ.get('SRCNN_SHORTCUT_FUSION', '1') != '0'
+# A/B switch: the keypoint branch's 6-channel classifier computed inside the epilogue of the deconvolution (conv2d(head=...))
+KPTS_HEAD_FUSION = _os.environ.get('SRCNN_KPTS_HEAD_FUSION', '1') != '0'
 
 
 # ---- what the tuner minimises.  'isolated': the latency of the launch alone on the chip (the right objective for one pair at a
@@ -351,7 +353,7 @@ def _tune_candidates(d, key, device, cands, log, L, st):
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
            res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None,
-           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None):
+           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None, head=None):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
     *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h).
     in_shift / out_shift (f16x3 engine): the input tensor holds its values x 2^in_shift, the output (and the residual, which
@@ -359,7 +361,9 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     SPLIT16 tensors in the middle of the f16 range (model/stereo_rcnn/plan.py: calibrate).  Exact: the factor goes into the
     epilogue's power-of-two rescale and a pre-scaled copy of the bias; ReLU commutes with it.
     m_limit (device int32 tensor) / m_limit_mul: only rows m < m_limit[0] * m_limit_mul are needed (srcnn_conv_desc.m_limit).
-    x2 / H2 / W2 (weights from prep_conv_shortcut): the second input (B, H2, W2, cin2) SPLIT16, stored with the SAME scale as x."""
+    x2 / H2 / W2 (weights from prep_conv_shortcut): the second input (B, H2, W2, cin2) SPLIT16, stored with the SAME scale as x.
+    head = (cw_head, y_head) (f16x3 SPLIT16 engine): a 6-channel 1x1 conv applied to the activated output pixels inside this
+    launch's epilogue (srcnn_conv_desc.head_w); y_head (pixels, 6) float32 receives it, y is not written (may be None)."""
     L = _lib.lib()
     d = _lib.ConvDesc()
     d.x = x.data_ptr() + 4 * x_offset_elems
@@ -378,7 +382,14 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
             bias = cache[out_shift] = (cw.bias * 2.0 ** out_shift).contiguous()
     d.bias = bias.data_ptr() if bias is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
-    d.y = y.data_ptr()
+    d.y = y.data_ptr() if y is not None else None
+    if head is not None:
+        hcw, hy = head
+        assert precision == 'f16x3' and x_fmt == _lib.FMT_SPLIT16 and hcw.cout == 6 and hcw.kh == 1 and hcw.kw == 1 and hcw.bias is not None
+        assert hy.dtype == torch.float32 and hy.is_contiguous()
+        d.head_w, d.head_bias, d.head_y = hcw.weight.data_ptr(), hcw.bias.data_ptr(), hy.data_ptr()
+        d.head_cout, d.head_scale = 6, 2.0 ** -out_shift
+        y_fmt = _lib.FMT_F32
     d.B, d.H, d.W, d.Cin = B, H, W, cw.cin
     d.x_cstride = cw.cin if x_cstride is None else x_cstride
     d.OH, d.OW, d.Cout = OH, OW, cw.cout
@@ -405,7 +416,15 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         if FlopCounter.rows is not None:
             FlopCounter.rows.append({'name': name or 'conv %dx%d %d->%d' % (cw.kh, cw.kw, cw.cin, cw.cout), 'M': B * OH * OW,
                                      'N': cw.cout, 'K': cw.alg_k, 'flops': 2.0 * B * OH * OW * cw.cout * cw.alg_k, 'bytes': nbytes})
-    if plan is not None:                   # explicit (tile_mr, tile_nr, waves, stages, splits): tests and tools
+    if head is not None:                   # the fused head lives in the 256x256 tile
+        _set_plan(d, (4, 4, 8, 2, 1))
+        if FlopCounter.enabled:            # the head's own (VALU) flops and its output instead of y
+            FlopCounter.flops += 2.0 * B * OH * OW * (4 if cw.mode == 1 else 1) * 6 * (cw.cout // (4 if cw.mode == 1 else 1))
+            FlopCounter.bytes += 4.0 * B * OH * OW * ((4 if cw.mode == 1 else 1) * 6 - cw.cout)
+            if FlopCounter.rows is not None:
+                FlopCounter.rows[-1]['flops'] = 2.0 * B * OH * OW * (cw.cout * cw.alg_k + 6 * cw.cout)
+                FlopCounter.rows[-1]['bytes'] = nbytes + 4.0 * B * OH * OW * ((4 if cw.mode == 1 else 1) * 6 - cw.cout)
+    elif plan is not None:                   # explicit (tile_mr, tile_nr, waves, stages, splits): tests and tools
         _set_plan(d, plan)
     elif AUTOTUNE:
         # a launch with a device-side row limit is tuned WITH a typical limit (LIMIT_TUNE_ROIS of its units): what is fastest for

@@ -468,9 +468,16 @@ class Plan(object):
             y = self.kp_a if i % 2 == 0 else self.kp_b
             self._conv(cw, x, R, s, s, y, s, s, g, 'k%d' % i, x_fmt=f, y_fmt=f, name='kpts.%d' % (2 * i), **lim(s * s))
             x, g = y, 'k%d' % i
-        self._conv(w.kpts_up, x, R, s, s, self.kp_up, s, s, g, 'kup', x_fmt=f, y_fmt=f, name='kpts.deconv', **lim(s * s))
         G = cfg.KPTS_GRID
-        self._conv(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, 'kup', None, x_fmt=f, name='kpts.class', **lim(G * G))
+        if f and engine.KPTS_HEAD_FUSION and w.kpts_class.cout == 6 and w.kpts_up.cout == 4 * 256:
+            # SPLIT16 engine: ConvTranspose2d + ReLU + the 6-channel classifier (resnet.py:258-262) in ONE launch -- the classifier
+            # runs in the deconvolution's epilogue on the pixels a workgroup has just activated; the (R, 28, 28, 256) upsampled
+            # tensor is neither written nor read back (srcnn_conv_desc.head_w)
+            self._conv(w.kpts_up, x, R, s, s, self.kp_up, s, s, g, 'kup', x_fmt=f, name='kpts.deconv+class',
+                       head=(w.kpts_class, self.kp_logits), **lim(s * s))
+        else:
+            self._conv(w.kpts_up, x, R, s, s, self.kp_up, s, s, g, 'kup', x_fmt=f, y_fmt=f, name='kpts.deconv', **lim(s * s))
+            self._conv(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, 'kup', None, x_fmt=f, name='kpts.class', **lim(G * G))
         kp, lp, rp = (self.kpts_prob, self.left_prob, self.right_prob) if outs is None else outs
         _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, kp.data_ptr(), lp.data_ptr(), rp.data_ptr(),
                                               None if limit is None else limit.data_ptr(), _lib.stream()), "srcnn_kpts_tail")

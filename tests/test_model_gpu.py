@@ -315,6 +315,57 @@ def test_projection_shortcut_inside_conv3_equals_separate_launches(dev):
         assert _relerr(a, b) < 2e-6
 
 
+def test_keypoint_classifier_inside_the_deconvolution_equals_separate_launches(dev):
+    """The keypoint branch with the 6-channel classifier computed in the epilogue of the ConvTranspose2d launch
+    (engine.KPTS_HEAD_FUSION, the default: srcnn_conv_desc.head_w) against the same branch as two launches with the upsampled
+    (R, 28, 28, 256) tensor written and read back: the logits agree to fp32 rounding (exact fp32 products of unrounded
+    activations vs the 3xf16 split of their SPLIT16 copy), the probabilities to 1e-5, one conv launch goes -- also through the
+    device-side row limit of the lazy form, and run twice for bit-repeatability (fixed summation order)."""
+    from stereo_rcnn_amd import engine, fixture
+    m, _ = _build_model(dev)
+    m.precision = 'f16x3'
+    m.use_program = m.use_graph = False
+    l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
+    plan = m._get_plan(1, l.shape[2], l.shape[3])
+    got, launches = {}, {}
+    saved = engine.KPTS_HEAD_FUSION
+    try:
+        for fused in (True, False, True):
+            engine.KPTS_HEAD_FUSION = fused
+            with torch.no_grad():
+                m(l, r, info)
+                engine.FlopCounter.enabled, engine.FlopCounter.launches = True, 0
+                try:
+                    out = m(l, r, info)
+                finally:
+                    engine.FlopCounter.enabled = False
+            torch.cuda.synchronize()
+            res = (plan.kp_logits.clone(), out[5].clone(), out[6].clone(), out[7].clone())
+            if fused and True in got:
+                for a, b in zip(got[True], res):
+                    assert torch.equal(a, b)                    # the fused form is bit-repeatable
+            got[fused], launches[fused] = res, engine.FlopCounter.launches
+            # the lazy form: the first 7 rois only, through the device-side row limit
+            lim = torch.tensor([7], dtype=torch.int32, device=dev)
+            outs = tuple(torch.zeros_like(t) for t in res[1:])
+            with torch.no_grad():
+                prev, engine.PRECISION = engine.PRECISION, 'f16x3'
+                try:
+                    plan.kpts_head(rois=out[0].reshape(-1, 5)[:plan.R].contiguous(), n_rois=plan.R, limit=lim, outs=outs)
+                finally:
+                    engine.PRECISION = prev
+            torch.cuda.synchronize()
+            n = 7 * outs[0].numel() // plan.R
+            assert float((outs[0].reshape(-1)[:n] - res[1].reshape(-1)[:n]).abs().max()) < 1e-5   # other conv plans under the row limit
+    finally:
+        engine.KPTS_HEAD_FUSION = saved
+    assert launches[False] - launches[True] == 1, launches
+    scale = float(got[False][0].abs().max())
+    assert float((got[True][0] - got[False][0]).abs().max()) < 2e-6 * max(scale, 1.0)
+    for a, b in zip(got[True][1:], got[False][1:]):
+        assert float((a - b).abs().max()) < 1e-5          # probabilities (measured 3e-6)
+
+
 def test_f16x3_engine_full_size_vs_golden(dev):
     from stereo_rcnn_amd import fixture
     g = np.load(os.path.join(GOLD, 'full_r101_seed3.npz'))
