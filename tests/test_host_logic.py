@@ -235,3 +235,57 @@ def test_rank_host_budget_and_numa_pinning(tmp_path, monkeypatch):
         assert sdist.pin_to_gpu_numa(0, cpus={10 ** 6}) is None           # nothing of the mask left: unchanged
     finally:
         os.sched_setaffinity(0, mine)
+
+
+def test_partition_masks_split_every_xcd_evenly():
+    """streams.partition_masks: bit b of a queue's CU mask = CU b // 8 of XCD b % 8 (profiles/queue_mapping_r04.txt); every
+    partition must hold the same number of CUs of EVERY XCD (a dispatch's blocks are dealt to all XCDs whatever the mask)."""
+    from stereo_rcnn_amd import streams
+    for parts in (1, 2, 3, 4, 8):
+        masks = streams.partition_masks(parts, 256)
+        assert len(masks) == parts and all(len(m) == 8 for m in masks)
+        seen = 0
+        for m in masks:
+            bits = [b for b in range(256) if m[b >> 5] >> (b & 31) & 1]
+            v = sum(1 << b for b in bits)
+            assert seen & v == 0
+            seen |= v
+            per_xcd = [sum(1 for b in bits if b % 8 == x) for x in range(8)]
+            assert len(set(per_xcd)) == 1 and per_xcd[0] >= 32 // parts - 1 and per_xcd[0] >= 1, (parts, per_xcd)
+        assert seen == (1 << 256) - 1
+    for parts in (2, 4):        # these use mask bits 3-4 only: an even split under an XCD-major enumeration as well
+        for m in streams.partition_masks(parts, 256):
+            assert len(set(m)) == 1
+
+
+def test_branch_streams_only_while_one_forward_is_in_flight(monkeypatch):
+    from stereo_rcnn_amd import streams
+    prev = streams.pairs_in_flight()
+    try:
+        monkeypatch.setattr(streams, 'SIDE_KIND', 'auto')
+        streams.set_pairs_in_flight(1)
+        assert streams.branch_overlap()
+        streams.set_pairs_in_flight(3)
+        assert not streams.branch_overlap() and streams.pairs_in_flight() == 3
+        monkeypatch.setattr(streams, 'SIDE_KIND', 'none')
+        streams.set_pairs_in_flight(1)
+        assert not streams.branch_overlap()
+        monkeypatch.setattr(streams, 'SIDE_KIND', 'pool')
+        streams.set_pairs_in_flight(4)
+        assert streams.branch_overlap()
+    finally:
+        streams.set_pairs_in_flight(prev)
+
+
+def test_ensure_hw_queues_sets_the_runtime_variable_before_hip_starts(monkeypatch):
+    import torch
+    from stereo_rcnn_amd import streams
+    monkeypatch.setattr(torch.cuda, 'is_initialized', lambda: False)
+    monkeypatch.delenv('GPU_MAX_HW_QUEUES', raising=False)
+    assert streams.max_pairs_in_flight() == 3                    # HIP's default: 4 queues, one is the null stream's
+    assert streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 7
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '16')
+    assert streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 15      # a larger user setting is kept
+    monkeypatch.setattr(torch.cuda, 'is_initialized', lambda: True)
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    assert not streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 3    # too late: HIP is up
