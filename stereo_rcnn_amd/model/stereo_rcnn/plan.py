@@ -11,10 +11,13 @@ MI355X-first structure (not the reference's eager module tree):
 Every arithmetic step is a call into libsrcnn_hip.so (see include/srcnn_hip.h).
 """
 import ctypes
+import logging
 
 import torch
 
 from ... import _lib, engine, streams
+
+_log = logging.getLogger('stereo_rcnn_amd')
 from ..utils.config import cfg
 
 
@@ -241,6 +244,13 @@ class Plan(object):
         if merge:
             for g, mx in w.calibration_max.items():
                 calib[g] = max(calib.get(g, 0.0), mx)
+        if not (calib.get('stem', 0.0) > 0 and math.isfinite(calib.get('stem', 0.0))):
+            # a blank (or non-finite) frame says nothing about the network's ranges: scales chosen from it would make every real
+            # frame trip the range guard and fall back to the fp32 engine.  Stay uncalibrated; the next forward tries again.
+            _log.warning('SPLIT16 activation scales NOT calibrated: the frame produced no finite non-zero stem output '
+                         '(blank warm-up input?); the next forward calibrates again')
+            self.packed_fmt = -1
+            return
         shifts = {}
         for g, mx in calib.items():
             if mx > 0 and math.isfinite(mx):
@@ -261,7 +271,11 @@ class Plan(object):
             w.calib_epoch += 1             # launch programs / graphs recorded with the old scales are stale (every plan checks)
         w.calibrated = True
         w.calibration_max = calib
+        w.calibration_frames = (getattr(w, 'calibration_frames', 0) + 1) if merge else 1
         self.packed_fmt = -1
+        _log.info('SPLIT16 activation scales calibrated on %d frame(s) (last: %dx%dx%d, max |stem| %.3g): shifts %s; projection '
+                  'shortcuts fused: %s', w.calibration_frames, self.B, self.H, self.W, calib.get('stem', 0.0),
+                  ' '.join('%s:%+d' % kv for kv in sorted(shifts.items())), fuse)
 
     # ------------------------------------------------------------------ stages
     def trunk(self):

@@ -400,6 +400,7 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
                                         dense_align, pool if solver == 'scipy' else None, native=(solver == 'host_py'))
             finally:
                 model.precision = prev
+                _note_guard_trip(model, im_left_data, 0)
     with torch.no_grad():
         lazy = _lazy(model)
         out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy)
@@ -417,6 +418,7 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
                              dense_align, pool, solver, slot)
         finally:
             model.precision = prev
+            _note_guard_trip(model, im_left_data, slot)
 
 
 def _plan_of(model, im_left_data, slot):
@@ -494,6 +496,32 @@ def detect_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shap
                                    dense_align, slot, solver)
         finally:
             model.precision = prev
+            _note_guard_trip(model, im_left_data, slot)
+
+
+RECALIBRATE_AFTER_TRIPS = 2      # range-guard trips (pairs re-run on the fp32 engine) after which the scales are widened
+
+
+def _note_guard_trip(model, im_left_data, slot):
+    """A pair left the f16 range of the SPLIT16 engine and was re-run on the exact fp32 engine.  The activation scales come from
+    the frames the calibration saw (the first forward, unless calibrate_activation_scales was called): a stream of frames unlike
+    them would silently run at fp32-engine speed for good.  After RECALIBRATE_AFTER_TRIPS trips the offending frame -- still the
+    input of this slot's plan -- is merged into the calibration (one fp32 forward; plans re-record their launch programs)."""
+    import logging
+    log = logging.getLogger('stereo_rcnn_amd')
+    w = model._weights
+    if w is None:
+        return
+    w.guard_trips = getattr(w, 'guard_trips', 0) + 1
+    log.warning('SPLIT16 range guard tripped (%d since the last calibration): pair re-run on the fp32 engine', w.guard_trips)
+    if w.guard_trips >= RECALIBRATE_AFTER_TRIPS:
+        B, _, H, W = im_left_data.shape
+        plan = model._get_plan(int(B), int(H), int(W), slot)
+        with torch.no_grad():
+            plan.calibrate(merge=True)
+        w.guard_trips = 0
+        log.warning('SPLIT16 activation scales widened to cover the offending frame (frames much smaller than it lose low-order bits: '
+                    'calibrate_activation_scales() on representative frames is the controlled way)')
 
 
 _stream_cache = {}
@@ -545,6 +573,8 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
                                  solver=solver, slot=retry_slot)
             finally:
                 model.precision = prev
+                if len(frame) != 3:
+                    _note_guard_trip(model, frame[0], retry_slot)
 
     for k, frame in enumerate(frames):
         slot = k % len(streams)

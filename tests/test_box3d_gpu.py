@@ -318,6 +318,34 @@ def test_pipeline_falls_back_to_fp32_when_the_split16_range_is_exceeded(dev):
         assert np.array_equal(a['box_left'], b['box_left']) and np.array_equal(a['xyz'], b['xyz'])
 
 
+def test_repeated_range_trips_widen_the_activation_scales(dev):
+    """the SPLIT16 scales come from the first forward's frame.  A stream of frames unlike it would trip the range guard
+    on every pair and run at fp32-engine speed for good, silently.  pipeline._note_guard_trip: every trip is logged, and after
+    RECALIBRATE_AFTER_TRIPS of them the offending frame is merged into the calibration -- from then on frames like it run on the
+    default engine again, and the frames the scales were first chosen from still match the fp32 engine."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import engine, fixture, pipeline
+    mdl = _model(dev, fixture.make_state_dict(3))
+    l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
+    hot = (mdl, l * 2000.0, r * 2000.0, info, calib, (120, 400, 3))
+    base = pipeline.detect_3d(mdl, l, r, info, calib, (120, 400, 3))            # calibrates on the ordinary frame
+    w = mdl._weights
+    assert w.calibrated and getattr(w, 'guard_trips', 0) == 0
+    epoch, shifts = w.calib_epoch, dict(w.shifts)
+    pipeline.detect_3d(*hot)
+    assert w.guard_trips == 1 and w.calib_epoch == epoch                          # first trip: fp32 re-run only
+    pipeline.detect_3d(*hot)
+    assert w.guard_trips == 0 and w.calib_epoch > epoch and w.calibration_frames == 2
+    assert w.shifts['stem'] < shifts['stem']                                       # wider range: smaller shift
+    with torch.no_grad():                                                          # the hot frame now fits the default engine
+        mdl(hot[1], hot[2], info)
+    mdl.check_range()
+    again = pipeline.detect_3d(mdl, l, r, info, calib, (120, 400, 3))            # the ordinary frame under the wider scales
+    assert len(again) == len(base) > 0
+    for a, b in zip(base, again):
+        assert float(np.abs(a['box_left'] - b['box_left']).max()) < 1e-2 and abs(a['score'] - b['score']) < 1e-3
+
+
 @pytest.mark.parametrize("solver", ['host', 'device'])
 def test_streamed_fp32_fallback_does_not_disturb_the_pairs_in_flight(dev, solver):
     """one out-of-range pair (image x2000) in the MIDDLE of a stream with three pairs in flight.  Its fp32 re-run
