@@ -13,6 +13,8 @@ ap.add_argument('--streams', type=int, default=3)
 ap.add_argument('--out', default='mi355x.json')
 ap.add_argument('--rounds', type=int, default=2)
 ap.add_argument('--cands', type=int, default=5)
+ap.add_argument('--min-gain', type=float, default=0.004)
+ap.add_argument('--steps', type=int, default=24)
 ap.add_argument('--start', default='', help='plan file to start from (default: in-situ isolated tuning)')
 args = ap.parse_args()
 from stereo_rcnn_amd import streams as _st
@@ -34,7 +36,7 @@ with torch.no_grad():
         torch.cuda.synchronize()
 noise = [run.measure(24) for _ in range(5)]
 print('noise check, 5 x median-of-3 of 24 steps: ' + ' '.join('%.3f' % t for t in noise) + ' ms/step')
-base, final, changes = tune.tune_throughput(m, l, r, info, streams=args.streams, rounds=args.rounds, cands_per_shape=args.cands, log=print)
+base, final, changes = tune.tune_throughput(m, l, r, info, streams=args.streams, rounds=args.rounds, cands_per_shape=args.cands, min_gain=args.min_gain, steps=args.steps, log=print)
 tune.save_shipped(args.out, {'gpu': torch.cuda.get_device_name(0), 'streams': args.streams, 'workload': 'BASELINE configs[1], network input 600x1987, batch 1',
                              'ms_per_step_before': round(base, 3), 'ms_per_step_after': round(final, 3),
                              'changes': [[list(k), list(a), list(b), round(t, 3)] for k, a, b, t in changes]})
