@@ -292,7 +292,7 @@ WORKLOADS = {
             text='BASELINE configs[2]: ResNet-101 FPN + stereo RPN + ROIAlign + dense_align, batch=8 stereo pairs per forward, '
                  '%(w)dx%(h)d synthetic (network input %(nw)dx%(nh)d), full pipeline per image: decode + class NMS + borders + 4-DoF '
                  'Newton-CG (host C threads) + dense alignment + 3-DoF Newton-CG'),
-    4: dict(layers=50, batch=4, streams=1, flow='2d',
+    4: dict(layers=50, batch=4, streams=2, flow='2d',
             text='BASELINE configs[4]: ResNet-50 backbone, 2x input resolution (%(w)dx%(h)d synthetic -> network input %(nw)dx%(nh)d), '
                  'batch=4 stereo pairs per forward, 300 proposals per image, forward + decode + class NMS (HBM-bound stress)'),
 }

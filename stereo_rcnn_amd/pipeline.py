@@ -534,6 +534,7 @@ def _slot_streams(n):
     have = _stream_cache.setdefault(dev, [])
     while len(have) < n:
         have.append(_streams.new_stream(_streams.MAIN_KIND if _streams.MAIN_KIND in _streams.KINDS else 'dedicated'))
+    _streams.check_queue_supply(n)
     _streams.set_pairs_in_flight(n)           # n > 1: the plans keep their branches on the main streams (streams.py)
     return have[:n]
 
@@ -545,6 +546,15 @@ def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, 
     those of detect_3d (same launches).  solver='host': the Newton-CG solves of the pairs in flight run on the host between
     the launches (one phase per pair per new frame), use slots >= 3.  solver='scipy' (needs `pool`) keeps the staged
     host/scipy arrangement."""
+    prev_n = _streams.pairs_in_flight()
+    try:
+        for objs in _detect_3d_stream(model, frames, pool, eval_thresh, class_index, dense_align, slots, solver):
+            yield objs
+    finally:
+        _streams.set_pairs_in_flight(prev_n)      # the plans go back to the caller's regime (one at a time: branches on side streams)
+
+
+def _detect_3d_stream(model, frames, pool, eval_thresh, class_index, dense_align, slots, solver):
     if solver == 'scipy':
         for objs in _detect_3d_stream_scipy(model, frames, pool, eval_thresh, class_index, dense_align, min(slots, 2)):
             yield objs

@@ -289,3 +289,18 @@ def test_ensure_hw_queues_sets_the_runtime_variable_before_hip_starts(monkeypatc
     monkeypatch.setattr(torch.cuda, 'is_initialized', lambda: True)
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
     assert not streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 3    # too late: HIP is up
+
+
+def test_queue_supply_warning(monkeypatch, caplog):
+    import logging
+    from stereo_rcnn_amd import streams
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    monkeypatch.setattr(streams, '_warned', set())
+    with caplog.at_level(logging.WARNING, logger='stereo_rcnn_amd'):
+        assert streams.check_queue_supply(3, 'pool') and not caplog.records
+        assert not streams.check_queue_supply(4, 'pool') and len(caplog.records) == 1       # 4 in flight + null stream > 4 queues
+        assert not streams.check_queue_supply(4, 'pool')
+        assert len(caplog.records) == 1                                                     # once per count
+        assert streams.check_queue_supply(4, 'dedicated')
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '8')
+    assert streams.check_queue_supply(7, 'pool')
