@@ -41,7 +41,7 @@ typedef void *srcnn_stream_t; /* hipStream_t */
 
 #define SRCNN_API __attribute__((visibility("default")))
 
-SRCNN_API int srcnn_version(void);
+SRCNN_API int srcnn_version(void);   /* 210 = round 4: stream creation, placement probe, srcnn_conv_desc.head_* appended (older callers that zero the struct are unaffected) */
 SRCNN_API const char *srcnn_last_error(void);
 
 /* ------------------------------------------------------------------ NMS (A6)

@@ -141,7 +141,7 @@ extern "C" {
 // debug hook (not part of include/srcnn_hip.h): device buffer of 16 x u64 per workgroup, or NULL to switch off
 SRCNN_API void srcnn_debug_set_stamp_buffer(void *buf) { srcnn::g_stamp = static_cast<unsigned long long *>(buf); }
 
-int srcnn_version(void) { return 200; }
+int srcnn_version(void) { return 210; }   // 210: srcnn_stream_create*, srcnn_probe_placement, srcnn_conv_desc.head_* (appended fields)
 
 int srcnn_range_flag_read(int reset)
 {

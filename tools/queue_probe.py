@@ -15,8 +15,10 @@ ap.add_argument('--steps', type=int, default=120)
 ap.add_argument('--repeats', type=int, default=3)
 ap.add_argument('--no-shipped-plans', action='store_true')
 ap.add_argument('--kpts', type=int, default=1)
+ap.add_argument('--sync-every', default='0', help='comma list: device synchronisation every N steps inside the timed loop (0 = never): re-aligns the phases of the forwards in flight')
 ap.add_argument('--then-single', type=int, default=0, help='afterwards: N forwards one at a time on the null stream (latency mode)')
 args = ap.parse_args()
+streams.ensure_hw_queues()
 dev = torch.device('cuda:0')
 if not args.no_shipped_plans:
     tune.load_shipped_plans()
@@ -33,14 +35,20 @@ for S in [int(v) for v in args.streams.split(',')]:
         for _ in range(2):
             run.run(max(S, 1))
             torch.cuda.synchronize()
-        ts = []
-        for _ in range(args.repeats):
-            t0 = time.perf_counter()
-            run.run(args.steps)
-            torch.cuda.synchronize()
-            ts.append((time.perf_counter() - t0) / args.steps * 1e3)
-    print('main=%-9s side=%-9s queues=%-2s S=%d: %s ms/step -> %.1f pairs/s (best)' % (
-        streams.MAIN_KIND, streams.SIDE_KIND, os.environ.get('GPU_MAX_HW_QUEUES', '4'), S, ' '.join('%.3f' % t for t in ts), 1e3 / min(ts)), flush=True)
+        for sync_every in [int(v) for v in args.sync_every.split(',')]:
+            ts = []
+            for _ in range(args.repeats):
+                t0 = time.perf_counter()
+                if sync_every > 0:
+                    for _k in range(0, args.steps, sync_every):
+                        run.run(min(sync_every, args.steps - _k))
+                        torch.cuda.synchronize()
+                else:
+                    run.run(args.steps)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / args.steps * 1e3)
+            print('main=%-9s side=%-9s queues=%-2s S=%d sync every %d: %s ms/step -> %.1f pairs/s (best)' % (
+                streams.MAIN_KIND, streams.SIDE_KIND, os.environ.get('GPU_MAX_HW_QUEUES', '4'), S, sync_every, ' '.join('%.3f' % t for t in ts), 1e3 / min(ts)), flush=True)
 if args.then_single:
     streams.set_pairs_in_flight(1)
     run1 = tune.StepRunner(m, l, r, info, 1)
