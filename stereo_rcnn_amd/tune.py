@@ -76,18 +76,20 @@ class StepRunner(object):
 
 
 def tune_throughput(model, im_l, im_r, im_info, streams=3, top_shapes=40, cands_per_shape=5, min_gain=0.004, rounds=2,
-                    steps=24, log=None):
+                    steps=24, log=None, runner=None):
     """Coordinate descent described in the module docstring.  The model must be on the f16x3 engine with use_program set as
-    in production.  Returns (ms_before, ms_after, [(key, old_plan, new_plan, ms)])."""
+    in production.  Returns (ms_before, ms_after, [(key, old_plan, new_plan, ms)]).  `runner`: an object with StepRunner's
+    step(slot) / measure(steps) (tests inject a model of the machine; default: the real multi-stream step)."""
     say = log or (lambda *a: None)
-    run = StepRunner(model, im_l, im_r, im_info, streams)
+    run = runner if runner is not None else StepRunner(model, im_l, im_r, im_info, streams)
     with torch.no_grad():
         # one eager forward with the hit counter armed: which shape keys does a forward launch, how often (also makes sure the
         # in-situ tuner has seen every shape: its log supplies the candidates and their isolated times)
         prog, model.use_program = getattr(model, 'use_program', False), False
         engine.KEY_HITS = {}
         run.step(0)
-        torch.cuda.synchronize()
+        if runner is None:
+            torch.cuda.synchronize()
         hits, engine.KEY_HITS = engine.KEY_HITS, None
         model.use_program = prog
     weight = {}

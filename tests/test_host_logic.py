@@ -304,3 +304,43 @@ def test_queue_supply_warning(monkeypatch, caplog):
         assert streams.check_queue_supply(4, 'dedicated')
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '8')
     assert streams.check_queue_supply(7, 'pool')
+
+
+def test_throughput_tuner_descends_on_the_measured_step(monkeypatch):
+    """tune.tune_throughput with a model of the machine in place of the GPU: three shape keys, the step time is the sum of the
+    chosen plans' costs IN THE MIX (which differ from the isolated times the in-situ tuner logged).  The descent must move each
+    key whose mix-cost improves by more than the threshold, keep the others, and leave engine._TUNED at the result."""
+    from stereo_rcnn_amd import engine, tune
+
+    class Model(object):
+        use_program = True
+
+    keys = [('f16x3', 1, 38, 125, 38, 125, 256, 256 + i, 3, 3, 1, 1, 0, 256) for i in range(3)]      # engine._shape_key layout
+    iso = {keys[0]: [((2, 2, 8, 2, 3), 0.050), ((2, 2, 8, 2, 1), 0.056), ((4, 4, 8, 2, 1), 0.070)],
+           keys[1]: [((2, 1, 4, 2, 1), 0.030), ((2, 2, 8, 2, 1), 0.031)],
+           keys[2]: [((1, 1, 4, 2, 1), 0.020), ((1, 2, 4, 2, 1), 0.021)]}
+    mix = {keys[0]: {(2, 2, 8, 2, 3): 1.20, (2, 2, 8, 2, 1): 1.00, (4, 4, 8, 2, 1): 1.50},      # the split plan loses in the mix
+           keys[1]: {(2, 1, 4, 2, 1): 0.70, (2, 2, 8, 2, 1): 0.699},                            # a gain below the threshold
+           keys[2]: {(1, 1, 4, 2, 1): 0.40, (1, 2, 4, 2, 1): 0.45}}
+    hits = {keys[0]: 23, keys[1]: 22, keys[2]: 1}
+    monkeypatch.setattr(engine, '_TUNED', {k: v[0][0] for k, v in iso.items()})
+    monkeypatch.setattr(engine, '_TUNE_LOG', {k: list(v) for k, v in iso.items()})
+
+    class Runner(object):
+        calls = 0
+
+        def step(self, slot):
+            for k, n in hits.items():
+                engine.KEY_HITS[k] = n
+
+        def measure(self, steps=24, repeats=3):
+            Runner.calls += 1
+            return 5.0 + sum(mix[k][engine._TUNED[k]] for k in keys)
+
+    log = []
+    base, final, changes = tune.tune_throughput(Model(), None, None, None, streams=4, min_gain=0.004, rounds=2, log=log.append,
+                                                runner=Runner())
+    assert abs(base - 7.30) < 1e-9 and abs(final - 7.10) < 1e-9
+    assert [(c[0], c[1], c[2]) for c in changes] == [(keys[0], (2, 2, 8, 2, 3), (2, 2, 8, 2, 1))]
+    assert engine._TUNED[keys[0]] == (2, 2, 8, 2, 1) and engine._TUNED[keys[1]] == (2, 1, 4, 2, 1) and engine._TUNED[keys[2]] == (1, 1, 4, 2, 1)
+    assert any('round 2: 0 plans changed' in ln for ln in log)

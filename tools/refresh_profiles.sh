@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every measured artefact of a round on the GPU box into gpurun_out/<tag>/ (copy what is to be judged to profiles/).
 #   usage (inside gpurun): bash tools/refresh_profiles.sh r01
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=/root/repo
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -21,9 +21,9 @@ SWEEP=1 python tools/conv_bench.py --no-pmc f16s > $O/conv_microbench_${TAG}_f16
 python tools/conv_bench.py --no-pmc f32 > $O/conv_microbench_${TAG}_f32.txt 2>&1
 python tools/gemm_ceiling.py > $O/gemm_ceiling_${TAG}.txt 2>&1
 # what the tuner's LDS cap does to the multi-stream headline (co-residency experiment)
-( for cap in 160 128 96 64; do SRCNN_MAX_LDS_KB=$cap python bench.py --no-pmc --no-cpu-baseline --no-f32-leg --no-3d-leg --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('tuner LDS cap $cap KB per workgroup: %.1f pairs/s with 3 pairs in flight, %.1f one at a time, conv %.3f ms/step' % (d['value'], d['config']['one_pair_at_a_time']['value'], d['roofline']['conv_ms_per_step']))"; done ) > $O/lds_cap_${TAG}.txt 2>&1
+( for cap in 160 128 96 64; do SRCNN_MAX_LDS_KB=$cap python bench.py --no-pmc --no-cpu-baseline --no-f32-leg --no-3d-leg --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('tuner LDS cap $cap KB per workgroup: %.1f pairs/s with the default pairs in flight, %.1f one at a time, conv %.3f ms/step' % (d['value'], d['config']['one_pair_at_a_time']['value'], d['roofline']['conv_ms_per_step']))"; done ) > $O/lds_cap_${TAG}.txt 2>&1
 # same-box A/B of the one-launch stereo RPN conv (conv mode 2)
-( for i in 1 2 3; do for v in 0 1; do SRCNN_RPN_PAIR=$v python bench.py --no-pmc --no-cpu-baseline --no-f32-leg --no-3d-leg --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('stereo RPN conv as one launch = $v: %.1f pairs/s (3 in flight), %d conv launches per step' % (d['value'], d['roofline']['launches_per_step']))"; done; done ) > $O/rpn_pair_launch_${TAG}.txt 2>&1
+( for i in 1 2 3; do for v in 0 1; do SRCNN_RPN_PAIR=$v python bench.py --no-pmc --no-cpu-baseline --no-f32-leg --no-3d-leg --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('stereo RPN conv as one launch = $v: %.1f pairs/s (default in flight), %d conv launches per step' % (d['value'], d['roofline']['launches_per_step']))"; done; done ) > $O/rpn_pair_launch_${TAG}.txt 2>&1
 # keypoint head on the kept detections (pipeline.LAZY_KPTS): same-box A/B of the step, duration of the tower's launches against
 # the device-side row limit, and the M-fast tile order of the fully connected shapes
 python tools/lazy_probe.py 2>&1 | grep -v amdgpu.ids > $O/lazy_keypoint_head_${TAG}.txt
