@@ -38,11 +38,14 @@ def sample(stop, rows):
 
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 2.5
+    cases = [(0, 'zero'), (0, 'rand'), (1, 'zero'), (1, 'rand')]
+    if len(sys.argv) > 2 and sys.argv[2] == 'order':      # the instruction-order question only: random data, three orders, twice
+        cases = [(0, 'rand'), (2, 'rand'), (3, 'rand'), (0, 'rand'), (2, 'rand'), (3, 'rand')]
     build()
     print('Sustained rate of the conv engine\'s MFMA pattern (3 x v_mfma_f32_32x32x16_f16 per accumulator, 4 accumulators per wave, '
           '8 waves per CU), %.1f s per case, rocm-smi sampled meanwhile (sclk MHz / package W: median [min..max] over the samples)' % secs)
-    for variant in (0, 1):
-        for data in ('zero', 'rand'):
+    for variant, data in cases:
+        if True:
             rows, stop = [], threading.Event()
             th = threading.Thread(target=sample, args=(stop, rows))
             th.start()

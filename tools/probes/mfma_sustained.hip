@@ -4,7 +4,7 @@
 // fragment fetches (8 ds_read_b128 per 12 MFMAs, as the 64x64 per-wave tile of conv_f16s.hip does).  One 512-thread workgroup
 // per CU (two waves per SIMD, as the engine's 8-wave tiles), launched back to back for the requested time; the wrapper
 // (tools/mfma_sustained.py) samples rocm-smi clocks / power meanwhile.
-//   usage: mfma_sustained <variant 0|1> <data zero|rand> <seconds> [workgroups per CU = 1]
+//   usage: mfma_sustained <variant 0|1|2|3> <data zero|rand> <seconds> [workgroups per CU = 1]   (2 / 3: operand-stationary MFMA orders)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -18,7 +18,11 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int LDS>
+// ORDER (round 4, energy question: does the matrix pipe draw less when consecutive MFMAs share an operand register?):
+//   0 = the engine's order (all al.bh, then all ah.bl, then all ah.bh; A and B both change between most neighbours)
+//   1 = A-stationary: per row block i: ah.bh0 ah.bl0 ah.bh1 ah.bl1 (A = ah for four in a row), al.bh0 al.bh1 (A = al for two)
+//   2 = B-stationary: per column block j: ah.bh ah'.bh al.bh al'.bh (B = bh_j for four in a row), ah.bl ah'.bl (B = bl_j for two)
+template <int LDS, int ORDER = 0>
 __global__ __launch_bounds__(512, 2) void mfma_sustained_kernel(const half8 *src, float *out, int iters)
 {
     __shared__ half8 frag[8 * 512 + 64];
@@ -56,18 +60,55 @@ __global__ __launch_bounds__(512, 2) void mfma_sustained_kernel(const half8 *src
                 bl[i] = f[(6 + i) * 512];
             }
         }
+        if (ORDER == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        } else if (ORDER == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -106,8 +147,10 @@ int main(int argc, char **argv)
     CHECK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     const int iters = 400000;             // ~0.1-0.2 s per launch
     auto launch = [&]() {
-        if (variant == 0) hipLaunchKernelGGL(mfma_sustained_kernel<0>, dim3(blocks), dim3(512), 0, 0, src, out, iters);
-        else hipLaunchKernelGGL(mfma_sustained_kernel<1>, dim3(blocks), dim3(512), 0, 0, src, out, iters);
+        if (variant == 0) hipLaunchKernelGGL((mfma_sustained_kernel<0, 0>), dim3(blocks), dim3(512), 0, 0, src, out, iters);
+        else if (variant == 1) hipLaunchKernelGGL((mfma_sustained_kernel<1, 0>), dim3(blocks), dim3(512), 0, 0, src, out, iters);
+        else if (variant == 2) hipLaunchKernelGGL((mfma_sustained_kernel<0, 1>), dim3(blocks), dim3(512), 0, 0, src, out, iters);
+        else hipLaunchKernelGGL((mfma_sustained_kernel<0, 2>), dim3(blocks), dim3(512), 0, 0, src, out, iters);
     };
     launch();
     CHECK(hipDeviceSynchronize());
@@ -130,7 +173,7 @@ int main(int argc, char **argv)
     const double flops = (double)launches * blocks * 8.0 * iters * 12.0 * 32768.0;
     printf("variant %d (%s) data %s: %d workgroups of 8 waves on %d CUs, %ld launches, %.2f s of kernel time: %.1f TFLOP/s issued "
            "(= %.1f TF/s algorithmic at 3 products per flop), %.2f ns per 12-MFMA slice per wave\n",
-           variant, variant ? "MFMA + 8 ds_read_b128 per 12 MFMAs" : "register-resident MFMA only", rnd ? "random" : "zeros", blocks, cus,
+           variant, variant == 1 ? "MFMA + 8 ds_read_b128 per 12 MFMAs" : variant == 2 ? "register-resident, A-stationary order" : variant == 3 ? "register-resident, B-stationary order" : "register-resident MFMA only", rnd ? "random" : "zeros", blocks, cus,
            launches, total_ms / 1e3, flops / (total_ms * 1e-3) / 1e12, flops / (total_ms * 1e-3) / 1e12 / 3.0,
            total_ms * 1e6 / ((double)launches * iters));
     return 0;
