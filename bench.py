@@ -822,6 +822,11 @@ def main():
                        'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
                        'host_enqueue_ms_per_step_idle_gpu': round(host_enqueue_idle_ms, 3), 'plans_preloaded': plans_loaded,
                        'conv_engine': args.precision, 'pairs_in_flight': S * B, 'batches_in_flight': S,
+                       'stream_placement': {'main_streams': sstreams.MAIN_KIND, 'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
+                                            'branch_side_streams': sstreams.SIDE_KIND,
+                                            'note': 'each forward in flight on a HIP stream with a hardware queue of its own; a plan forks its '
+                                                    'independent branches onto side streams only while ONE forward is in flight '
+                                                    '(stereo_rcnn_amd/streams.py, profiles/queue_mapping_r04.txt)'},
                        'shipped_plans': ('%d conv plans from stereo_rcnn_amd/plans/mi355x.json: tuned on an MI355X with the measured %d-in-flight step '
                                          'as objective (stereo_rcnn_amd/tune.py); one_pair_at_a_time runs on the in-situ tuner\'s own picks' % (shipped, S)) if shipped else None,
                        'tuner_objective': ('concurrent: every conv plan timed with %d copies of the launch in flight on %d HIP streams (the regime '
