@@ -48,11 +48,11 @@ HW_QUEUES = 8
 
 def ensure_hw_queues(n=HW_QUEUES):
     """Ask the HIP runtime for at least `n` hardware queues per device (GPU_MAX_HW_QUEUES, read once when HIP starts), so that
-    the pooled streams of up to n - 1 forwards in flight and the null stream do not share queues.  Entry points (bench.py,
-    test_net.py, demo.py) call this before the first HIP call; returns False -- and changes nothing -- when HIP is already
+    the pooled streams of up to n - 1 forwards in flight and the null stream do not share queues.  Entry points that keep several pairs in flight
+    (bench.py, test_net.py) call this before the first HIP call; returns False -- and changes nothing -- when HIP is already
     up with fewer queues (the caller may then use 'dedicated' main streams, or at most GPU_MAX_HW_QUEUES - 1 in flight)."""
     cur = os.environ.get('GPU_MAX_HW_QUEUES')
-    if cur is not None and int(cur) >= n:
+    if cur is not None and cur.strip().isdigit() and int(cur) >= n:
         return True
     if torch.cuda.is_initialized():
         return False
@@ -62,7 +62,8 @@ def ensure_hw_queues(n=HW_QUEUES):
 
 def max_pairs_in_flight():
     """Forwards that can each have a pooled stream on a hardware queue of its own (one queue is the null stream's)."""
-    return max(1, int(os.environ.get('GPU_MAX_HW_QUEUES', '4')) - 1)
+    cur = os.environ.get('GPU_MAX_HW_QUEUES', '4')
+    return max(1, (int(cur) if cur.strip().isdigit() else 4) - 1)
 
 
 _handles = []      # native handles of the streams created here: they live as long as the process (the slots' streams are created
@@ -93,7 +94,7 @@ def new_stream(kind='pool', device=None):
     return torch.cuda.ExternalStream(h.value, device=dev)
 
 
-def partition_masks(parts, n_cus=256, local_bits=None):
+def partition_masks(parts, n_cus=256):
     """CU masks that split the device into `parts` equal partitions, each holding the same number of CUs of EVERY XCD.
 
     Bit b of a queue's CU mask: the driver deals the bits out round-robin over the XCDs (bit b -> XCD b % 8, that XCD's CU number
