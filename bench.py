@@ -5,6 +5,7 @@ batch=1, 300 proposals, no dense-align  (BASELINE.json configs[1]).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --config 2      # BASELINE configs[2]: batch = 8 pairs per forward, full 3-D pipeline incl. dense alignment
+    python bench.py --config 3      # BASELINE configs[3]: the 3769-id KITTI val list replayed from PNG files, sharded i mod N, gathered
     python bench.py --config 4      # BASELINE configs[4]: ResNet-50 trunk, 2x resolution (network input 1200x3974), batch = 4
 (same JSON contract; `config.workload` names the BASELINE entry; the default, --config 1, is the headline.)
 
@@ -41,7 +42,8 @@ ENGINE_DESC = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=None,
+                    help='timed steps (default 100; --config 3: the rank\'s whole shard of the 3769-id val list)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--graph', action='store_true',
                     help='replay the forward as one hipGraph instead of launching eagerly (measured slower on MI355X: the '
@@ -72,10 +74,12 @@ def parse():
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / collective check without a GPU: every rank packs fake detection records on the CPU and '
                          'gathers them over gloo; prints the JSON line with value 0 (used by the CPU tests)')
-    ap.add_argument('--config', type=int, default=1, choices=[1, 2, 4],
+    ap.add_argument('--config', type=int, default=1, choices=[1, 2, 3, 4],
                     help='BASELINE.json configs[] index of the workload: 1 = headline (batch 1, forward + decode + class NMS); '
                          '2 = batch 8 per forward + the whole 3-D flow (borders, 4-DoF solve, dense alignment, 3-DoF solve) per '
-                         'image; 4 = ResNet-50 trunk at network input 1200x3974, batch 4, forward + decode + class NMS')
+                         'image; 3 = the KITTI val list (3769 ids) replayed over synthetic PNG pairs through test_net.run_split: PNG decode, '
+                         'H2D, fused preprocessing, forward, full 3-D flow, KITTI result files, records gathered (throughput only: no '
+                         'dataset offline); 4 = ResNet-50 trunk at network input 1200x3974, batch 4, forward + decode + class NMS')
     ap.add_argument('--layers-out', default='',
                     help='write the full per-layer roofline table (every conv launch: shape, bytes, time, own bound) to this file; '
                          'the JSON line always carries the 15 layer groups that lose most time as roofline.layers')
@@ -284,6 +288,201 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+CONFIG3_TEXT = ('BASELINE configs[3]: KITTI val list (%(n)d ids, data/kitti/splits/val.txt) replayed over %(d)d synthetic %(w)dx%(h)d PNG stereo '
+                'pairs (no dataset offline: throughput only, AP not checkable), ids sharded i mod N over %(world)d GPU(s); per frame: PNG '
+                'decode (host threads) -> H2D -> fused preprocessing -> ResNet-101 FPN forward -> decode + class NMS -> keypoints of the '
+                'kept detections -> borders -> 4-DoF Newton-CG (host C threads) -> dense alignment -> 3-DoF Newton-CG -> KITTI result '
+                'file (stereo_rcnn_amd.test_net.run_split); per-frame records gathered by one all_gather at the end')
+
+
+def _fake_objects_from_pixels(left):
+    """Dry run only (no GPU): deterministic fake detections from the decoded frame, so that the writer and the gather carry data."""
+    import numpy as np
+    rng = np.random.default_rng(int(left[0, 0, 0]) + 1)
+    objs = []
+    for i in range(int(left[0, 0, 0]) % 3 + 1):
+        x1, y1 = rng.uniform(0, 300), rng.uniform(20, 80)
+        objs.append({'score': float(rng.uniform(0.1, 1)), 'box_left': np.array([x1, y1, x1 + 40, y1 + 30], np.float32),
+                     'box_right': np.array([x1 - 8, y1, x1 + 32, y1 + 30], np.float32), 'dim': np.array([1.6, 1.5, 4.0]),
+                     'alpha': 0.3 * i, 'kpts': np.array([x1 + 5, 1, 0.9, x1, x1 + 40], np.float32),
+                     'xyz_init': rng.uniform(-5, 30, 3), 'theta_init': 0.1, 'xyz': rng.uniform(-5, 30, 3), 'theta': 0.2 + i,
+                     'aligned': True, 'disparity': float(rng.uniform(5, 60)), 'roi_index': i})
+    return objs
+
+
+def run_config3(args, rank, local_rank, world, use_dist):
+    """BASELINE configs[3] (the reference's test_net.py:109-136,217-225,329-334 over data/kitti/splits/val.txt): one step = one
+    frame of the rank's shard through stereo_rcnn_amd.test_net.run_split -- everything between the PNG files and the KITTI result
+    files -- followed by the gather of the per-frame records.  Same JSON contract; `config.host_ms_per_pair` splits the host side
+    (decode / H2D issue / solves / result files / waiting for the GPU) and `config.host_saturation` says at how many pairs/s one
+    rank's host budget (cores / LOCAL_WORLD_SIZE) is used up -- the scaling limiter SURVEY 8(e) names."""
+    import shutil
+    import tempfile
+    from stereo_rcnn_amd import fixture, test_net
+    from stereo_rcnn_amd import distributed as sdist
+    dry = bool(args.dry_run)
+    if not dry:
+        from stereo_rcnn_amd import serving
+        serving.before_hip()
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('gloo' if dry else 'nccl')
+    n_ids = fixture.KITTI_VAL_IDS
+    all_idx = sdist.shard_indices(n_ids, rank, world)
+    K = len(all_idx) if args.steps is None else int(args.steps)
+    W = max(0, int(args.warmup))
+    distinct = 4 if dry else 8
+    h, w = (40, 120) if dry else (args.height, args.width)
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+    root = tempfile.mkdtemp(prefix='srcnn_val_r%d_' % rank, dir=base)
+    res_dir = os.path.join(root, 'results')
+    try:
+        # every rank replays its own copy of the tree (tmpfs); only the ids it owns (and their pool files) are ever opened
+        need = sorted(set(all_idx[i % len(all_idx)] for i in range(max(K, 1))) | set(all_idx[:max(W, 8)]))
+        ids = fixture.write_kitti_tree(root, n_ids, distinct, h, w)
+        mine = [ids[all_idx[i % len(all_idx)]] for i in range(K)]
+        warm = [ids[i] for i in all_idx[:max(W, 8)]]
+        del need
+        lw = sdist.local_world_size()
+        threads = sdist.host_solver_threads()
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cpus = os.cpu_count() or 1
+        budget = max(1, cpus // lw)
+        prefetch = max(4, min(16, budget))                     # PNG decode threads (PIL releases the GIL while inflating)
+        timers, ptimers = {}, {}
+        records = []
+        if dry:
+            dev, model, detect = None, None, (lambda frames: (_fake_objects_from_pixels(f[0]) for f in frames))
+            slots, roof, numa = 0, None, None
+            test_net.run_split(None, root, warm[:2], res_dir, None, detect_stream=detect, prefetch=2)
+            if use_dist:
+                dist.barrier()
+            t0 = time.perf_counter()
+            test_net.run_split(None, root, mine, res_dir, None, detect_stream=detect, prefetch=2, records=records, timers=timers)
+        else:
+            from stereo_rcnn_amd import _lib, engine, pipeline
+            from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+            torch.cuda.set_device(local_rank)
+            dev = torch.device('cuda', local_rank)
+            _lib.lib()
+            numa = sdist.pin_to_gpu_numa(local_rank) if use_dist and world > 1 else None
+            pipeline.HOST_SOLVER_THREADS = threads
+            model = resnet(('__background__', 'Car'), 101, pretrained=False)
+            model.create_architecture()
+            model.load_state_dict(fixture.make_state_dict(3))
+            model.cuda()
+            model.eval()
+            model.precision = args.precision
+            model.use_program = not args.no_program
+            slots = max(1, args.streams) if args.streams > 0 else 4
+            test_net.run_split(model, root, warm, res_dir, dev, solver='host', slots=slots, prefetch=prefetch)   # calibration, tuning, programs
+            # algorithmic conv work of one frame as this flow runs it (keypoint tower on the kept detections only): one eager frame
+            # with the counter on; the row-limited launches are counted at the share of their rows that ran
+            from stereo_rcnn_amd.model.utils import kitti_utils
+            lu = torch.from_numpy(test_net.read_png_rgb(os.path.join(root, 'image_2', warm[0] + '.png'))).to(dev)
+            ru = torch.from_numpy(test_net.read_png_rgb(os.path.join(root, 'image_3', warm[0] + '.png'))).to(dev)
+            calib = kitti_utils.read_obj_calibration(os.path.join(root, 'calib', warm[0] + '.txt'))
+            prog, model.use_program = model.use_program, False
+            engine.FlopCounter.enabled, engine.FlopCounter.flops, engine.FlopCounter.launches, engine.FlopCounter.bytes = True, 0.0, 0, 0.0
+            engine.FlopCounter.rows = []
+            objs0 = pipeline.detect_3d_images(model, lu, ru, calib, slot=slots + 1)
+            torch.cuda.synchronize()
+            rows, engine.FlopCounter.rows, engine.FlopCounter.enabled = engine.FlopCounter.rows, None, False
+            model.use_program = prog
+            kept = int(pipeline._stage(300, dev, slots + 1).rec_host[0, 0])       # detections class NMS kept in that frame
+            flops_pair = sum(r['flops'] * ((kept / 300.0) if r['name'].startswith('kpts') else 1.0) for r in rows)
+            roof = {'flops_pair': flops_pair, 'kept': kept, 'objects': len(objs0)}
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            pipeline.TIMERS = ptimers
+            t0 = time.perf_counter()
+            test_net.run_split(model, root, mine, res_dir, dev, solver='host', slots=slots, prefetch=prefetch, records=records,
+                               timers=timers)
+            pipeline.TIMERS = None
+        t_split = time.perf_counter() - t0
+        # the gather of the split: this rank's K records (frame j of the job lives on rank j % world), ONE all_gather
+        recs = records if dry else [r.to(dev) for r in records]
+        full = sdist.gather_split_records(recs, K * world, rank, world)
+        if not dry:
+            torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed, t_split], dtype=torch.float64, device=dev if (use_dist and not dry) else 'cpu')
+        if use_dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el[0])
+        n_files = len(os.listdir(os.path.join(res_dir, 'data')))
+        assert int(full.shape[0]) == K * world and n_files >= min(K, len(all_idx)), (tuple(full.shape), n_files)
+        objects = int(sum(float(r[0, 0]) for r in records))
+        per = lambda key, src: round(src.get(key, 0.0) * 1e3 / max(K, 1), 3)
+        main_busy = max(0.0, timers.get('loop_s', 0.0) - ptimers.get('gpu_wait_s', 0.0))
+        host_ms = {'png_decode_and_calib_parse': per('decode_s', timers), 'png_decode_threads': prefetch,
+                   'h2d_issue': per('h2d_s', timers), 'newton_cg_solves_wall': per('solve_s', ptimers), 'host_solver_threads': threads,
+                   'result_files_and_record': per('write_s', timers), 'waiting_for_the_gpu': per('gpu_wait_s', ptimers),
+                   'main_thread_busy': round(main_busy * 1e3 / max(K, 1), 3),
+                   'note': 'ms per pair on THIS rank; decode is summed over its threads (they run ahead of the loop); main_thread_busy = loop '
+                           'wall time minus time blocked on the device = launching, solves, result files, Python'}
+        dec_rate = prefetch * 1e3 / max(host_ms['png_decode_and_calib_parse'], 1e-6)
+        main_rate = 1e3 / max(host_ms['main_thread_busy'], 1e-6)
+        cpu_ms = host_ms['png_decode_and_calib_parse'] + host_ms['main_thread_busy'] + host_ms['newton_cg_solves_wall'] * max(threads - 1, 0)
+        saturation = {'cores_budget_per_rank': budget, 'LOCAL_WORLD_SIZE': lw,
+                      'decode_bound_pairs_per_s': round(dec_rate, 1), 'main_thread_bound_pairs_per_s': round(main_rate, 1),
+                      'core_seconds_bound_pairs_per_s': round(budget * 1e3 / max(cpu_ms, 1e-6), 1),
+                      'pairs_per_s_at_which_the_host_saturates': round(min(dec_rate, main_rate, budget * 1e3 / max(cpu_ms, 1e-6)), 1),
+                      'note': 'one rank: decode threads x 1 / decode ms; the single-threaded loop (launches + solves + files); and the '
+                              'rank\'s core budget / CPU ms per pair (solver threads counted as busy for the solve wall time) -- the smallest '
+                              'is where the host side of this rank stops scaling'}
+        if rank == 0:
+            nh, nw_ = (0, 0)
+            roofline = None
+            if not dry:
+                from stereo_rcnn_amd import engine as _e
+                nh, nw_, _ = _e.preprocess_size(h, w, 600)
+                ach = roof['flops_pair'] * (K * world / elapsed) / world / 1e12          # per GPU
+                roofline = {'bound': 'mfma', 'kernel': ENGINE_DESC[args.precision], 'achieved': round(ach, 2), 'peak': PEAKS[args.precision],
+                            'unit': 'TFLOP/s', 'frac': round(ach / PEAKS[args.precision], 4), 'traffic': None,
+                            'algorithmic_gflop_per_step': round(roof['flops_pair'] / 1e9, 1),
+                            'execution': 'whole-flow mode: algorithmic conv FLOPs of one frame as this flow runs it (keypoint tower on the %d '
+                                         'detections class NMS kept of 300 rois) x pairs/s per GPU; the kernel-level figure (HIP events per '
+                                         'launch, PMC traffic) is `python bench.py` (--config 1), same kernels' % roof['kept']}
+            res = {'metric': 'stereo pairs/sec @1242x375 ResNet-101', 'value': round(K * world / elapsed, 3), 'unit': 'stereo pairs/s',
+                   'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(elapsed / max(K, 1) * 1e3, 3), 'higher_is_better': True,
+                   'scaling': 'weak' if args.steps is not None else 'strong', 'vs_baseline': None,
+                   'dtype': 'none' if dry else ('f32' if args.precision == 'f32' else 'f32 result via 3xf16 split MFMA (f32 accumulate)'),
+                   'data': 'synthetic',
+                   'config': {'workload': ('DRY RUN (no GPU, injected detector): ' if dry else '') + CONFIG3_TEXT
+                              % {'n': n_ids, 'd': distinct, 'w': w, 'h': h, 'world': world},
+                              'baseline_config_index': 3, 'pairs_per_step': 1, 'frames_per_rank': K, 'val_ids': n_ids,
+                              'network_input': [nh, nw_], 'pairs_in_flight': slots, 'solver': 'host (C threads, bit-identical to scipy)',
+                              'keypoints_on_kept_detections_only': True, 'objects_written_rank0': objects,
+                              'result_files_rank0': n_files, 'records_gathered': [int(v) for v in full.shape],
+                              'split_ms_per_pair_before_gather': round(float(el[1]) / max(K, 1) * 1e3, 3),
+                              'gather_ms_total': round((elapsed - float(el[1])) * 1e3, 2),
+                              'host_ms_per_pair': host_ms, 'host_saturation': saturation, 'numa_pinning': numa,
+                              'weights': 'seeded random init, reference state_dict schema',
+                              'parallelism': ('ids sharded i mod %d, weights replicated, no data-path collective; one all_gather of the '
+                                              'per-frame records at the end' % world) if use_dist else 'single GPU',
+                              'scaling_note': 'default --steps = the rank\'s whole shard of the %d ids (total work fixed: strong); '
+                                              '--steps K = K frames per rank (weak)' % n_ids},
+                   'roofline': roofline}
+            if dry:
+                res['dry_run'] = True
+            elif not args.no_cpu_baseline and world == 1:
+                res['cpu_baseline'] = cpu_baseline(2, h, w)
+            print(json.dumps(res), flush=True)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
 WORKLOADS = {
     1: dict(layers=101, batch=1, streams=4, flow='2d',
             text='BASELINE configs[1]: ResNet-101 FPN, batch=1 stereo pair per GPU, %(w)dx%(h)d synthetic (network input %(nw)dx%(nh)d), '
@@ -333,12 +532,23 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     use_dist = 'RANK' in os.environ          # launched by torch.distributed.run (any world size, incl. 1)
+    if args.config == 3:
+        return run_config3(args, rank, local_rank, world, use_dist)
+    if args.steps is None:
+        args.steps = 100
     if args.dry_run:
         return dry_run(args, rank, world)
     assert world == args.gpus or not use_dist, "launched with %d ranks for --gpus %d" % (world, args.gpus)
-    # every forward in flight on a hardware queue of its own: GPU_MAX_HW_QUEUES is read once, when HIP starts (stereo_rcnn_amd/streams.py)
+    # every forward in flight on a hardware queue of its own: GPU_MAX_HW_QUEUES is read once, when HIP starts
+    # (stereo_rcnn_amd/serving.py -- the same regime set-up the product's streamed entry points use)
+    from stereo_rcnn_amd import serving
     from stereo_rcnn_amd import streams as sstreams
-    sstreams.ensure_hw_queues()
+    queues_ok = serving.before_hip()
+    if use_dist and world > 1:
+        # first multi-GPU runs must be diagnosable: under torchrun every rank is its own process and reads the variable itself
+        assert queues_ok and int(os.environ.get('GPU_MAX_HW_QUEUES', '0')) >= sstreams.HW_QUEUES, \
+            'rank %d: GPU_MAX_HW_QUEUES=%r before HIP init (needs >= %d: one hardware queue per forward in flight)' \
+            % (rank, os.environ.get('GPU_MAX_HW_QUEUES'), sstreams.HW_QUEUES)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -380,11 +590,13 @@ def main():
     # the multi-stream regime is tuned by the measured step itself instead (stereo_rcnn_amd/tune.py -> the shipped plan file)
     tune_mode = args.tune if args.tune != 'auto' else 'isolated'
     engine.set_tune_mode(tune_mode, S)
-    sstreams.set_pairs_in_flight(S)        # S > 1: branches stay on the forwards' main streams (stereo_rcnn_amd/streams.py)
-    from stereo_rcnn_amd import tune as stune
-    shipped = 0
-    if not args.no_shipped_plans and not args.plans and tune_mode == 'isolated' and args.precision == 'f16x3':
-        shipped = stune.load_shipped_plans()
+    # the serving regime (S > 1: branches stay on the forwards' main streams, shipped throughput-tuned plans adopted): the SAME
+    # call pipeline.detect_3d_stream / test_net.py make -- the benchmark measures what the product runs
+    want_plans = not args.no_shipped_plans and not args.plans and tune_mode == 'isolated' and args.precision == 'f16x3'
+    if not want_plans:
+        serving.USE_SHIPPED_PLANS = False          # ... nor may a later leg (the 3-D flow enters the regime itself) adopt them
+    regime = serving.enter(S, device=dev, plans=want_plans)
+    shipped = regime['shipped_plans'] if want_plans else 0
     plans_loaded = bool(args.plans) and os.path.exists(args.plans) and engine.load_plans(args.plans) > 0
     if args.pmc_child:              # counter-collection child of measure_traffic_live(): forwards only, one at a time
         assert plans_loaded, "--pmc-child needs the parent's tuned plans"
@@ -517,11 +729,14 @@ def main():
         if use_dist:
             spans = gather_spans[-max(1, (args.steps + G - 1) // G):]
             gms = sum(a.elapsed_time(b) for a, b in spans) / max(args.steps, 1) if spans else 0.0
-            mine = torch.tensor([elapsed / args.steps * 1e3, gms], dtype=torch.float64, device=dev)
+            mine = torch.tensor([elapsed / args.steps * 1e3, gms, host_enqueue_ms], dtype=torch.float64, device=dev)
             allr = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
             multi_gpu = {'per_rank_ms_per_step': [round(float(t[0]), 3) for t in allr],
                          'per_rank_gather_ms_per_step': [round(float(t[1]), 4) for t in allr],
+                         # N Python processes share the host: a rank whose enqueue time approaches its step time is host-bound
+                         'per_rank_host_enqueue_ms_per_step': [round(float(t[2]), 3) for t in allr],
+                         'GPU_MAX_HW_QUEUES_per_rank': os.environ.get('GPU_MAX_HW_QUEUES'),
                          'gather_share_of_step': round(max(float(t[1]) for t in allr) / max(float(t[0]) for t in allr), 4),
                          'note': 'each rank times its own K steps (barrier before and after); value uses the max; the all_gather of the '
                                  'detection records runs on a side stream, one per %d steps, overlapped with the following forwards' % G}

@@ -25,6 +25,9 @@ def main(argv=None):
     ap.add_argument('--checkpoint', required=True)
     ap.add_argument('--precision', choices=['f16x3', 'f32'], default='f16x3')
     args = ap.parse_args(argv)
+    from . import serving
+    serving.before_hip()
+    serving.enter(1)                      # one pair: latency regime (branches on side streams, in-situ plans)
     dev = torch.device('cuda:0')
     model = resnet(('__background__', 'Car'), 101, pretrained=False)
     model.create_architecture()

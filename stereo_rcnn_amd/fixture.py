@@ -172,3 +172,44 @@ def make_inputs(seed=3, height=375, width=1242, device='cpu', target_short=600):
     tr, _ = preprocess(r, target_short, device=device)
     info = torch.tensor([[tl.shape[2], tl.shape[3], s]], dtype=torch.float32, device=device)
     return tl, tr, info
+
+
+# --------------------------------------------------------------------------- a KITTI object tree of synthetic frames
+KITTI_VAL_IDS = 3769     # ids of the reference's data/kitti/splits/val.txt (BASELINE.json words it "3712 pairs"; the file has 3769)
+
+DEMO_CALIB_ROWS = (
+    ('P0', (721.5377, 0, 609.5593, 0, 0, 721.5377, 172.854, 0, 0, 0, 1, 0)),
+    ('P1', (721.5377, 0, 609.5593, -387.5744, 0, 721.5377, 172.854, 0, 0, 0, 1, 0)),
+    ('P2', (721.5377, 0, 609.5593, 44.85728, 0, 721.5377, 172.854, 0.2163791, 0, 0, 1, 0.002745884)),
+    ('P3', (721.5377, 0, 609.5593, -339.5242, 0, 721.5377, 172.854, 2.199936, 0, 0, 1, 0.002729905)),
+    ('R0_rect', (1, 0, 0, 0, 1, 0, 0, 0, 1)),
+    ('Tr_velo_to_cam', (1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0)),
+)
+
+
+def write_kitti_tree(root, n_ids=KITTI_VAL_IDS, distinct=16, height=375, width=1242, seed0=3, split_name='val.txt'):
+    """A KITTI object `training/` tree (image_2/, image_3/, calib/ -- the layout lib/datasets/kitti.py:60-75 reads, the one
+    test_net.run_split takes) whose `n_ids` frames replay `distinct` seeded synthetic PNG pairs: the real split cannot be
+    shipped (no dataset offline), its LENGTH and per-frame host work (PNG decode of two 375x1242 images, calibration parse,
+    result file) can.  Frame i is a symlink to pair i % distinct, so the tree costs `distinct` x 2 PNGs of disk (tmpfs) and
+    every frame still goes through a real file open + PNG decode.  Returns the id list (also written as <root>/<split_name>)."""
+    import os
+    from PIL import Image
+    for d in ('image_2', 'image_3', 'calib', '_pool'):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    calib = os.path.join(root, '_pool', 'calib.txt')
+    with open(calib, 'w') as fh:
+        fh.write('\n'.join('%s: %s' % (k, ' '.join('%.12e' % v for v in vals)) for k, vals in DEMO_CALIB_ROWS) + '\n')
+    for p in range(distinct):
+        left, right = synthetic_pair(seed0 + p, height, width)
+        Image.fromarray(left).save(os.path.join(root, '_pool', 'l_%03d.png' % p))
+        Image.fromarray(right).save(os.path.join(root, '_pool', 'r_%03d.png' % p))
+    ids = ['%06d' % i for i in range(n_ids)]
+    for i, frame in enumerate(ids):
+        for d, src in (('image_2', 'l_%03d.png' % (i % distinct)), ('image_3', 'r_%03d.png' % (i % distinct)), ('calib', 'calib.txt')):
+            dst = os.path.join(root, d, frame + ('.txt' if d == 'calib' else '.png'))
+            if not os.path.lexists(dst):
+                os.symlink(os.path.join('..', '_pool', src), dst)
+    with open(os.path.join(root, split_name), 'w') as fh:
+        fh.write('\n'.join(ids) + '\n')
+    return ids

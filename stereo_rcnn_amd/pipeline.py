@@ -223,6 +223,20 @@ def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape,
 
 
 HOST_SOLVER_THREADS = 0          # srcnn_solve_*_records_host: <= 0 = one thread per 8 detections, at most 16
+# host-side accounting of the record flow (bench.py --config 3): a dict {'solve_s', 'gpu_wait_s'} that step_3d / collect_3d add
+# to -- wall seconds of the host Newton-CG calls, and seconds the host sat in event.synchronize() waiting for the device
+TIMERS = None
+
+
+def _timed(key, t0):
+    if TIMERS is not None:
+        import time
+        TIMERS[key] = TIMERS.get(key, 0.0) + time.perf_counter() - t0
+
+
+def _now():
+    import time
+    return time.perf_counter() if TIMERS is not None else 0.0
 
 
 def step_3d(st):
@@ -233,14 +247,18 @@ def step_3d(st):
     L = _lib.lib()
     stream, iml, imr, scale, cal, im_h, im_w, thresh, dense = st.ctx
     n = st.n
+    t0 = _now()
     st.event.synchronize()
+    _timed('gpu_wait_s', t0)
     if st.phase == 1:
         if st.rec_host[0, 1] > 0:                              # range guard: collect_3d raises
             st.phase = 0
             return
+        t0 = _now()
         _lib.check(L.srcnn_solve_4dof_records_host(st.rec_host.data_ptr(), n, REC_COLS, im_h, im_w, cal[0], cal[1], cal[2],
                                                    cal[3], thresh, st.state_host[0].data_ptr(), HOST_SOLVER_THREADS),
                    "srcnn_solve_4dof_records_host")
+        _timed('solve_s', t0)
         st.state_host[1].zero_()
         if not dense or not bool((st.rec_host[1:1 + int(st.rec_host[0, 0]), 20] > 0).any()):
             st.phase = 0
@@ -261,10 +279,12 @@ def step_3d(st):
             st.event.record()
         st.phase = 2
         return
+    t0 = _now()
     _lib.check(L.srcnn_solve_3dof_records_host(st.rec_host.data_ptr(), n, REC_COLS, im_h, im_w, cal[0], cal[1], cal[2], cal[3],
                                                st.align_host[0].data_ptr(), st.align_host[1].data_ptr(),
                                                st.state_host[1].data_ptr(), HOST_SOLVER_THREADS),
                "srcnn_solve_3dof_records_host")
+    _timed('solve_s', t0)
     st.phase = 0
 
 
@@ -273,7 +293,9 @@ def collect_3d(st):
     while st.phase:
         step_3d(st)
     st.ctx = None
+    t0 = _now()
     st.event.synchronize()
+    _timed('gpu_wait_s', t0)
     rec, state = st.rec_host.numpy(), st.state_host.numpy()
     if rec[0, 1] > 0:           # SPLIT16 range guard of THIS pair's forward (its plan's own word, copied and cleared by the pack)
         from . import engine
@@ -534,8 +556,10 @@ def _slot_streams(n):
     have = _stream_cache.setdefault(dev, [])
     while len(have) < n:
         have.append(_streams.new_stream(_streams.MAIN_KIND if _streams.MAIN_KIND in _streams.KINDS else 'dedicated'))
-    _streams.check_queue_supply(n)
-    _streams.set_pairs_in_flight(n)           # n > 1: the plans keep their branches on the main streams (streams.py)
+    # the serving regime of bench.py's headline (serving.py): branches stay on the main streams with n > 1, the hardware-queue
+    # supply is checked, and the shipped throughput-tuned conv plans are adopted (once; MI355X only; matching shapes only)
+    from . import serving
+    serving.enter(n)
     return have[:n]
 
 

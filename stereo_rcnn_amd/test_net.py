@@ -37,7 +37,7 @@ def read_png_rgb(path):
 
 
 def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4,
-              solver='host', slots=3, detect_stream=None, records=None):
+              solver='host', slots=3, detect_stream=None, records=None, timers=None):
     """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds).
     `detect_stream(frames)`: replaces the detector (a generator of object lists, one per frame) -- the CPU tests drive the
     sharding / writer / gather logic with it; `records`: a list that receives one detection record per frame
@@ -46,16 +46,26 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
     uint8 images are copied to the device and everything else -- preprocessing, forward, decode, NMS, borders, 4-DoF solve,
     dense alignment, 3-DoF rectification -- runs on the record flow with `slots` pairs in flight: solver='host' (default; the
     Newton-CG solves in C on the host between the device stages, bit-identical to the scipy path) or 'device' (solves as
-    kernels).  solver='scipy' (with a SolverPool) runs the reference's host arrangement instead: the comparison path."""
+    kernels).  solver='scipy' (with a SolverPool) runs the reference's host arrangement instead: the comparison path.
+    `timers`: a dict that receives the host-side seconds of the loop (bench.py --config 3): 'decode_s' (PNG decode + calibration
+    parse, summed over the prefetch threads), 'h2d_s' (issuing the uint8 copies), 'write_s' (KITTI result files + record),
+    'loop_s' (wall time of the whole loop); pipeline.TIMERS holds the solver and GPU-wait shares of the same loop."""
     import collections
     import concurrent.futures as cf
     t0, n_obj = time.time(), 0
     os.makedirs(os.path.join(result_dir, 'data'), exist_ok=True)
+    if timers is not None:
+        for k in ('decode_s', 'h2d_s', 'write_s', 'loop_s'):
+            timers.setdefault(k, 0.0)
 
     def load(frame):
-        return (read_image(os.path.join(kitti_root, 'image_2', frame + '.png')),
-                read_image(os.path.join(kitti_root, 'image_3', frame + '.png')),
-                kitti_utils.read_obj_calibration(os.path.join(kitti_root, 'calib', frame + '.txt')))
+        td = time.perf_counter()
+        out = (read_image(os.path.join(kitti_root, 'image_2', frame + '.png')),
+               read_image(os.path.join(kitti_root, 'image_3', frame + '.png')),
+               kitti_utils.read_obj_calibration(os.path.join(kitti_root, 'calib', frame + '.txt')))
+        if timers is not None:
+            timers['decode_s'] += time.perf_counter() - td        # (float += under the GIL: good enough for a per-pair average)
+        return out
 
     calibs = collections.deque()
 
@@ -76,7 +86,10 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
         calibs.append(calib)
         if detect_stream is not None:
             return (left, right, calib)                         # injected detector: frames stay on the host
+        th = time.perf_counter()
         lu, ru = torch.from_numpy(left).to(device, non_blocking=True), torch.from_numpy(right).to(device, non_blocking=True)
+        if timers is not None:
+            timers['h2d_s'] += time.perf_counter() - th
         if solver in ('device', 'host'):
             return (lu, ru, calib)                              # preprocessing is fused in front of the forward
         l, scale = engine.preprocess(lu, cfg.TEST.SCALES[0])
@@ -97,16 +110,21 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
 
     for k, (frame, objs) in enumerate(zip(ids, results())):
         calib = calibs.popleft()
+        tw = time.perf_counter()
         open(os.path.join(result_dir, 'data', frame + '.txt'), 'w').close()      # a frame without detections still gets a file
         pipeline.write_kitti_results(result_dir, frame, calib, [o for o in objs if o['aligned']])   # test_net.py:322-330
         n_obj += sum(o['aligned'] for o in objs)
         if records is not None:
             from .distributed import objects_to_record
             records.append(objects_to_record(objs))
+        if timers is not None:
+            timers['write_s'] += time.perf_counter() - tw
         if log and (k + 1) % 50 == 0:
             log('%d/%d frames, %.1f frames/s' % (k + 1, len(ids), (k + 1) / (time.time() - t0)))
     if device is not None and torch.device(device).type == 'cuda':
         torch.cuda.synchronize(device)
+    if timers is not None:
+        timers['loop_s'] += time.time() - t0
     return len(ids), n_obj, time.time() - t0
 
 
@@ -127,8 +145,9 @@ def main(argv=None):
     args = ap.parse_args(argv)
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     use_dist = 'RANK' in os.environ and world > 1
-    from . import streams as _streams
-    _streams.ensure_hw_queues()          # before HIP starts: one hardware queue per pair in flight (streams.py)
+    from . import serving
+    serving.before_hip()                 # before HIP starts: one hardware queue per pair in flight (serving.py, streams.py);
+                                         # run_split -> pipeline.detect_3d_stream enters the serving regime (plans, branch placement)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

@@ -32,10 +32,8 @@ def shipped_plans_path(name='mi355x.json'):
 def load_shipped_plans(name='mi355x.json'):
     """Adopt the shipped throughput-tuned plans (shape keys carry batch and frame size, so only matching shapes use them).
     Returns the number of plans loaded (0 if the file is absent)."""
-    p = shipped_plans_path(name)
-    if not os.path.exists(p):
-        return 0
-    return engine.load_plans(p)
+    from . import serving                  # the product's own loader (device-model gated); tools force a reload
+    return serving.load_shipped_plans(name, force=True)
 
 
 class StepRunner(object):
@@ -52,7 +50,7 @@ class StepRunner(object):
         hpost.class_nms_device(det, 1, 0.05)
 
     def run(self, n):
-        _streams.set_pairs_in_flight(self.S)
+        _streams.set_pairs_in_flight(self.S)      # (the tuner itself starts from whatever plans are loaded: it does not call serving.enter)
         for k in range(n):
             if self.S == 1:
                 self.step(0)

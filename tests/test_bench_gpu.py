@@ -73,3 +73,24 @@ def test_bench_other_baseline_configs_are_driver_runnable(dev, cfg, batch):
     assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and r['conv_ms_per_step'] <= r['step_ms_of_this_execution'] * 1.02
     assert len(r['layers']) == 15 and all(g['us'] > 0 and g['own_bound_us'] > 0 for g in r['layers'])
     assert r['layers'] == sorted(r['layers'], key=lambda g: -g['lost_us'])
+
+
+def test_bench_config3_val_list_replay_is_driver_runnable(dev):
+    """BASELINE.json configs[3]: frames of the 3769-id val list replayed from PNG files through test_net.run_split (decode, H2D,
+    fused preprocessing, forward, full 3-D flow with the host solver, KITTI result files) and gathered -- one JSON line of the
+    same contract, with the host-side split per pair and the rate at which one rank's host budget saturates."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '3', '--steps', '32', '--warmup', '8',
+                          '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')][-1])
+    c = d['config']
+    assert KEYS <= set(d) and d['steps'] == 32 and d['n_gpus'] == 1 and d['unit'] == 'stereo pairs/s' and 'dry_run' not in d
+    assert c['baseline_config_index'] == 3 and 'BASELINE configs[3]' in c['workload'] and 'model' not in c
+    assert c['network_input'] == [600, 1987] and c['records_gathered'] == [32, 301, 32] and c['result_files_rank0'] >= 32
+    assert d['value'] > 20 and abs(d['value'] - 1e3 / d['ms_per_step']) < 0.05 * d['value']
+    assert c['objects_written_rank0'] > 0                       # the 3-D flow solved and aligned objects on the synthetic frames
+    hm = c['host_ms_per_pair']
+    assert hm['png_decode_and_calib_parse'] > 1.0 and hm['newton_cg_solves_wall'] > 0 and hm['main_thread_busy'] > 0
+    assert c['host_saturation']['pairs_per_s_at_which_the_host_saturates'] > 10
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and 1200 < r['algorithmic_gflop_per_step'] < 1960

@@ -209,3 +209,48 @@ def test_kitti_split_driver_world_size_2_gloo(tmp_path):
         assert len(lines) == sum(o['aligned'] for o in objs)
         total_aligned += len(lines)
     assert total_aligned == got[0][2] + got[1][2]
+
+
+def test_synthetic_kitti_tree_is_what_run_split_reads(tmp_path):
+    """fixture.write_kitti_tree: the layout test_net.run_split takes, `n_ids` frames replaying `distinct` PNG pairs through real
+    files (symlinks), calibration readable by the product's own parser."""
+    import numpy as np
+    from stereo_rcnn_amd import fixture, test_net
+    from stereo_rcnn_amd.model.utils import kitti_utils
+    root = str(tmp_path / 'training')
+    ids = fixture.write_kitti_tree(root, n_ids=7, distinct=2, height=24, width=64)
+    assert ids == ['%06d' % i for i in range(7)] == test_net.read_split(os.path.join(root, 'val.txt'))
+    a, b = test_net.read_png_rgb(os.path.join(root, 'image_2', '000001.png')), test_net.read_png_rgb(os.path.join(root, 'image_2', '000003.png'))
+    c = test_net.read_png_rgb(os.path.join(root, 'image_2', '000002.png'))
+    assert a.shape == (24, 64, 3) and a.dtype == np.uint8 and np.array_equal(a, b) and not np.array_equal(a, c)
+    left, right = fixture.synthetic_pair(3 + 1, 24, 64)
+    assert np.array_equal(a, left) and np.array_equal(test_net.read_png_rgb(os.path.join(root, 'image_3', '000001.png')), right)
+    cal = kitti_utils.read_obj_calibration(os.path.join(root, 'calib', '000006.txt'))
+    assert abs(cal.p2[0, 0] - 721.5377) < 1e-9 and abs(cal.p2[0, 3] - cal.p3[0, 3] - (44.85728 + 339.5242)) < 1e-6
+    assert fixture.KITTI_VAL_IDS == 3769
+
+
+def test_bench_config3_val_list_replay_dry_run_world_2():
+    """BASELINE configs[3] through the driver's own contract, two ranks over gloo, no GPU: the 3769-id list sharded i mod 2,
+    every rank replays its frames from PNG files through test_net.run_split (injected detector), writes one KITTI file per
+    frame, and the per-frame records of the whole job are gathered by one all_gather."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--config', '3', '--steps', '7', '--warmup', '1',
+                          '--dry-run'], cwd=root, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == 2 and d['steps'] == 7 and d['dry_run'] is True and d['unit'] == 'stereo pairs/s' and d['value'] > 0
+    assert c['baseline_config_index'] == 3 and c['val_ids'] == 3769 and 'configs[3]' in c['workload']
+    assert c['records_gathered'] == [14, 301, 32] and c['result_files_rank0'] == 7 and c['objects_written_rank0'] >= 7
+    hm, sat = c['host_ms_per_pair'], c['host_saturation']
+    assert hm['png_decode_and_calib_parse'] > 0 and hm['result_files_and_record'] > 0 and hm['main_thread_busy'] > 0
+    assert sat['LOCAL_WORLD_SIZE'] == 2 and sat['pairs_per_s_at_which_the_host_saturates'] > 0
+    assert {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+            'data', 'config', 'roofline'} <= set(d)
