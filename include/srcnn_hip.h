@@ -235,6 +235,14 @@ SRCNN_API int srcnn_proposal_layer(const float *probs, const float *deltas, int 
                          int pre_nms, int post_nms, float nms_thresh,
                          float *rois_left, float *rois_right, int *num_valid /* (B) device, may be NULL */,
                          void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
+/* Inspection (tests; not on the hot path): where srcnn_proposal_layer leaves its intermediates in the caller's workspace after
+ * a call with the same (B, num_anchors, pre_nms) -- byte offsets of: [0] order (B x n int32: the n = min(pre_nms, A) best
+ * anchors, descending score, ties by ascending index), [1] dets (B x 2 x n x 5 float32: decoded + clipped left / right boxes and
+ * the score, in that order), [2] keep (B x 2 x n int32: ascending row indices that survive the NMS; the left / right scans of an
+ * image stop together once post_nms rows survive in both, so each list is a PREFIX of the full greedy list), [3] num (B x 2
+ * int32: entries of each keep list), [4] total bytes.  This is what lets a test compare the kernels' actual discrete decisions
+ * with a reference run's (tests/tie_audit.py).  Returns SRCNN_OK, or SRCNN_ERR_ARG for n_offsets < 5. */
+SRCNN_API int srcnn_proposal_workspace_layout(int B, int num_anchors, int pre_nms, size_t *offsets, int n_offsets);
 
 /* ------------------------------------------------------------------ heads (A9-A12)
  * cls softmax over n_cls logits (stereo_rcnn.py:257). */

@@ -73,9 +73,11 @@ def clip_boxes(boxes, im_info):
 
 def proposal_layer(probs, deltas, im_info, feat_shapes,
                    pre_nms_top_n=C.RPN_PRE_NMS_TOP_N, post_nms_top_n=C.RPN_POST_NMS_TOP_N,
-                   nms_thresh=C.RPN_NMS_THRESH):
+                   nms_thresh=C.RPN_NMS_THRESH, order=None):
     """proposal_layer.py:42-145 (TEST cfg).  probs (B,A,2), deltas (B,A,6) ->
-    rois_left, rois_right (B, post, 5) and a dict of intermediates for stage tests."""
+    rois_left, rois_right (B, post, 5) and a dict of intermediates for stage tests.
+    order: (B, >= pre_nms_top_n) anchor indices to use INSTEAD of the stable sort -- the order a recorded reference run's
+    (unstable) torch.sort actually produced (tests/tie_audit.py)."""
     scores = probs[:, :, 1]
     d_left = deltas[:, :, :4].clone()
     d_right = deltas[:, :, :4].clone()
@@ -86,7 +88,8 @@ def proposal_layer(probs, deltas, im_info, feat_shapes,
     anchors = anchors.view(1, -1, 4).expand(bsz, -1, 4)
     prop_l = clip_boxes(decode_boxes(anchors, d_left), im_info)
     prop_r = clip_boxes(decode_boxes(anchors, d_right), im_info)
-    order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
+    if order is None:
+        order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
     out_l = scores.new_zeros(bsz, post_nms_top_n, 5)
     out_r = scores.new_zeros(bsz, post_nms_top_n, 5)
     extra = {'order': [], 'keep_left': [], 'keep_right': [], 'keep': [], 'dets_left': [], 'dets_right': []}

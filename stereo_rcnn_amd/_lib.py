@@ -71,6 +71,7 @@ _SIGNATURES = {
     "srcnn_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_rpn_score": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "srcnn_proposal_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "srcnn_proposal_workspace_layout": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_size_t), c_int]),
     "srcnn_proposal_layer": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_void_p,
                                      c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),

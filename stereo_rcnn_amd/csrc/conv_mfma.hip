@@ -396,6 +396,9 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
         SRCNN_REQUIRE(d->precision == 1 && d->x_format == 1 && a.head_y && a.head_b && d->head_cout == 6 && cq == 256 && !d->x2 &&
                           !d->residual && d->mode != 2,
                       "fused head: SPLIT16 f16x3 engine, 6 head channels over 256-channel pixels, no residual / second input / mode 2");
+        // the head lives in the vector epilogue of the 256x256 tile (the general path is compiled out there): a channel stride or
+        // offset that is not a multiple of 8 would skip it and leave head_y unwritten
+        SRCNN_REQUIRE((d->y_cstride & 7) == 0 && (d->y_coffset & 7) == 0, "fused head: y_cstride and y_coffset must be multiples of 8");
     }
     if (a.y_fmt == 1) {
         a.range_flag = range_flag_word();

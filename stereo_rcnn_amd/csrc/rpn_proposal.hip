@@ -383,6 +383,16 @@ size_t srcnn_proposal_workspace_bytes(int B, int num_anchors, int pre_nms, int p
     return srcnn::proposal_layout(B, n, n).total;
 }
 
+int srcnn_proposal_workspace_layout(int B, int num_anchors, int pre_nms, size_t *offsets, int n_offsets)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(offsets && n_offsets >= 5 && B > 0 && num_anchors > 0, "bad args");
+    const int n = pre_nms > 0 && pre_nms < num_anchors ? pre_nms : num_anchors;
+    const ProposalLayout L = proposal_layout(B, n, n);
+    offsets[0] = L.order; offsets[1] = L.dets; offsets[2] = L.keep; offsets[3] = L.num; offsets[4] = L.total;
+    return SRCNN_OK;
+}
+
 int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num_anchors, const int *level_hw_host,
                          int nlevels, const float *im_info, int pre_nms, int post_nms, float nms_thresh,
                          float *rois_left, float *rois_right, int *num_valid, void *workspace,

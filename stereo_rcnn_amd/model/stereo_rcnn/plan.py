@@ -192,7 +192,8 @@ class Plan(object):
 
     def _par(self):
         """branches on side streams in this run?"""
-        return streams.branch_overlap() if self.overlap is None else bool(self.overlap)
+        want = streams.branch_overlap() if self.overlap is None else bool(self.overlap)
+        return want and self.side[0] is not None           # SRCNN_SIDE_STREAMS=none: nothing to fork onto, whatever was forced
 
     @property
     def side(self):
@@ -210,6 +211,8 @@ class Plan(object):
         `out_group` (None = an unscaled tensor: the image, the F32 results that leave the network)."""
         ko = self._k(out_group)
         engine.conv2d(cw, x, B, H, W, y, OH, OW, in_shift=self._k(in_group), out_shift=ko, **kw)
+        if kw.get('head') is not None:       # fused head: y itself is not written (as_f32 / calibration must not read it)
+            return
         self._buf_shift[y.data_ptr()] = ko
         if self._calib is not None and out_group is not None:
             ycs = kw.get('y_cstride')

@@ -418,11 +418,12 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
                 raise
             prev, model.precision = model.precision, 'f32'       # same fallback as the record flows below
             try:
-                return _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
+                objs = _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
                                         dense_align, pool if solver == 'scipy' else None, native=(solver == 'host_py'))
             finally:
                 model.precision = prev
-                _note_guard_trip(model, im_left_data, 0)
+            _note_guard_trip(model, im_left_data, 0)             # only after a re-run that succeeded (its own error is not masked)
+            return objs
     with torch.no_grad():
         lazy = _lazy(model)
         out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy)
@@ -436,11 +437,12 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
         # an activation left the f16 range: this pair again on the exact fp32 engine (F32 activations), never garbage
         prev, model.precision = model.precision, 'f32'
         try:
-            return detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
+            objs = detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval_thresh, class_index,
                              dense_align, pool, solver, slot)
         finally:
             model.precision = prev
-            _note_guard_trip(model, im_left_data, slot)
+        _note_guard_trip(model, im_left_data, slot)
+        return objs
 
 
 def _plan_of(model, im_left_data, slot):
@@ -514,21 +516,39 @@ def detect_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shap
             raise
         prev, model.precision = model.precision, 'f32'
         try:
-            return detect_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shapes, eval_thresh, class_index,
+            objs = detect_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shapes, eval_thresh, class_index,
                                    dense_align, slot, solver)
         finally:
             model.precision = prev
-            _note_guard_trip(model, im_left_data, slot)
+        _note_guard_trip(model, im_left_data, slot)
+        return objs
 
 
 RECALIBRATE_AFTER_TRIPS = 2      # range-guard trips (pairs re-run on the fp32 engine) after which the scales are widened
+# Widening the scales changes the low-order bits of EVERY later frame (one glitched frame would cost them for good), so it can be
+# switched off: SRCNN_AUTO_RECALIBRATE=0 (or pipeline.AUTO_RECALIBRATE = False) keeps counting trips -- guard_trips(model) -- and
+# leaves the decision to the caller (model.calibrate_activation_scales(frames) is the controlled way; reset_guard_trips(model)).
+AUTO_RECALIBRATE = _os.environ.get('SRCNN_AUTO_RECALIBRATE', '1') != '0'
+MAX_SHIFT_WIDENING = 6           # automatic re-calibration never lowers a tensor group's shift by more than this many bits in total
 
 
-def _note_guard_trip(model, im_left_data, slot):
-    """A pair left the f16 range of the SPLIT16 engine and was re-run on the exact fp32 engine.  The activation scales come from
-    the frames the calibration saw (the first forward, unless calibrate_activation_scales was called): a stream of frames unlike
-    them would silently run at fp32-engine speed for good.  After RECALIBRATE_AFTER_TRIPS trips the offending frame -- still the
-    input of this slot's plan -- is merged into the calibration (one fp32 forward; plans re-record their launch programs)."""
+def guard_trips(model):
+    """Pairs re-run on the fp32 engine since the last calibration / reset (0 if the model has no engine-side weights yet)."""
+    return int(getattr(model._weights, 'guard_trips', 0)) if model._weights is not None else 0
+
+
+def reset_guard_trips(model):
+    if model._weights is not None:
+        model._weights.guard_trips = 0
+
+
+def _note_guard_trip(model, im_left_data, slot, may_recalibrate=True):
+    """A pair left the f16 range of the SPLIT16 engine and was re-run (successfully) on the exact fp32 engine.  The activation
+    scales come from the frames the calibration saw (the first forward, unless calibrate_activation_scales was called): a stream of
+    frames unlike them would silently run at fp32-engine speed for good.  After RECALIBRATE_AFTER_TRIPS trips -- if AUTO_RECALIBRATE
+    and the caller is not streaming -- the offending frame, still the input of this slot's plan, is merged into the calibration (one
+    fp32 forward; plans re-record their launch programs), unless that would widen some group by more than MAX_SHIFT_WIDENING bits
+    beyond its first calibration: then the frame is an outlier, the scales stay, and only the counter says so."""
     import logging
     log = logging.getLogger('stereo_rcnn_amd')
     w = model._weights
@@ -536,11 +556,21 @@ def _note_guard_trip(model, im_left_data, slot):
         return
     w.guard_trips = getattr(w, 'guard_trips', 0) + 1
     log.warning('SPLIT16 range guard tripped (%d since the last calibration): pair re-run on the fp32 engine', w.guard_trips)
-    if w.guard_trips >= RECALIBRATE_AFTER_TRIPS:
+    if w.guard_trips >= RECALIBRATE_AFTER_TRIPS and AUTO_RECALIBRATE and may_recalibrate:
+        first = getattr(w, 'first_shifts', None)
+        if first is None:
+            first = w.first_shifts = dict(w.shifts)
+        before = (dict(w.shifts), list(w.fuse_shortcut), dict(w.calibration_max), w.calib_epoch)
         B, _, H, W = im_left_data.shape
         plan = model._get_plan(int(B), int(H), int(W), slot)
         with torch.no_grad():
             plan.calibrate(merge=True)
+        if any(first.get(g, k) - k > MAX_SHIFT_WIDENING for g, k in w.shifts.items()):
+            w.shifts, w.fuse_shortcut, w.calibration_max = before[0], before[1], before[2]
+            w.calib_epoch += 1
+            log.warning('SPLIT16 activation scales NOT widened: the offending frame needs more than %d bits beyond the first calibration '
+                        '(an outlier frame); it keeps running on the fp32 engine', MAX_SHIFT_WIDENING)
+            return
         w.guard_trips = 0
         log.warning('SPLIT16 activation scales widened to cover the offending frame (frames much smaller than it lose low-order bits: '
                     'calibrate_activation_scales() on representative frames is the controlled way)')
@@ -601,14 +631,18 @@ def _detect_3d_stream(model, frames, pool, eval_thresh, class_index, dense_align
             prev, model.precision = model.precision, 'f32'
             try:
                 if len(frame) == 3:
-                    return detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align,
+                    objs = detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align,
                                             retry_slot, solver=solver)
-                return detect_3d(model, frame[0], frame[1], frame[2], frame[3], frame[4], eval_thresh, class_index, dense_align,
-                                 solver=solver, slot=retry_slot)
+                else:
+                    objs = detect_3d(model, frame[0], frame[1], frame[2], frame[3], frame[4], eval_thresh, class_index, dense_align,
+                                     solver=solver, slot=retry_slot)
             finally:
                 model.precision = prev
-                if len(frame) != 3:
-                    _note_guard_trip(model, frame[0], retry_slot)
+            if len(frame) != 3:
+                # streamed: other pairs are in flight -- count the trip, never re-calibrate here (that synchronises the device and
+                # changes the scales under the pairs in flight); the caller re-calibrates between streams if it wants to
+                _note_guard_trip(model, frame[0], retry_slot, may_recalibrate=False)
+            return objs
 
     for k, frame in enumerate(frames):
         slot = k % len(streams)

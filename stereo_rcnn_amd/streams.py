@@ -50,20 +50,39 @@ def ensure_hw_queues(n=HW_QUEUES):
     """Ask the HIP runtime for at least `n` hardware queues per device (GPU_MAX_HW_QUEUES, read once when HIP starts), so that
     the pooled streams of up to n - 1 forwards in flight and the null stream do not share queues.  Entry points that keep several pairs in flight
     (bench.py, test_net.py) call this before the first HIP call; returns False -- and changes nothing -- when HIP is already
-    up with fewer queues (the caller may then use 'dedicated' main streams, or at most GPU_MAX_HW_QUEUES - 1 in flight)."""
+    up with fewer queues (the caller may then use 'dedicated' main streams, or at most GPU_MAX_HW_QUEUES - 1 in flight).
+    A smaller GPU_MAX_HW_QUEUES already in the environment is raised unless SRCNN_KEEP_HW_QUEUES=1 says it is deliberate."""
     cur = os.environ.get('GPU_MAX_HW_QUEUES')
-    if cur is not None and cur.strip().isdigit() and int(cur) >= n:
-        return True
     if torch.cuda.is_initialized():
-        return False
+        return _hw_queues() >= n
+    if cur is not None and cur.strip().isdigit():
+        if int(cur) >= n:
+            return True
+        if os.environ.get('SRCNN_KEEP_HW_QUEUES', '0') not in ('', '0'):      # a smaller value set on purpose stays
+            return False
     os.environ['GPU_MAX_HW_QUEUES'] = str(n)
     return True
 
 
+_queues_at_hip_start = None       # GPU_MAX_HW_QUEUES as HIP read it (recorded the first time we see HIP initialised)
+
+
+def _hw_queues():
+    """The queue count HIP runs with: the variable is read once when HIP starts, so once HIP is up the value seen THEN counts,
+    not whatever the environment says later."""
+    global _queues_at_hip_start
+    cur = os.environ.get('GPU_MAX_HW_QUEUES', '4')
+    n = int(cur) if cur.strip().isdigit() else 4
+    if _queues_at_hip_start is not None:
+        return _queues_at_hip_start
+    if torch.cuda.is_initialized():
+        _queues_at_hip_start = n
+    return n
+
+
 def max_pairs_in_flight():
     """Forwards that can each have a pooled stream on a hardware queue of its own (one queue is the null stream's)."""
-    cur = os.environ.get('GPU_MAX_HW_QUEUES', '4')
-    return max(1, (int(cur) if cur.strip().isdigit() else 4) - 1)
+    return max(1, _hw_queues() - 1)
 
 
 _handles = []      # native handles of the streams created here: they live as long as the process (the slots' streams are created
@@ -72,15 +91,23 @@ _handles = []      # native handles of the streams created here: they live as lo
 
 
 def destroy_all():
-    """Destroys every stream this module created (callers must have dropped their torch wrappers): for long-lived processes that
-    rebuild their stream set."""
+    """Destroys every native stream this module created, after dropping the wrappers the package itself caches (the pipeline's
+    slot streams): for long-lived processes that rebuild their stream set.  Callers must have dropped THEIR wrappers
+    (tune.StepRunner objects, streams handed out by main_streams) -- a wrapper used after this call is a dangling handle."""
+    import sys
+    pl = sys.modules.get(__package__ + '.pipeline')
+    if pl is not None:
+        pl._stream_cache.clear()
+    torch.cuda.synchronize()
     while _handles:
         _lib.lib().srcnn_stream_destroy(_handles.pop())
 
 
 def new_stream(kind='pool', device=None):
-    """A new non-blocking stream on `device` (default: current).  kind: 'pool' (torch's pooled streams on the shared hardware
-    queues), 'high' (pooled, high priority: HIP keeps a separate queue set per priority), 'dedicated' (own hardware queue)."""
+    """A new stream on `device` (default: current).  kind: 'pool' (torch's pooled NON-BLOCKING streams on the shared hardware
+    queues), 'high' (pooled, high priority: HIP keeps a separate queue set per priority), 'dedicated' (own hardware queue -- created
+    through hipExtStreamCreateWithCUMask, which gives the stream HIP's default, NULL-stream-BLOCKING semantics: work on the null
+    stream serialises with it, see the module docstring)."""
     assert kind in KINDS, kind
     if kind == 'pool':
         return torch.cuda.Stream(device=device)

@@ -54,6 +54,57 @@ def net_golden(net, seed, h, w, short, tag):
     print('reference_net_%s.npz' % tag, {k: v.shape for k, v in d.items()})
 
 
+def net_golden_cv_input_with_rpn(net, seed, h, w, tag, top=7000):
+    """A frame whose network input comes from the OpenCV-resize restatement (oracle/preprocess.py) -- the input the product's own
+    preprocessing kernel produces bit for bit -- so that the ragged tails are the ones a real KITTI frame of this size has
+    (370x1224 -> 600x1985; fixture.make_inputs' truncating resize gives 1984).  Besides the network outputs the golden keeps what
+    the reference's proposal layer was FED (captured by wrapping _ProposalLayer.forward): every anchor's foreground score and the
+    deltas of the `top` best anchors (only the 6000 best can reach the NMS) -- the data of the tie audit in
+    tests/test_model_gpu.py: every discrete decision (top-6000 membership, order, IoU > 0.7) that differs between the HIP run and
+    the reference run must be a near-tie of the reference's own margins."""
+    import hashlib
+    from oracle import preprocess as opre
+    lu, ru = fixture.synthetic_pair(seed, h, w)
+    tl, s = opre.prepare_image(lu)
+    tr, _ = opre.prepare_image(ru)
+    l, r = torch.from_numpy(tl), torch.from_numpy(tr)
+    info = torch.tensor([[l.shape[2], l.shape[3], s]], dtype=torch.float32)
+    cap = {}
+    layer = net.RCNN_rpn.RPN_proposal
+    orig = layer.forward
+
+    real_sort = torch.sort
+
+    def recording_sort(*a, **k):                  # proposal_layer.py:96 -- torch.sort(scores, 1, True): NOT stable; its tie order is
+        out = real_sort(*a, **k)                  # whatever this torch build does, so the golden keeps the order it actually used
+        cap.setdefault('sorts', []).append(out[1].clone())
+        return out
+
+    def recording(inp):
+        cap['probs'], cap['deltas'], cap['shapes'] = inp[0].clone(), inp[1].clone(), [list(map(int, x)) for x in inp[4]]
+        torch.sort = recording_sort
+        try:
+            return orig(inp)
+        finally:
+            torch.sort = real_sort
+    layer.forward = recording
+    try:
+        d = net_outputs(net, l, r, info)
+    finally:
+        layer.forward = orig
+    fg = cap['probs'][0, :, 1].numpy().astype(np.float32)
+    idx = np.argsort(-fg, kind='stable')[:top].astype(np.int32)
+    orders = [o for o in cap.get('sorts', []) if o.numel() == fg.shape[0]]
+    assert len(orders) == 1, [tuple(o.shape) for o in cap.get('sorts', [])]
+    d['rpn_order'] = orders[0].view(-1)[:6000].numpy().astype(np.int32)          # the 6000 anchors the reference's NMS saw, in its order
+    d.update({'input_shape': np.asarray(l.shape), 'spec': np.asarray([seed, h, w, 600]), 'im_info': info.numpy(),
+              'input_sha256': np.frombuffer(hashlib.sha256(np.ascontiguousarray(tl).tobytes()).digest(), np.uint8),
+              'rpn_fg': fg, 'rpn_top_idx': idx, 'rpn_top_deltas': cap['deltas'][0].numpy()[idx].astype(np.float32),
+              'rpn_shapes': np.asarray(cap['shapes'], np.int32)})
+    np.savez_compressed(os.path.join(HERE, 'reference_net_%s.npz' % tag), **d)
+    print('reference_net_%s.npz' % tag, {k: v.shape for k, v in d.items()})
+
+
 def net_outputs(net, l, r, info):
     z, nb = torch.zeros(1, 1, 5), torch.zeros(1)
     with torch.no_grad():
@@ -475,6 +526,8 @@ if __name__ == '__main__':
         net_golden_r50_2x_b4(reference_model_r50(5))
     if 'kitti370' in which:       # KITTI's other common frame size: 370x1224 -> 600x1985 (other ragged tails in every layer)
         net_golden(reference_model(3), 4, 370, 1224, 600, 'full_370x1224_r101_seed4')
+    if 'kitti370cv' in which:     # ... the same frame size through the OpenCV-resize restatement (600x1985), with the RPN data of the tie audit
+        net_golden_cv_input_with_rpn(reference_model(3), 4, 370, 1224, 'cv_370x1224_r101_seed4')
     if 'demo' in which:
         demo_pair_golden(reference_model(3, sd=fixture.demo_state_dict(3)))
     if 'misc' in which:

@@ -281,14 +281,24 @@ def test_ensure_hw_queues_sets_the_runtime_variable_before_hip_starts(monkeypatc
     import torch
     from stereo_rcnn_amd import streams
     monkeypatch.setattr(torch.cuda, 'is_initialized', lambda: False)
+    monkeypatch.setattr(streams, '_queues_at_hip_start', None)
     monkeypatch.delenv('GPU_MAX_HW_QUEUES', raising=False)
+    monkeypatch.delenv('SRCNN_KEEP_HW_QUEUES', raising=False)
     assert streams.max_pairs_in_flight() == 3                    # HIP's default: 4 queues, one is the null stream's
     assert streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 7
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '16')
     assert streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 15      # a larger user setting is kept
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '2')
+    monkeypatch.setenv('SRCNN_KEEP_HW_QUEUES', '1')
+    assert not streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 1   # a smaller one too, when marked deliberate
+    monkeypatch.delenv('SRCNN_KEEP_HW_QUEUES')
+    assert streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 7       # ... otherwise it is raised
     monkeypatch.setattr(torch.cuda, 'is_initialized', lambda: True)
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    monkeypatch.setattr(streams, '_queues_at_hip_start', None)
     assert not streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 3    # too late: HIP is up
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '8')                                     # changing the variable after HIP started changes
+    assert not streams.ensure_hw_queues(8) and streams.max_pairs_in_flight() == 3    # nothing: the value HIP READ is what counts
 
 
 def test_queue_supply_warning(monkeypatch, caplog):
@@ -296,6 +306,7 @@ def test_queue_supply_warning(monkeypatch, caplog):
     from stereo_rcnn_amd import streams
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
     monkeypatch.setattr(streams, '_warned', set())
+    monkeypatch.setattr(streams, '_queues_at_hip_start', None)
     with caplog.at_level(logging.WARNING, logger='stereo_rcnn_amd'):
         assert streams.check_queue_supply(3, 'pool') and not caplog.records
         assert not streams.check_queue_supply(4, 'pool') and len(caplog.records) == 1       # 4 in flight + null stream > 4 queues
@@ -344,3 +355,29 @@ def test_throughput_tuner_descends_on_the_measured_step(monkeypatch):
     assert [(c[0], c[1], c[2]) for c in changes] == [(keys[0], (2, 2, 8, 2, 3), (2, 2, 8, 2, 1))]
     assert engine._TUNED[keys[0]] == (2, 2, 8, 2, 1) and engine._TUNED[keys[1]] == (2, 1, 4, 2, 1) and engine._TUNED[keys[2]] == (1, 1, 4, 2, 1)
     assert any('round 2: 0 plans changed' in ln for ln in log)
+
+
+def test_serving_regime_gates_the_shipped_plans(monkeypatch):
+    """serving.enter: one forward at a time never adopts the throughput-tuned plan file; several in flight adopt it once, only on
+    the GPU model it was tuned on, and never when switched off (the product runs what bench.py runs: VERDICT r4 item 4)."""
+    from stereo_rcnn_amd import engine, serving, streams
+    monkeypatch.setattr(serving, '_loaded', {})
+    monkeypatch.setattr(engine, '_TUNED', {})
+    prev = streams.pairs_in_flight()
+    try:
+        assert serving.enter(1)['shipped_plans'] == 0 and not engine._TUNED and streams.pairs_in_flight() == 1
+        monkeypatch.setattr(serving, 'device_matches', lambda name='mi355x.json', device=None: False)
+        assert serving.enter(4)['shipped_plans'] == 0 and not engine._TUNED            # another GPU model: in-situ tuner only
+        serving.drop_shipped_plans()
+        monkeypatch.setattr(serving, 'device_matches', lambda name='mi355x.json', device=None: True)
+        info = serving.enter(4)
+        assert info['shipped_plans'] == info['shipped_plans_adopted_now'] == len(engine._TUNED) > 50 and not info['branch_side_streams']
+        assert all(k[1] in (1, 2, 300) for k in engine._TUNED)      # shapes of batch-1 pairs only: 2 images, 1 RPN map, 300 rois
+        epoch = engine.PLAN_EPOCH
+        assert serving.enter(3)['shipped_plans_adopted_now'] == 0 and engine.PLAN_EPOCH == epoch      # once per process
+        serving.drop_shipped_plans()
+        monkeypatch.setattr(serving, 'USE_SHIPPED_PLANS', False)
+        monkeypatch.setattr(engine, '_TUNED', {})
+        assert serving.enter(4)['shipped_plans'] == 0 and not engine._TUNED
+    finally:
+        streams.set_pairs_in_flight(prev)

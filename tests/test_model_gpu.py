@@ -663,6 +663,68 @@ def test_hip_forward_at_kitti_370x1224_vs_reference_code_golden(dev, precision):
     assert all(v < 1e-4 for v in iso.values()), iso
 
 
+@pytest.mark.parametrize("precision", ['f16x3', 'f32'])
+def test_hip_forward_at_kitti_370x1224_through_the_product_preprocessing_with_tie_audit(dev, precision):
+    """VERDICT r4 items 7(b), 7(c).  The 370x1224 KITTI frame as the PRODUCT sees it: uint8 images through the fused preprocessing
+    kernel -> network input 600x1985 (OpenCV's cvRound; bit-equal to the golden's input), against the reference code's outputs on
+    that input.  Instead of excusing unmatched proposals by a fraction, the discrete stage is AUDITED (tests/tie_audit.py):
+      1. what feeds it -- every anchor's score, the deltas of the candidates -- is within float rounding of the reference's;
+      2. the kernels' ACTUAL decisions (candidate order, decoded boxes, NMS keep lists, read out of the proposal workspace) are
+         the restated algorithm's on those inputs: oracle NMS on the kernels' own boxes gives the kernels' keep lists, index for
+         index -- bit-exact NMS indices at this shape, inside the assembled forward;
+      3. every decision that differs from the reference run (top-6000 membership, order, IoU > 0.7) is a near-tie of the
+         reference's own margin; none unexplained.
+    The regressions of the matched proposals and the heads fed the reference's rois carry the arithmetic at 1e-4 as before."""
+    import hashlib
+    import tie_audit
+    from oracle import ops as oops
+    from stereo_rcnn_amd import fixture
+    g = np.load(os.path.join(GOLD, 'reference_net_cv_370x1224_r101_seed4.npz'))
+    seed, h, w, short = [int(v) for v in g['spec']]
+    m, _ = _build_model(dev)
+    m.precision = precision
+    lu, ru = fixture.synthetic_pair(seed, h, w)
+    with torch.no_grad():
+        out, iml, imr, info = m.forward_images(torch.from_numpy(lu).to(dev), torch.from_numpy(ru).to(dev))
+        torch.cuda.synchronize()
+        assert list(iml.shape) == list(g['input_shape']) == [1, 3, 600, 1985]
+        assert hashlib.sha256(np.ascontiguousarray(iml.cpu().numpy()).tobytes()).digest() == g['input_sha256'].tobytes()
+        plan = m._get_plan(1, 600, 1985)
+        hip = tie_audit.hip_run_from_workspace(plan)
+        # 1. the discrete stage's inputs
+        eps_s = float(np.abs(hip['fg'] - g['rpn_fg']).max())
+        top = torch.from_numpy(g['rpn_top_idx'].astype(np.int64))
+        eps_d = _relerr(plan.deltas[0].cpu()[top], torch.from_numpy(g['rpn_top_deltas']))
+        assert eps_s < 1e-4 and eps_d < 2e-4, (eps_s, eps_d)
+        # 2. the kernels' own decisions are the algorithm's on their own inputs
+        stable = np.argsort(-hip['fg'], kind='stable')[:hip['order'].shape[0]]
+        assert np.array_equal(hip['order'], stable)                                   # exact stable top-6000, index for index
+        assert np.array_equal(hip['dets_left'][:, 4], hip['fg'][hip['order']])
+        for eye in ('left', 'right'):
+            full = np.asarray(oops.nms(hip['dets_' + eye], 0.7))
+            mine = hip['keep_' + eye]
+            assert mine.shape[0] >= 300 and np.array_equal(mine, full[:mine.shape[0]]), eye       # a prefix of the greedy list: the scans stop together
+        keep = hip['keep']
+        assert float(np.abs(hip['rois_left'][0, :keep.shape[0], 1:].numpy() - hip['dets_left'][keep, :4]).max()) == 0.0
+        assert float(np.abs(hip['rois_right'][0, :keep.shape[0], 1:].numpy() - hip['dets_right'][keep, :4]).max()) == 0.0
+        # 3. every decision that differs from the reference run is a tie
+        ref = tie_audit.reference_run_from_golden(g)
+        rep = tie_audit.audit(ref, hip)
+        ref_out = {k: torch.from_numpy(g[k]) for k in HEAD_OUTS}
+        frac, errs = _check_end_to_end(out, torch.from_numpy(g['rois_left'])[0], torch.from_numpy(g['rois_right'])[0], ref_out, 0.0)
+        iso = _heads_on_reference_rois(m, iml, g, precision, dev)
+    print('370x1224 -> 600x1985 %s: scores within %.1e, deltas %.1e; decisions that differ from the reference run: membership %d, order '
+          '%d, IoU %d (scores within tolerance of the cut: %d; boxes within %.1e px), unexplained %d; matched proposals %.3f, errs on '
+          'those %s; heads fed the reference rois %s'
+          % (precision, eps_s, eps_d, rep['membership_flips'], rep['order_inversions'], rep['iou_flips'], rep['scores_within_tol_of_the_cut'],
+             rep['eps_box_px'], len(rep['unexplained']), frac, errs, iso))
+    assert not rep['unexplained'], rep['unexplained'][:5]
+    assert frac == 1.0 or rep['decisions_that_differ'] > 0
+    assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, errs
+    assert all(v < 2e-3 for v in errs.values()), errs
+    assert all(v < 1e-4 for v in iso.values()), iso
+
+
 def test_hip_forward_full_size_batch_of_eight_vs_reference_code_golden(dev):
     """BASELINE configs[2] at the shape `bench.py --config 2` runs: EIGHT different 375x1242 pairs (bench.make_batch's seeds
     3..10) in one forward at network input 600x1987 -- M = 16 x 150 x 497 rows through layer1, 2400 rois through the heads --
