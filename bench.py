@@ -87,6 +87,10 @@ def parse():
                     help='do not measure roofline.traffic in this run (default at N = 1, --config 1: two short child runs of '
                          'this script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE`, about a minute); '
                          'the committed profiles/pmc_*_traffic.json is then quoted if it matches the kernel sources')
+    ap.add_argument('--no-mix-layers', action='store_true',
+                    help='skip the per-layer table of the headline regime itself (roofline.headline.layers: marginal in-mix cost of '
+                         'every conv group + workgroup residency from the kernel\'s stamps, stereo_rcnn_amd/mix_table.py; ~30 s)')
+    ap.add_argument('--mix-out', default='', help='write the in-mix per-layer tables (text) to this file')
     ap.add_argument('--pmc-child', type=int, default=0, help=argparse.SUPPRESS)     # internal: N forwards, one stream, exit
     ap.add_argument('--no-shipped-plans', action='store_true',
                     help='ignore stereo_rcnn_amd/plans/mi355x.json (conv plans tuned with the multi-stream step as objective, '
@@ -668,7 +672,7 @@ def main():
                     rec_bufs[gr[0]][gr[1] + b].copy_(hs[b].rec, non_blocking=True)
             gathered(gr)
             return
-        out = model(im_l, im_r, im_info, slot=slot)
+        out = model(im_l, im_r, im_info, slot=slot, alias_outputs=True)     # views of the slot's result buffers: consumed right below, in stream order
         for b in range(B):
             o = pipeline.image_outputs(out, b) if B > 1 else out
             det = hpost.decode_detections(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], im_info[b:b + 1])
@@ -801,7 +805,7 @@ def main():
             def lazy_step(slot):
                 if wl['flow'] == '3d':
                     return step(slot, gather=False)
-                out = model(im_l, im_r, im_info, slot=slot, kpts=False)
+                out = model(im_l, im_r, im_info, slot=slot, kpts=False, alias_outputs=True)
                 plan = model._get_plan(B, int(im_l.shape[2]), int(im_l.shape[3]), slot)
                 for b in range(B):
                     o = pipeline.image_outputs(out, b) if B > 1 else out
@@ -981,6 +985,37 @@ def main():
                 model.precision = args.precision
             model.use_graph = use_graph
             model.use_program = use_program
+            # ---- per-layer evidence of the regime `value` is measured in (rocprofv3 serialises the queues; HIP events around a
+            #      launch would time the sharing): marginal in-mix cost per conv group and workgroup residency from the stamps
+            if (not args.no_mix_layers and S > 1 and world == 1 and args.config == 1 and args.precision == 'f16x3' and model.use_program
+                    and roofline is not None):
+                from stereo_rcnn_amd import mix_table
+
+                class _MixRunner(object):
+                    def measure(self, steps, repeats=3):
+                        run_steps(S)                    # re-records the launch programs after a plan-epoch bump
+                        torch.cuda.synchronize()
+                        ts = []
+                        for _ in range(repeats):
+                            tm = time.perf_counter()
+                            run_steps(steps)
+                            torch.cuda.synchronize()
+                            ts.append((time.perf_counter() - tm) * 1e3 / steps)
+                        return sorted(ts)[len(ts) // 2]
+                try:
+                    mr_ = _MixRunner()
+                    mbase, marg = mix_table.marginal(mr_, rows, steps=24)
+                    sms, resid = mix_table.residency(mr_, S, steps=24)
+                    roofline['headline']['layers'] = mix_table.for_json(mbase, marg, resid)
+                    roofline['headline']['layers']['step_ms_with_stamps'] = round(sms, 3)
+                    if args.mix_out:
+                        with open(args.mix_out, 'w') as f:
+                            f.write(mix_table.format_marginal(mbase, marg, S) + '\n\n' + mix_table.format_residency(sms, resid, S, base_ms=mbase) + '\n')
+                except Exception as e:                  # a measurement aid must never cost the benchmark line
+                    roofline['headline']['layers'] = {'error': repr(e)[:300]}
+                finally:
+                    engine.REPEAT = []
+                    engine.PLAN_EPOCH += 1
 
     # ---- the whole 3-D flow of the same pair (the metric's "3D box" half; BASELINE configs[2] minus the batch): short,
     #      outside the timed region, reported beside the headline -- never as `value`.  EVERY rank runs it (barrier + max over

@@ -221,6 +221,10 @@ SRCNN_API int srcnn_nchw_to_nhwc(const float *x, int B, int C, int H, int W, flo
  * flattened order, reproducing the (c, c+3) softmax pairing quirk (stereo_rpn.py:81-83,89-91). */
 SRCNN_API int srcnn_rpn_score(const float *head, int B, int hw, int head_cstride, float *probs, float *deltas,
                     int level_offset, int num_anchors_total, srcnn_stream_t stream);
+/* The same for ALL pyramid levels in one launch: heads[l] (B, level_hw[l], head_cstride) of level l (host arrays of nlevels <= 5
+ * entries); level l's anchors start at 3 x the locations of the levels before it; num_anchors_total = 3 x all locations. */
+SRCNN_API int srcnn_rpn_score_levels(const float *const *heads, const int *level_hw, int nlevels, int B, int head_cstride,
+                                     float *probs, float *deltas, int num_anchors_total, srcnn_stream_t stream);
 /* Whole _ProposalLayer.forward (proposal_layer.py:42-145): anchors (generate_anchors.py:112-173),
  * decode+clip (bbox_transform.py:79-104,177-185), stable descending sort / top pre_nms,
  * NMS(left) & NMS(right), sorted intersection, first post_nms, zero pad, batch index in col 0.
@@ -247,6 +251,11 @@ SRCNN_API int srcnn_proposal_workspace_layout(int B, int num_anchors, int pre_nm
 /* ------------------------------------------------------------------ heads (A9-A12)
  * cls softmax over n_cls logits (stereo_rcnn.py:257). */
 SRCNN_API int srcnn_softmax_rows(const float *x, int rows, int cols, int x_stride, float *y, srcnn_stream_t stream);
+/* The box head's stacked fc output (rows, fc_stride >= n_bbox + n_dim + n_cls): columns [RCNN_bbox_pred | RCNN_dim_orien_pred |
+ * RCNN_cls_score] (stereo_rcnn.py:251-257) split in ONE launch into the three tensors the forward returns -- the regressions
+ * copied bit for bit into contiguous rows, the class logits through the softmax above. */
+SRCNN_API int srcnn_box_head_tail(const float *fc, int rows, int n_bbox, int n_dim, int n_cls, int fc_stride, float *bbox_pred,
+                                  float *dim_orien_pred, float *cls_prob, srcnn_stream_t stream);
 /* keypoint tail (stereo_rcnn.py:262-271): logits (n, G, G, 6) NHWC from kpts_class ->
  * sum over H, softmax over 4*G (kpts) and G (left/right borders).  roi_limit: NULL, or a device int -- rows [0, *roi_limit) only. */
 SRCNN_API int srcnn_kpts_tail(const float *logits, int n, int G, float *kpts_prob, float *left_prob, float *right_prob,

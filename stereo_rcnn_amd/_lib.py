@@ -70,12 +70,14 @@ _SIGNATURES = {
     "srcnn_nhwc_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_rpn_score": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "srcnn_rpn_score_levels": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "srcnn_proposal_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "srcnn_proposal_workspace_layout": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_size_t), c_int]),
     "srcnn_proposal_layer": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_void_p,
                                      c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
     "srcnn_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "srcnn_box_head_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srcnn_kpts_tail": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srcnn_decode_detections": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
     "srcnn_class_nms_workspace_bytes": (c_size_t, [c_int]),

@@ -113,6 +113,8 @@ int nms_pairs_until(int *keep_out, const float *dets, int *num_out, const int *n
 // t_end (s_memtime, per-CU shader clocks), hw_id, 1 | xcc_id << 8, realtime_entry, realtime_end (100 MHz, chip-wide)}
 // at stamp[16 * workgroup]; see tools/stamp_conv.py
 unsigned long long *debug_stamp_buffer();
+// ... or, while a stamp ARENA is set (core.hip), a region of this launch's own; nullptr = do not stamp
+unsigned long long *debug_stamp_region(int wgs, int tag, int lds_bytes, int threads, int M, int N, int K);
 
 // profiling hooks (conv engine)
 bool prof_enabled();

@@ -477,6 +477,9 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
     hipStream_t st = as_stream(stream);
     const bool prof = prof_enabled();
     if (prof) prof_begin(st);
+    if (d->precision == 1 && a.x_fmt == 1 && a.stamp == nullptr)       // debug: a stamp arena hands every launch its own region
+        a.stamp = debug_stamp_region(a.mtiles * a.ntiles * pl.splits, a.tag, pl.stages * 128 * 64 * (pl.mr + pl.nr), pl.waves * 64,
+                                     a.M, a.Cout, a.K);
     if (d->precision == 1 && a.x_fmt == 1) launch_conv_f16s(a, pl, st);
     else if (d->precision == 1) launch_conv_f16x3(a, pl, st);
     else if (pl.mr == 2 && pl.nr == 2) launch<2, 2>(a, pl.splits, st);

@@ -134,12 +134,58 @@ unsigned *range_flag_word()
 static unsigned long long *g_stamp = nullptr;
 unsigned long long *debug_stamp_buffer() { return g_stamp; }
 
+// Stamp ARENA (debug): every conv_f16s launch issued -- or recorded into a launch program -- while it is set gets a region of
+// its own (16 x u64 per workgroup), so that the launches of SEVERAL forwards in flight can be told apart after the run: the
+// per-layer residency table of the regime the headline is measured in (tools/mix_layers.py).  A replayed program writes the
+// regions its launches got at record time, every replay anew: after a run the arena holds the LAST execution of every launch.
+struct StampLogRow { long long off_words; int wgs, tag, lds_bytes, threads, M, N, K; };
+static unsigned long long *g_arena = nullptr;
+static size_t g_arena_words = 0, g_arena_cursor = 0;
+static std::vector<StampLogRow> g_arena_log;
+static std::mutex g_arena_mu;
+
+unsigned long long *debug_stamp_region(int wgs, int tag, int lds_bytes, int threads, int M, int N, int K)
+{
+    if (!g_arena) return g_stamp;                               // legacy single-launch hook (tools/stamp_conv.py) or nullptr
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    const size_t need = (size_t)wgs * 16;
+    if (g_arena_cursor + need > g_arena_words) return nullptr;  // arena full: this launch runs unstamped
+    unsigned long long *r = g_arena + g_arena_cursor;
+    g_arena_log.push_back({(long long)g_arena_cursor, wgs, tag, lds_bytes, threads, M, N, K});
+    g_arena_cursor += need;
+    return r;
+}
+
 }  // namespace srcnn
 
 extern "C" {
 
 // debug hook (not part of include/srcnn_hip.h): device buffer of 16 x u64 per workgroup, or NULL to switch off
 SRCNN_API void srcnn_debug_set_stamp_buffer(void *buf) { srcnn::g_stamp = static_cast<unsigned long long *>(buf); }
+
+// debug hooks of the stamp arena (see above): buf = device buffer of `words` u64 (zero it first), or NULL to switch off.
+// srcnn_debug_stamp_log copies up to max_rows rows of 8 x int64 {offset in words, workgroups, layer tag, LDS bytes, threads, M, N, K}
+// and returns the number of launches logged since the arena was set.
+SRCNN_API void srcnn_debug_set_stamp_arena(void *buf, size_t words)
+{
+    std::lock_guard<std::mutex> lk(srcnn::g_arena_mu);
+    srcnn::g_arena = static_cast<unsigned long long *>(buf);
+    srcnn::g_arena_words = buf ? words : 0;
+    srcnn::g_arena_cursor = 0;
+    srcnn::g_arena_log.clear();
+}
+
+SRCNN_API int srcnn_debug_stamp_log(long long *rows, int max_rows)
+{
+    std::lock_guard<std::mutex> lk(srcnn::g_arena_mu);
+    const int n = (int)srcnn::g_arena_log.size();
+    for (int i = 0; i < n && i < max_rows; ++i) {
+        const auto &r = srcnn::g_arena_log[i];
+        long long *o = rows + (size_t)i * 8;
+        o[0] = r.off_words; o[1] = r.wgs; o[2] = r.tag; o[3] = r.lds_bytes; o[4] = r.threads; o[5] = r.M; o[6] = r.N; o[7] = r.K;
+    }
+    return n;
+}
 
 int srcnn_version(void) { return 210; }   // 210: srcnn_stream_create*, srcnn_probe_placement, srcnn_conv_desc.head_* (appended fields)
 

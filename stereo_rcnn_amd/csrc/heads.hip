@@ -21,6 +21,25 @@ __global__ void softmax_rows_kernel(const float *__restrict__ x, int rows, int c
     for (int c = 0; c < cols; ++c) y[(size_t)r * cols + c] = expf(p[c] - m) / s;
 }
 
+// Tail of the box head in one launch: the stacked fc output rows [bbox n_bbox | dim_orien n_dim | cls logits n_cls] are split into
+// the three tensors the forward returns -- bbox_pred and dim_orien_pred copied bit for bit into contiguous rows, the class
+// logits through the softmax of softmax_rows_kernel (same expression order).
+__global__ void box_head_tail_kernel(const float *__restrict__ fc, int rows, int n_bbox, int n_dim, int n_cls, int xs,
+                                     float *__restrict__ bbox, float *__restrict__ dim, float *__restrict__ cls)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *p = fc + (size_t)r * xs;
+    for (int c = 0; c < n_bbox; ++c) bbox[(size_t)r * n_bbox + c] = p[c];
+    for (int c = 0; c < n_dim; ++c) dim[(size_t)r * n_dim + c] = p[n_bbox + c];
+    p += n_bbox + n_dim;
+    float m = p[0];
+    for (int c = 1; c < n_cls; ++c) m = fmaxf(m, p[c]);
+    float s = 0.f;
+    for (int c = 0; c < n_cls; ++c) s += expf(p[c] - m);
+    for (int c = 0; c < n_cls; ++c) cls[(size_t)r * n_cls + c] = expf(p[c] - m) / s;
+}
+
 // one block per roi; logits (n, G, G, 6) NHWC.  G <= 32.
 __global__ __launch_bounds__(256) void kpts_tail_kernel(const float *__restrict__ logits, int G,
                                                         float *__restrict__ kpts_prob, float *__restrict__ left_prob,
@@ -298,6 +317,18 @@ int srcnn_softmax_rows(const float *x, int rows, int cols, int x_stride, float *
     SRCNN_LAUNCH(softmax_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, as_stream(stream), x, rows, cols,
                        x_stride, y);
     return check_launch("srcnn_softmax_rows");
+}
+
+int srcnn_box_head_tail(const float *fc, int rows, int n_bbox, int n_dim, int n_cls, int fc_stride, float *bbox_pred,
+                        float *dim_orien_pred, float *cls_prob, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(fc && bbox_pred && dim_orien_pred && cls_prob && rows >= 0 && n_bbox > 0 && n_dim > 0 && n_cls > 0 &&
+                      fc_stride >= n_bbox + n_dim + n_cls, "bad args");
+    if (rows == 0) return SRCNN_OK;
+    SRCNN_LAUNCH(box_head_tail_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, as_stream(stream), fc, rows, n_bbox, n_dim, n_cls,
+                       fc_stride, bbox_pred, dim_orien_pred, cls_prob);
+    return check_launch("srcnn_box_head_tail");
 }
 
 int srcnn_kpts_tail(const float *logits, int n, int G, float *kpts_prob, float *left_prob, float *right_prob,

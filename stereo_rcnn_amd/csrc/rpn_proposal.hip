@@ -48,6 +48,45 @@ __global__ void rpn_score_kernel(const float *__restrict__ head, int B, int hw, 
     }
 }
 
+// All pyramid levels in ONE launch (the five per-level launches sat at the ~5 us launch floor): the level of a location is found
+// from the cumulative location counts; per location the arithmetic is rpn_score_kernel's, expression for expression.
+struct RpnLevels {
+    const float *head[5];
+    int cum[6];        // cumulative locations per image: level l owns [cum[l], cum[l + 1])
+    int n;
+};
+
+__global__ void rpn_score_levels_kernel(RpnLevels lv, int B, int hcs, float *__restrict__ probs, float *__restrict__ deltas,
+                                        int a_total)
+{
+    const int per = lv.cum[lv.n];
+    const int total = B * per;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += blockDim.x * gridDim.x) {
+        const int b = idx / per, g = idx - b * per;
+        int l = 0;
+        while (l + 1 < lv.n && g >= lv.cum[l + 1]) ++l;
+        const int hw = lv.cum[l + 1] - lv.cum[l], loc = g - lv.cum[l];
+        const float *h = lv.head[l] + ((size_t)b * hw + loc) * hcs;
+        float pr[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s0 = h[c], s1 = h[c + 3];
+            const float m = fmaxf(s0, s1);
+            const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+            const float sum = e0 + e1;
+            pr[c] = e0 / sum;
+            pr[c + 3] = e1 / sum;
+        }
+        const size_t base = (size_t)b * a_total + ((size_t)lv.cum[l] + loc) * 3;     // anchors of a level start at 3 x its first location
+        float *po = probs + base * 2;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) po[c] = pr[c];
+        float *dl = deltas + base * 6;
+#pragma unroll
+        for (int c = 0; c < 18; ++c) dl[c] = h[6 + c];
+    }
+}
+
 // ------------------------------------------------------------------ top-K + sort
 __device__ __forceinline__ unsigned score_key(float f)
 {
@@ -69,16 +108,18 @@ struct TkState {
     unsigned prefix, remaining, ties, T, iprefix, idx_limit, need_tb, count;
 };
 
-__global__ void tk_set_remaining_kernel(TkState *state, int B, unsigned k)
-{
-    for (int b = threadIdx.x; b < B; b += blockDim.x) state[b].remaining = k;
-}
+__device__ void tk_pick_wave(TkState *state, unsigned *__restrict__ hist, int b, int lane, int kind, int shift, int last,
+                             int first, unsigned K);
 
-__global__ __launch_bounds__(256) void tk_hist_kernel(const float *__restrict__ probs, int A, const TkState *state,
-                                                      unsigned *__restrict__ hist, int kind, int shift, int width,
-                                                      unsigned mask_above)
+// One radix pass = ONE launch: grid-wide LDS histograms of a digit, and the workgroup that finishes last (arrival counter behind a
+// device-scope fence) walks the 2048 bins with its first wave -- what used to be the separate one-wave tk_pick launch.  `first`:
+// the state's `remaining` is still the memset's zero and stands for K (the tk_set_remaining launch is gone as well).
+__global__ __launch_bounds__(256) void tk_hist_kernel(const float *__restrict__ probs, int A, TkState *state,
+                                                      unsigned *__restrict__ hist, unsigned *__restrict__ arrivals, int kind,
+                                                      int shift, int width, unsigned mask_above, int last, int first, unsigned K)
 {
     __shared__ unsigned lh[TK_BINS];
+    __shared__ int s_last;
     const int b = blockIdx.y;
     const TkState st = state[b];
     if (kind == 1 && !st.need_tb) return;
@@ -98,16 +139,24 @@ __global__ __launch_bounds__(256) void tk_hist_kernel(const float *__restrict__ 
     unsigned *gh = hist + (size_t)b * TK_BINS;
     for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x)
         if (lh[i]) atomicAdd(&gh[i], lh[i]);
+    // the last workgroup to arrive picks the digit (every image of the batch has its own arrival counter)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&arrivals[b], 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                   // the other workgroups' histogram atomics are visible from here on
+    if (threadIdx.x < 64) tk_pick_wave(state, hist, b, threadIdx.x, kind, shift, last, first, K);
+    if (threadIdx.x == 0) arrivals[b] = 0;             // ready for the next pass (next launch on this stream)
 }
 
 // one wave per image: lane l owns bins [32l, 32l+32)
-__global__ __launch_bounds__(64) void tk_pick_kernel(TkState *state, unsigned *__restrict__ hist, int kind, int shift,
-                                                     int last, int K, int A)
+__device__ void tk_pick_wave(TkState *state, unsigned *__restrict__ hist, int b, int lane, int kind, int shift, int last,
+                             int first, unsigned K)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
     TkState st = state[b];
     unsigned *gh = hist + (size_t)b * TK_BINS;
-    if (kind == 1 && !st.need_tb) return;
+    if (first) st.remaining = K;
     unsigned mine[32], sum = 0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) { mine[i] = gh[lane * 32 + i]; sum += mine[i]; gh[lane * 32 + i] = 0; }
@@ -163,7 +212,6 @@ __global__ __launch_bounds__(64) void tk_pick_kernel(TkState *state, unsigned *_
         }
         state[b] = st;
     }
-    (void)K; (void)A;
 }
 
 __global__ __launch_bounds__(256) void tk_compact_kernel(const float *__restrict__ probs, int A, TkState *state,
@@ -350,7 +398,8 @@ static ProposalLayout proposal_layout(int B, int n, int K)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     L.state = take((size_t)B * sizeof(TkState));
-    L.hist = take((size_t)B * TK_BINS * sizeof(unsigned));     // contiguous with state: zeroed by one memset
+    L.hist = take((size_t)B * (TK_BINS + 64) * sizeof(unsigned));     // contiguous with state: zeroed by one memset; the words behind the
+                                                                       // B histograms are the radix passes' arrival counters
     L.cand = take((size_t)B * TK_MAXK * sizeof(unsigned long long));
     L.order = take((size_t)B * K * sizeof(int));
     L.dets = take((size_t)B * 2 * n * 5 * sizeof(float));
@@ -374,6 +423,26 @@ int srcnn_rpn_score(const float *head, int B, int hw, int head_cstride, float *p
     SRCNN_LAUNCH(rpn_score_kernel, dim3(std::min(cdiv(total, 256), 4096)), dim3(256), 0, as_stream(stream), head,
                        B, hw, head_cstride, probs, deltas, level_offset, num_anchors_total);
     return check_launch("srcnn_rpn_score");
+}
+
+int srcnn_rpn_score_levels(const float *const *heads, const int *level_hw, int nlevels, int B, int head_cstride, float *probs,
+                           float *deltas, int num_anchors_total, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(heads && level_hw && probs && deltas && B > 0 && nlevels >= 1 && nlevels <= 5 && head_cstride >= 24, "bad args");
+    RpnLevels lv;
+    lv.n = nlevels;
+    lv.cum[0] = 0;
+    for (int l = 0; l < 5; ++l) {
+        lv.head[l] = l < nlevels ? heads[l] : nullptr;
+        SRCNN_REQUIRE(l >= nlevels || (heads[l] && level_hw[l] > 0), "null head / empty level");
+        lv.cum[l + 1] = lv.cum[l] + (l < nlevels ? level_hw[l] : 0);
+    }
+    SRCNN_REQUIRE(3 * lv.cum[nlevels] == num_anchors_total, "num_anchors_total must be 3 x the locations of all levels");
+    const int total = B * lv.cum[nlevels];
+    SRCNN_LAUNCH(rpn_score_levels_kernel, dim3(std::min(cdiv(total, 256), 4096)), dim3(256), 0, as_stream(stream), lv, B,
+                       head_cstride, probs, deltas, num_anchors_total);
+    return check_launch("srcnn_rpn_score_levels");
 }
 
 size_t srcnn_proposal_workspace_bytes(int B, int num_anchors, int pre_nms, int post_nms)
@@ -443,21 +512,16 @@ int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num
         const int G = 256;
         static const int sshift[3] = {21, 10, 0}, swidth[3] = {11, 11, 10};
         static const unsigned smask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
-        SRCNN_LAUNCH(tk_set_remaining_kernel, dim3(1), dim3(64), 0, st, state, B, (unsigned)ksel);
-        for (int p = 0; p < 3; ++p) {
-            SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, 0,
-                               sshift[p], swidth[p], smask[p]);
-            SRCNN_LAUNCH(tk_pick_kernel, dim3(B), dim3(64), 0, st, state, hist, 0, sshift[p], p == 2, ksel,
-                               num_anchors);
-        }
+        SRCNN_REQUIRE(B <= 64, "batches of more than 64 pairs not supported by the proposal layer");
+        unsigned *arrivals = hist + (size_t)B * TK_BINS;
+        for (int p = 0; p < 3; ++p)
+            SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, arrivals, 0,
+                               sshift[p], swidth[p], smask[p], p == 2 ? 1 : 0, p == 0 ? 1 : 0, (unsigned)ksel);
         static const int ishift[2] = {11, 0};
         static const unsigned imask[2] = {0u, 0xFFFFF800u};
-        for (int p = 0; p < 2; ++p) {
-            SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, 1,
-                               ishift[p], 11, imask[p]);
-            SRCNN_LAUNCH(tk_pick_kernel, dim3(B), dim3(64), 0, st, state, hist, 1, ishift[p], p == 1, ksel,
-                               num_anchors);
-        }
+        for (int p = 0; p < 2; ++p)
+            SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, arrivals, 1,
+                               ishift[p], 11, imask[p], p == 1 ? 1 : 0, 0, (unsigned)ksel);
         SRCNN_LAUNCH(tk_compact_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, cand, TK_MAXK);
         SRCNN_LAUNCH(tk_rank_kernel, dim3(cdiv(ksel, 64), B), dim3(1024), 0, st, cand, TK_MAXK, ksel, n, order);
     }

@@ -197,6 +197,11 @@ def tune_mode_key():
     return ('conc', TUNE_STREAMS) if TUNE_MODE == 'concurrent' and TUNE_STREAMS > 1 else ()
 
 
+# Measurement hook (mix_table.py): [(compiled regex, n)] -- a conv launch whose layer name matches is issued n MORE times right
+# behind itself (same arguments: the output is simply rewritten).  The step-time increase per extra launch is that layer's
+# marginal cost INSIDE the several-forwards-in-flight mix, which no per-launch timing can give.  Empty in production.
+REPEAT = []
+
 # Bumped by whoever rewrites _TUNED under a model that already recorded launch programs (tune.tune_throughput, load_plans):
 # every Plan compares it in run() and re-records.  KEY_HITS: while a dict, conv2d counts the launches per plan key.
 PLAN_EPOCH = 0
@@ -452,6 +457,11 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _lib.workspace(need, x.device, "conv")
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")
+    if REPEAT and name:
+        for rx, n in REPEAT:
+            if rx.match(name):
+                for _ in range(n):
+                    _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d(repeat)")
 
 
 def preprocess_size(H, W, target_short=600):

@@ -154,6 +154,8 @@ class Plan(object):
         self.h2 = e(R, 2048)
         self.fc = e(R, weights.fc.cout)
         self.cls_prob = e(R, weights.n_cls)
+        self.bbox_pred = e(R, weights.n_bbox)          # contiguous copies of the fc output's regression columns (srcnn_box_head_tail)
+        self.dim_orien = e(R, weights.n_dim)
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         self.kp_in = e(R, 2 * P, 2 * P, 256)
         # zero-initialised: the lazy keypoint head (kpts_for_kept) computes the leading rows only, and the rows behind them
@@ -180,6 +182,7 @@ class Plan(object):
         self.programs = {}      # (precision, kpts, branches on side streams) -> (native launch program handle, buffers it keeps alive)
         self._rec = None        # program being recorded right now
         self.packed_fmt = -1    # format `packed` currently holds for the inputs of the NEXT run (-1: none, pack in trunk())
+        self._src = (self.im_left, self.im_right)    # where trunk() packs the stem input from: this plan's own planes, or the caller's tensors (set_inputs)
         self.fmt = 0            # activation format of the internal buffers for the current/last run
         # independent branches of the forward (FPN laterals, small RPN levels, box head vs keypoint head) are
         # issued on side streams with event fork/join, so eager runs AND the captured hipGraph execute them
@@ -285,10 +288,10 @@ class Plan(object):
         w, N = self.w, self.N
         H, W = self.H, self.W
         f = self.fmt                                  # SPLIT16 activations (f16x3 engine) or F32
-        if self.packed_fmt != f:                      # set_images() already wrote the stem input in this format otherwise
-            engine.stem_pack(self.im_left, self.packed, 0, out_fmt=f)
-            engine.stem_pack(self.im_right, self.packed, self.B, out_fmt=f)
-        self.packed_fmt = -1                          # consumed: the next forward packs again unless set_images() ran
+        if self.packed_fmt != f:                      # set_images() / pack_inputs() already wrote the stem input in this format otherwise
+            engine.stem_pack(self._src[0], self.packed, 0, out_fmt=f)
+            engine.stem_pack(self._src[1], self.packed, self.B, out_fmt=f)
+        self.packed_fmt = -1                          # consumed: the next forward packs again unless set_images() / pack_inputs() ran
         sh, sw = self.stem_hw
         self._conv(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, None, 'stem', x_cstride=4, x_fmt=f, name='stem')   # F32 out
         ph, pw = self.c1_hw
@@ -354,7 +357,6 @@ class Plan(object):
         feats = [self.p2, self.p3, self.p4, self.p5, self.p6]
         h, w_ = self.rpn_shapes[l]
         cat, hd = self.rpn_cat[l], self.rpn_hd[l]
-        off = sum(3 * a * b for a, b in self.rpn_shapes[:l])
         if f and engine.RPN_PAIR_LAUNCH:       # SPLIT16 engine: both eyes in one launch (conv mode 2: the right half lands 512 channels further)
             self._conv(w.rpn_conv_pair, feats[l], 2 * B, h, w_, cat, h, w_, 'P', 'rpn', y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f,
                        name='rpn_conv.P%d' % (l + 2))
@@ -364,8 +366,15 @@ class Plan(object):
             self._conv(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, 'P', 'rpn', y_cstride=1024, y_coffset=512,
                        x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
         self._conv(w.rpn_head, cat, B, h, w_, hd, h, w_, 'rpn', None, x_fmt=f, name='rpn_head.P%d' % (l + 2))
-        _lib.check(_lib.lib().srcnn_rpn_score(hd.data_ptr(), B, h * w_, 24, self.probs.data_ptr(),
-                                              self.deltas.data_ptr(), off, self.A, _lib.stream()), "srcnn_rpn_score")
+
+    def _rpn_scores(self):
+        """Pair softmax + NHWC flatten of every level's head output into probs / deltas (stereo_rpn.py:81-91): one launch for all
+        five levels, after the last of them (on whatever stream it ran) has been joined."""
+        nl = len(self.rpn_shapes)
+        heads = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.rpn_hd])
+        hw = (ctypes.c_int * nl)(*[a * b for a, b in self.rpn_shapes])
+        _lib.check(_lib.lib().srcnn_rpn_score_levels(heads, hw, nl, self.B, 24, self.probs.data_ptr(), self.deltas.data_ptr(), self.A,
+                                                     _lib.stream()), "srcnn_rpn_score_levels")
 
     def fpn_rpn(self):
         """FPN top-down path (stereo_rcnn.py:161-168) with the stereo RPN head (stereo_rpn.py:73-95) of every
@@ -420,6 +429,7 @@ class Plan(object):
         if par:
             self._join(s_lat)
             self._join(s_rpn)
+        self._rpn_scores()
 
     def fpn(self):
         prev, self.overlap = self.overlap, False
@@ -432,6 +442,7 @@ class Plan(object):
         """(kept for stage timing tools) the RPN head alone, serial."""
         for l in range(5):
             self._rpn_level(l)
+        self._rpn_scores()
 
     def proposals(self):
         L = _lib.lib()
@@ -466,8 +477,8 @@ class Plan(object):
         self._conv(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, 'P', 'h1', x_fmt=f, y_fmt=f, name='box.top0')   # 7x7/7 conv == GEMM (resnet.py:257)
         self._conv(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, 'h1', 'h2', x_fmt=f, y_fmt=f, name='box.top3')
         self._conv(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, 'h2', None, x_fmt=f, name='box.fc')
-        _lib.check(_lib.lib().srcnn_softmax_rows(self.fc.data_ptr() + 4 * (w.n_bbox + w.n_dim), R, w.n_cls, w.fc.cout,
-                                                 self.cls_prob.data_ptr(), _lib.stream()), "srcnn_softmax_rows")
+        _lib.check(_lib.lib().srcnn_box_head_tail(self.fc.data_ptr(), R, w.n_bbox, w.n_dim, w.n_cls, w.fc.cout, self.bbox_pred.data_ptr(),
+                                                  self.dim_orien.data_ptr(), self.cls_prob.data_ptr(), _lib.stream()), "srcnn_box_head_tail")
 
     def kpts_head(self, rois=None, n_rois=None, limit=None, outs=None):
         """Keypoint branch (stereo_rcnn.py:260-271).  Default: all R rois of the forward.  rois / n_rois / limit: the lazy form
@@ -564,10 +575,27 @@ class Plan(object):
         self.heads(kpts)
 
     # ------------------------------------------------------------------ driver
-    def set_inputs(self, im_left, im_right, im_info):
-        self.im_left.copy_(im_left, non_blocking=True)
-        self.im_right.copy_(im_right, non_blocking=True)
+    def set_inputs(self, im_left, im_right, im_info, copy=False):
+        """The network inputs of the next run.  Float32 contiguous device tensors are NOT copied: the stem's pack kernel reads them
+        where they are (the plan keeps a reference until the next call; two 14 MB copy launches per forward saved) -- unless
+        `copy` (a captured hipGraph reads fixed addresses) or the tensors need a conversion anyway."""
+        ok = lambda t: (t.is_cuda and t.device == self.dev and t.dtype == torch.float32 and t.is_contiguous()
+                        and tuple(t.shape) == tuple(self.im_left.shape))
+        if copy or not (ok(im_left) and ok(im_right)):
+            self.im_left.copy_(im_left, non_blocking=True)
+            self.im_right.copy_(im_right, non_blocking=True)
+            self._src = (self.im_left, self.im_right)
+        else:
+            self._src = (im_left, im_right)
+        self.packed_fmt = -1
         self.im_info.copy_(im_info.view(self.B, 3), non_blocking=True)
+
+    def pack_inputs(self, fmt):
+        """Issue the stem-input pack of the current sources NOW (outside a recorded launch program: the program's own launch list
+        then starts at the stem conv and never holds a pointer to a caller's tensor)."""
+        engine.stem_pack(self._src[0], self.packed, 0, out_fmt=fmt)
+        engine.stem_pack(self._src[1], self.packed, self.B, out_fmt=fmt)
+        self.packed_fmt = fmt
 
     def set_images(self, img_left_u8, img_right_u8, precision='f32', target_short=600):
         """Fused A0 (B = 1): uint8 RGB device images -> this plan's network-input planes (kept: dense alignment reads
@@ -588,6 +616,7 @@ class Plan(object):
                                           self.packed.data_ptr() + i * per_image, fmt, _lib.stream()), "srcnn_preprocess")
         self.im_info.copy_(torch.tensor([[self.H, self.W, scale]], dtype=torch.float32), non_blocking=True)
         self.packed_fmt = fmt
+        self._src = (self.im_left, self.im_right)      # the planes the preprocessing just wrote
         return scale
 
     def _record_program(self, precision, kpts=True):
@@ -596,6 +625,7 @@ class Plan(object):
         L = _lib.lib()
         self.launch_all(kpts)                 # warm-up: tunes the plans, sizes every workspace, splits the weights
         torch.cuda.synchronize()
+        self.packed_fmt = self.fmt            # `packed` holds this input in the run's format: the recorded list starts behind the pack
         prog = L.srcnn_program_create()
         refs = []
         _lib._recording_refs = refs
@@ -631,9 +661,17 @@ class Plan(object):
             self.programs, self.graphs, self._epoch = {}, {}, epoch
         try:
             if use_program and not use_graph:
-                self.packed_fmt = -1                  # the recorded list always contains the stem_pack launches
+                # the stem input is packed here, eagerly, from wherever the inputs are (set_inputs keeps references instead of
+                # copying; set_images wrote `packed` itself); the recorded list starts at the stem conv
                 ent = self.programs.get((precision, kpts, self._par()))      # one list per (engine, branch, stream regime)
-                prog = ent[0] if ent else self._record_program(precision, kpts)
+                if ent is None:
+                    prog = self._record_program(precision, kpts)             # (its warm-up run packs and consumes the input)
+                    self.packed_fmt = -1
+                else:
+                    prog = ent[0]
+                if self.packed_fmt != self.fmt:
+                    self.pack_inputs(self.fmt)
+                self.packed_fmt = -1
                 _lib.check(_lib.lib().srcnn_program_run(prog, torch.cuda.current_stream().cuda_stream), "srcnn_program_run")
                 return
             if not use_graph or not kpts:
@@ -659,30 +697,27 @@ class Plan(object):
         k = self._buf_shift.get(buf.data_ptr(), 0)
         return y * (2.0 ** -k) if k else y
 
-    def outputs(self, kpts=True):
-        """The forward's results as tensors the caller owns.  After an eager run the result buffers themselves are
-        handed over and replaced by fresh allocations (no copy kernels); a captured graph writes to fixed addresses,
-        so once a graph exists the results are cloned instead."""
+    def outputs(self, kpts=True, alias=False):
+        """The forward's results.  Default: tensors the caller OWNS -- after an eager run the result buffers themselves are handed
+        over and replaced by fresh allocations (no copy kernels); a recorded launch program / captured graph writes to fixed
+        addresses, so once one exists the results are cloned instead (8 small copy launches).
+        alias=True (the streamed entry points: pipeline flows, bench.py's step): VIEWS of this plan's own buffers, valid until the
+        next forward on this plan (slot) -- for callers that consume them in stream order right away (decode + class NMS write
+        fresh tensors), which is what every serving flow does: no copy launches at all."""
         w, B = self.w, self.B
-        fc = self.fc.view(B, self.post, -1)
-        bbox_pred = fc[:, :, :w.n_bbox].contiguous()
-        dim_orien = fc[:, :, w.n_bbox:w.n_bbox + w.n_dim].contiguous()
+        names = ('rois_left', 'rois_right', 'cls_prob', 'bbox_pred', 'dim_orien', 'kpts_prob', 'left_prob', 'right_prob')
+        if alias:
+            t = {n: getattr(self, n) for n in names}
+        elif self.graphs or self.programs:
+            t = {n: (getattr(self, n).clone() if kpts or n not in ('kpts_prob', 'left_prob', 'right_prob') else None) for n in names}
+        else:
+            t = {n: getattr(self, n) for n in names}
+            for n in names:
+                if kpts or n not in ('kpts_prob', 'left_prob', 'right_prob'):
+                    setattr(self, n, torch.empty_like(getattr(self, n)))
+        res = {'rois_left': t['rois_left'], 'rois_right': t['rois_right'], 'cls_prob': t['cls_prob'].view(B, self.post, -1),
+               'bbox_pred': t['bbox_pred'].view(B, self.post, -1), 'dim_orien_pred': t['dim_orien'].view(B, self.post, -1),
+               'kpts_prob': t['kpts_prob'], 'left_border_prob': t['left_prob'], 'right_border_prob': t['right_prob']}
         if not kpts:        # lazy keypoint head: the three keypoint outputs do not exist for this forward
-            res = {'rois_left': self.rois_left.clone(), 'rois_right': self.rois_right.clone(),
-                   'cls_prob': self.cls_prob.view(B, self.post, -1).clone(), 'bbox_pred': bbox_pred, 'dim_orien_pred': dim_orien,
-                   'kpts_prob': None, 'left_border_prob': None, 'right_border_prob': None}
-            return res
-        if self.graphs or self.programs:
-            return {
-                'rois_left': self.rois_left.clone(), 'rois_right': self.rois_right.clone(),
-                'cls_prob': self.cls_prob.view(B, self.post, -1).clone(),
-                'bbox_pred': bbox_pred, 'dim_orien_pred': dim_orien,
-                'kpts_prob': self.kpts_prob.clone(), 'left_border_prob': self.left_prob.clone(),
-                'right_border_prob': self.right_prob.clone(),
-            }
-        out = {'rois_left': self.rois_left, 'rois_right': self.rois_right,
-               'cls_prob': self.cls_prob.view(B, self.post, -1), 'bbox_pred': bbox_pred, 'dim_orien_pred': dim_orien,
-               'kpts_prob': self.kpts_prob, 'left_border_prob': self.left_prob, 'right_border_prob': self.right_prob}
-        for name in ('rois_left', 'rois_right', 'cls_prob', 'kpts_prob', 'left_prob', 'right_prob'):
-            setattr(self, name, torch.empty_like(getattr(self, name)))
-        return out
+            res['kpts_prob'] = res['left_border_prob'] = res['right_border_prob'] = None
+        return res

@@ -40,6 +40,10 @@ class _StereoRCNN(nn.Module):
         # conv engine: 'f16x3' (default: error-compensated 3-term split on the f16 MFMA, fp32-class results, same parity
         # tolerances) or 'f32' (exact fp32 MFMA, ~2.4x slower)
         self.precision = 'f16x3'
+        # forward() returns tensors the caller owns (copies, once a launch program / graph writes to fixed addresses).  True -- or
+        # forward(alias_outputs=True), what the streamed entry points pass -- returns VIEWS of the slot's own result buffers instead,
+        # valid until the next forward on that slot: for callers that consume them right away in stream order (plan.Plan.outputs)
+        self.alias_outputs = False
         self._weights = None
         self._plans = {}
 
@@ -134,7 +138,7 @@ class _StereoRCNN(nn.Module):
         return engine.nhwc_to_nchw(out)
 
     def forward(self, im_left_data, im_right_data, im_info, gt_boxes_left=None, gt_boxes_right=None,
-                gt_boxes_merge=None, gt_dim_orien=None, gt_kpts=None, num_boxes=None, slot=0, kpts=True):
+                gt_boxes_merge=None, gt_dim_orien=None, gt_kpts=None, num_boxes=None, slot=0, kpts=True, alias_outputs=None):
         """Reference signature and 15-tuple return (stereo_rcnn.py:141-142,322-324).
         The gt_* / num_boxes arguments are accepted and ignored exactly as in eval mode.
         `slot` (extension): independent buffer set, so that several pairs can be in flight on different HIP
@@ -146,10 +150,10 @@ class _StereoRCNN(nn.Module):
             raise NotImplementedError("training forward is out of scope; call .eval()")
         B, _, H, W = im_left_data.shape
         plan = self._get_plan(int(B), int(H), int(W), slot)
-        plan.set_inputs(im_left_data, im_right_data, im_info)
-        return self._run(plan, kpts)
+        plan.set_inputs(im_left_data, im_right_data, im_info, copy=bool(self.use_graph))
+        return self._run(plan, kpts, alias_outputs)
 
-    def forward_images(self, img_left_u8, img_right_u8, target_short=None, slot=0, kpts=True):
+    def forward_images(self, img_left_u8, img_right_u8, target_short=None, slot=0, kpts=True, alias_outputs=None):
         """Extension: the reference's preprocessing (demo.py:103-129) fused in front of the forward.  uint8 RGB
         (H, W, 3) DEVICE images -> (the forward's 15-tuple, im_left_data, im_right_data, im_info); the network-input planes
         and the stem's packed input are produced in one pass per eye, the float32 planes are returned because the dense
@@ -161,7 +165,7 @@ class _StereoRCNN(nn.Module):
         OH, OW, _ = engine.preprocess_size(H0, W0, short)
         plan = self._get_plan(1, OH, OW, slot)
         plan.set_images(img_left_u8, img_right_u8, self.precision, short)
-        return self._run(plan, kpts), plan.im_left, plan.im_right, plan.im_info
+        return self._run(plan, kpts, alias_outputs), plan.im_left, plan.im_right, plan.im_info
 
     def calibrate_activation_scales(self, frames, slot=0):
         """Extension: choose the SPLIT16 engine's per-tensor power-of-two activation scales (plan.Plan.calibrate) from SEVERAL
@@ -187,9 +191,9 @@ class _StereoRCNN(nn.Module):
         if flag:
             raise engine.Split16RangeError('SPLIT16 range exceeded in %s' % name)
 
-    def _run(self, plan, kpts=True):
+    def _run(self, plan, kpts=True, alias=None):
         plan.run(self.use_graph, self.precision, getattr(self, 'use_program', False), kpts=kpts)
-        o = plan.outputs(kpts)
+        o = plan.outputs(kpts, alias=self.alias_outputs if alias is None else bool(alias))
         self.RCNN_loss_cls = 0
         self.RCNN_loss_bbox = 0
         rpn_loss_cls, rpn_loss_bbox_left_right = 0, 0

@@ -338,7 +338,7 @@ def _detect_3d_scipy(model, im_left_data, im_right_data, im_info, calib, im_shap
     k4, k3 = (14, 13) if native else (4, 3)
     with torch.no_grad():
         lazy = _lazy(model)                   # the same form of the keypoint branch as the record flows (see LAZY_KPTS)
-        out = model(im_left_data, im_right_data, im_info, kpts=not lazy)
+        out = model(im_left_data, im_right_data, im_info, kpts=not lazy, alias_outputs=True)
         det = postprocess.decode_detections(*out[:8], im_info)
         if lazy:
             keep_idx, num = postprocess.class_nms_device(det, class_index, eval_thresh, cfg.TEST.NMS)
@@ -426,7 +426,7 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
             return objs
     with torch.no_grad():
         lazy = _lazy(model)
-        out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy)
+        out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy, alias_outputs=True)
         st = launch_3d(out, im_left_data, im_right_data, im_info, _scale32(im_info), calib, im_shape, eval_thresh,
                        class_index, dense_align, slot, solver, lazy=_plan_of(model, im_left_data, slot) if lazy else None)
     try:
@@ -456,7 +456,7 @@ def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, 
     (model.forward_images), then the device 3-D flow.  wait=False returns the handle for collect_3d()."""
     with torch.no_grad():
         lazy = _lazy(model)
-        out, iml, imr, info = model.forward_images(img_left_u8, img_right_u8, slot=slot, kpts=not lazy)
+        out, iml, imr, info = model.forward_images(img_left_u8, img_right_u8, slot=slot, kpts=not lazy, alias_outputs=True)
         from . import engine
         scale = float(np.float32(engine.preprocess_size(int(img_left_u8.shape[0]), int(img_left_u8.shape[1]),
                                                         cfg.TEST.SCALES[0])[2]))
@@ -483,7 +483,7 @@ def launch_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shap
     B = int(im_left_data.shape[0])
     with torch.no_grad():
         lazy = _lazy(model)
-        out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy)
+        out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy, alias_outputs=True)
         pl = _plan_of(model, im_left_data, slot) if lazy else None
         handles = []
         for b in range(B):
@@ -529,7 +529,7 @@ RECALIBRATE_AFTER_TRIPS = 2      # range-guard trips (pairs re-run on the fp32 e
 # switched off: SRCNN_AUTO_RECALIBRATE=0 (or pipeline.AUTO_RECALIBRATE = False) keeps counting trips -- guard_trips(model) -- and
 # leaves the decision to the caller (model.calibrate_activation_scales(frames) is the controlled way; reset_guard_trips(model)).
 AUTO_RECALIBRATE = _os.environ.get('SRCNN_AUTO_RECALIBRATE', '1') != '0'
-MAX_SHIFT_WIDENING = 6           # automatic re-calibration never lowers a tensor group's shift by more than this many bits in total
+MAX_SHIFT_WIDENING = 10          # automatic re-calibration never lowers a tensor group's shift by more than this many bits in total (x1000)
 
 
 def guard_trips(model):
@@ -658,7 +658,7 @@ def _detect_3d_stream(model, frames, pool, eval_thresh, class_index, dense_align
                 l, r, info, calib, im_shape = frame[:5]
                 scale = float(np.float32(frame[5])) if len(frame) > 5 else _scale32(info)
                 lazy = _lazy(model)
-                out = model(l, r, info, slot=slot, kpts=not lazy)
+                out = model(l, r, info, slot=slot, kpts=not lazy, alias_outputs=True)
                 st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot, solver,
                                lazy=_plan_of(model, l, slot) if lazy else None)
         for older, _ in inflight:                              # solver='host': one host phase of every pair already in flight

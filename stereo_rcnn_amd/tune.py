@@ -45,7 +45,7 @@ class StepRunner(object):
 
     def step(self, slot):
         im_l, im_r, im_info = self.inputs
-        out = self.model(im_l, im_r, im_info, slot=slot, kpts=self.kpts)
+        out = self.model(im_l, im_r, im_info, slot=slot, kpts=self.kpts, alias_outputs=True)
         det = hpost.decode_detections(out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], im_info[0:1])
         hpost.class_nms_device(det, 1, 0.05)
 

@@ -690,7 +690,7 @@ def test_hip_forward_at_kitti_370x1224_through_the_product_preprocessing_with_ti
         assert list(iml.shape) == list(g['input_shape']) == [1, 3, 600, 1985]
         assert hashlib.sha256(np.ascontiguousarray(iml.cpu().numpy()).tobytes()).digest() == g['input_sha256'].tobytes()
         plan = m._get_plan(1, 600, 1985)
-        hip = tie_audit.hip_run_from_workspace(plan)
+        hip = tie_audit.hip_run_from_workspace(plan, out[0], out[1])
         # 1. the discrete stage's inputs
         eps_s = float(np.abs(hip['fg'] - g['rpn_fg']).max())
         top = torch.from_numpy(g['rpn_top_idx'].astype(np.int64))
@@ -903,3 +903,48 @@ def test_calibration_over_several_frames_and_program_invalidation(dev):
         assert float(ok.float().mean()) >= 0.97
         assert float((out[3][0].cpu()[idx[ok]] - ref[3][0].cpu()[ok]).abs().max()) < 1e-4
     assert torch.isfinite(c[3]).all()
+
+
+@pytest.mark.parametrize("use_program", [False, True])
+def test_aliased_outputs_and_inputs_by_reference(dev, use_program):
+    """forward(alias_outputs=True) -- what the streamed entry points pass -- returns views of the slot's own result buffers (no copy
+    launches): bit-equal to the owned outputs of the same forward, and overwritten by the next forward on that slot, as
+    documented.  Inputs are read where they are (no copy into the plan): a second forward from OTHER tensors must not see the
+    first ones, and a non-contiguous / float64 input still works (it is copied)."""
+    from stereo_rcnn_amd import fixture
+    m, _ = _build_model(dev)
+    m.precision, m.use_program = 'f16x3', use_program
+    a = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
+    b = [t.to(dev) for t in fixture.make_inputs(4, 120, 400, target_short=192)]
+    with torch.no_grad():
+        m(*a)                                                            # calibration, tuning, program recording
+        own_a = [t.clone() for t in m(*a)[:8]]
+        own_b = [t.clone() for t in m(*b)[:8]]
+        assert not torch.equal(own_a[3], own_b[3])
+        al = m(*a, alias_outputs=True)[:8]
+        plan = m._get_plan(1, a[0].shape[2], a[0].shape[3])
+        assert al[0].data_ptr() == plan.rois_left.data_ptr() and al[3].data_ptr() == plan.bbox_pred.data_ptr()
+        for x, y in zip(al, own_a):
+            assert torch.equal(x, y)
+        m(*b, alias_outputs=True)                                        # the views now show the next forward's results
+        for x, y in zip(al, own_b):
+            assert torch.equal(x, y)
+        # inputs that cannot be read in place are copied: float64, and a non-contiguous view of a wider tensor
+        wide = torch.zeros(1, 3, a[1].shape[2], a[1].shape[3] + 5, device=dev)
+        wide[..., :a[1].shape[3]] = a[1]
+        view = wide[..., :a[1].shape[3]]
+        assert not view.is_contiguous()
+        out_c = [t.clone() for t in m(a[0].double(), view, a[2])[:8]]
+        for x, y in zip(out_c, own_a):
+            assert torch.equal(x, y)
+        # the caller may overwrite its input tensors after the forward has been issued and synchronised; the next forward packs anew
+        scratch = [a[0].clone(), a[1].clone()]
+        r1 = [t.clone() for t in m(scratch[0], scratch[1], a[2])[:8]]
+        torch.cuda.synchronize()
+        scratch[0].copy_(b[0]); scratch[1].copy_(b[1])
+        r2 = [t.clone() for t in m(scratch[0], scratch[1], b[2])[:8]]
+    torch.cuda.synchronize()
+    for x, y in zip(r1, own_a):
+        assert torch.equal(x, y)
+    for x, y in zip(r2, own_b):
+        assert torch.equal(x, y)

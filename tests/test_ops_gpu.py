@@ -661,3 +661,51 @@ def test_conv_row_limit_never_reads_rows_beyond_it(dev):
     rows = keep * s * s
     assert torch.equal(got.view(-1, C).view(torch.int32)[:rows], want.view(-1, C).view(torch.int32)[:rows])
     assert torch.isfinite(engine.act_convert(got, S, 0)).all()
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_rpn_score_of_all_levels_in_one_launch_equals_the_per_level_launches(dev, B):
+    """srcnn_rpn_score_levels (one launch for the five pyramid levels) writes exactly what five srcnn_rpn_score launches write."""
+    import ctypes
+    from stereo_rcnn_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B)
+    shapes = [(38, 125), (19, 63), (10, 32), (5, 16), (3, 8)]
+    A = sum(3 * h * w for h, w in shapes)
+    heads = [(torch.randn(B, h * w, 24, generator=g) * 3).to(dev).contiguous() for h, w in shapes]
+    pa, da = torch.zeros(B, A, 2, device=dev), torch.zeros(B, A, 6, device=dev)
+    pb, db = torch.full((B, A, 2), -1.0, device=dev), torch.full((B, A, 6), -1.0, device=dev)
+    off = 0
+    for (h, w), hd in zip(shapes, heads):
+        _lib.check(L.srcnn_rpn_score(hd.data_ptr(), B, h * w, 24, pa.data_ptr(), da.data_ptr(), off, A, _lib.stream()))
+        off += 3 * h * w
+    ptrs = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in heads])
+    hw = (ctypes.c_int * 5)(*[h * w for h, w in shapes])
+    _lib.check(L.srcnn_rpn_score_levels(ptrs, hw, 5, B, 24, pb.data_ptr(), db.data_ptr(), A, _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(da, db)
+    assert L.srcnn_rpn_score_levels(ptrs, hw, 5, B, 24, pb.data_ptr(), db.data_ptr(), A + 3, _lib.stream()) != 0      # anchor count must match
+
+
+def test_proposal_selection_batched_and_repeated(dev):
+    """The radix select's passes are single launches whose LAST workgroup picks the digit (arrival counter per image): a batch of
+    three images with different tie structures, run three times on one workspace -- counters and histograms must come back to zero
+    by themselves, every run and every image equal to the oracle's stable top-K."""
+    from oracle import proposal as oprop
+    from stereo_rcnn_amd.model.rpn.proposal_layer import _ProposalLayer
+    g = torch.Generator().manual_seed(11)
+    shapes = [[38, 125], [19, 63], [10, 32], [5, 16], [3, 8]]
+    A = sum(3 * h * w for h, w in shapes)
+    sc = torch.rand(3, A, generator=g)
+    sc[1] = torch.round(sc[1] / 0.01) * 0.01                      # heavy ties
+    sc[2] = 0.5                                                   # all tied: the index tie-break decides everything
+    probs = torch.stack((1 - sc, sc), 2).contiguous()
+    deltas = (torch.randn(3, A, 6, generator=g) * 0.3).contiguous()
+    info = torch.tensor([[600.0, 1987.0, 1.6]] * 3)
+    rl_ref, rr_ref, extra = oprop.proposal_layer(probs, deltas, info, shapes, pre_nms_top_n=1000, post_nms_top_n=150)
+    layer = _ProposalLayer(16, [0.5, 1, 2])
+    for _ in range(3):
+        rl, rr = layer.run(probs.to(dev), deltas.to(dev), info.to(dev), shapes, 1000, 150, 0.7)
+        for b in range(3):
+            assert int(layer.last_num_valid[b]) == min(150, len(extra['keep'][b]))
+        assert float((rl.cpu() - rl_ref).abs().max()) < 2e-3 and float((rr.cpu() - rr_ref).abs().max()) < 2e-3

@@ -115,10 +115,11 @@ def audit(ref, hip, thresh=C.RPN_NMS_THRESH, chunk=400):
     return rep
 
 
-def hip_run_from_workspace(plan, b=0):
+def hip_run_from_workspace(plan, rois_left, rois_right, b=0):
     """The HIP proposal stage's ACTUAL intermediates of the plan's last forward, read out of the proposal workspace
     (include/srcnn_hip.h: srcnn_proposal_workspace_layout) -- the kernels' own candidate order, decoded boxes and keep lists, not a
-    re-computation.  Call on the stream the forward ran on, after synchronising."""
+    re-computation.  Call on the stream the forward ran on, after synchronising.  rois_left / rois_right: the forward's own outputs
+    (an eager forward hands its result buffers over and the plan allocates fresh ones)."""
     import ctypes
     from stereo_rcnn_amd import _lib
     from stereo_rcnn_amd.model.utils.config import cfg
@@ -136,4 +137,4 @@ def hip_run_from_workspace(plan, b=0):
     kl, kr = keep[0, :num[0]].astype(np.int64), keep[1, :num[1]].astype(np.int64)
     return {'order': order, 'dets_left': dets[0].copy(), 'dets_right': dets[1].copy(), 'keep_left': kl, 'keep_right': kr,
             'keep': np.intersect1d(kl, kr)[:post], 'fg': plan.probs[b, :, 1].cpu().numpy().astype(np.float32),
-            'rois_left': plan.rois_left[b:b + 1].cpu(), 'rois_right': plan.rois_right[b:b + 1].cpu()}
+            'rois_left': rois_left[b:b + 1].cpu(), 'rois_right': rois_right[b:b + 1].cpu()}
