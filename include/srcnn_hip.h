@@ -41,7 +41,7 @@ typedef void *srcnn_stream_t; /* hipStream_t */
 
 #define SRCNN_API __attribute__((visibility("default")))
 
-SRCNN_API int srcnn_version(void);   /* 210 = round 4: stream creation, placement probe, srcnn_conv_desc.head_* appended (older callers that zero the struct are unaffected) */
+SRCNN_API int srcnn_version(void);   /* 220 = round 5: srcnn_conv_desc.head_wf / head_rows / head_parts / head_plane appended, srcnn_rpn_score_levels / _parts, srcnn_box_head_tail, srcnn_proposal_workspace_layout; 210 = round 4: stream creation, placement probe, srcnn_conv_desc.head_* appended (older callers that zero the struct are unaffected) */
 SRCNN_API const char *srcnn_last_error(void);
 
 /* ------------------------------------------------------------------ NMS (A6)
@@ -165,6 +165,24 @@ typedef struct srcnn_conv_desc {
     void *head_y;
     int head_cout;
     float head_scale;
+    /* MFMA form of the fused narrow head (NULL = none; not together with head_w): the same second 1x1 convolution, computed as a
+     * small GEMM on the matrix pipe from the tile the epilogue holds in LDS -- 3-term f16 split like the engine itself, so the
+     * result equals what a separate launch of the head on the stored SPLIT16 activations gives (up to the summation order).
+     * head_wf: the head's weights (head_cout, C_h) split into hi / lo f16 (x 2^k like any weight) and zero-padded to head_rows
+     *   (a multiple of 8, <= 24) rows, in FRAGMENT ORDER: [C_h / 16 steps][hi, lo][k group 0, 1][head_rows][8 halves], element
+     *   (step s, g, n, i) = W[n][16 s + 8 g + i]   (stereo_rcnn_amd/engine.py: head_fragments builds it).
+     * head_parts = 0, FINAL form (Cq = 256: the 256x256 tile owns every channel of its pixels; modes 0 and 1):
+     *   head_y[pixel, k] = head_scale * sum_c act(conv(x))[pixel, c] W[k, c] + head_bias[k]     (head_cout floats per pixel)
+     * head_parts > 0, PARTIAL form (modes 0 and 2; Cout a multiple of 256): C_h = Cout (mode 0) or 2 Cout (mode 2: the head reads
+     *   [left Cout | right Cout], rows of the second half of the batch are the right eye) and every (eye, N tile) of the launch
+     *   stores its share   head_y[(eye * ntiles + nt) * head_plane + pixel * head_cout + k] = head_scale * partial sum;
+     *   the caller adds the planes in a fixed order and the bias (srcnn_rpn_score_parts).  ntiles = Cout / 256 (256x256 tile) or
+     *   Cout / 128 (tile_mr = tile_nr = 2: the 128x128 8-wave tile): size head_y for head_parts >= eyes * Cout / 128 planes.
+     * In both forms y is not written; the SPLIT16 range guard watches the activations that enter the head. */
+    const void *head_wf;
+    int head_rows;
+    int head_parts;
+    long long head_plane;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
@@ -225,6 +243,12 @@ SRCNN_API int srcnn_rpn_score(const float *head, int B, int hw, int head_cstride
  * entries); level l's anchors start at 3 x the locations of the levels before it; num_anchors_total = 3 x all locations. */
 SRCNN_API int srcnn_rpn_score_levels(const float *const *heads, const int *level_hw, int nlevels, int B, int head_cstride,
                                      float *probs, float *deltas, int num_anchors_total, srcnn_stream_t stream);
+/* ... and from the per-(eye, N tile) PARTIAL sums the RPN conv's fused head leaves (srcnn_conv_desc.head_wf, partial form): level l
+ * has nparts[l] planes of plane_floats[l] >= B * level_hw[l] * 24 floats each, plane q at parts[l] + q * plane_floats[l], rows
+ * (b * hw + loc) x 24 channels; the planes are added in index order, then bias24 (the head's 24 biases, device), then as above. */
+SRCNN_API int srcnn_rpn_score_parts(const float *const *parts, const int *nparts, const long long *plane_floats, const int *level_hw,
+                                    int nlevels, int B, const float *bias24, float *probs, float *deltas, int num_anchors_total,
+                                    srcnn_stream_t stream);
 /* Whole _ProposalLayer.forward (proposal_layer.py:42-145): anchors (generate_anchors.py:112-173),
  * decode+clip (bbox_transform.py:79-104,177-185), stable descending sort / top pre_nms,
  * NMS(left) & NMS(right), sorted intersection, first post_nms, zero pad, batch index in col 0.

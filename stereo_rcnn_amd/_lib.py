@@ -34,7 +34,8 @@ class ConvDesc(ctypes.Structure):
                 ("tile_waves", c_int), ("tile_stages", c_int), ("layer_tag", c_int),
                 ("m_limit", c_void_p), ("m_limit_mul", c_int),
                 ("x2", c_void_p), ("Cin2", c_int), ("H2", c_int), ("W2", c_int), ("x2_cstride", c_int), ("stride2", c_int),
-                ("head_w", c_void_p), ("head_bias", c_void_p), ("head_y", c_void_p), ("head_cout", c_int), ("head_scale", c_float)]
+                ("head_w", c_void_p), ("head_bias", c_void_p), ("head_y", c_void_p), ("head_cout", c_int), ("head_scale", c_float),
+                ("head_wf", c_void_p), ("head_rows", c_int), ("head_parts", c_int), ("head_plane", ctypes.c_longlong)]
 
 
 _SIGNATURES = {
@@ -71,6 +72,8 @@ _SIGNATURES = {
     "srcnn_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_rpn_score": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "srcnn_rpn_score_levels": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "srcnn_rpn_score_parts": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(c_int),
+                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "srcnn_proposal_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "srcnn_proposal_workspace_layout": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_size_t), c_int]),
     "srcnn_proposal_layer": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_void_p,

@@ -40,6 +40,13 @@ struct ConvArgs {
     const float *head_w, *head_b;
     float *head_y;
     float head_scale;
+    // ... or, MFMA form (srcnn_conv_desc.head_wf; 256x256 and 128x128 8-wave tiles): the head as a second, narrow GEMM on the tile the
+    // epilogue holds in LDS.  head_wf = the head's weights split into hi / lo f16 and laid out in MFMA fragment order; head_rows =
+    // its outputs padded to a multiple of 8 (<= 32), head_n the real ones; head_parts 0 = the tile owns all channels of its pixels:
+    // bias added, head_n floats per pixel stored; > 0 = per-(eye, N tile) partial sums into planes of head_plane floats each.
+    const void *head_wf;
+    int head_rows, head_n, head_parts;
+    long long head_plane;
 };
 
 

@@ -99,12 +99,16 @@ extern __shared__ __attribute__((aligned(1024))) _Float16 smem[];
 
 // MR/NR: per-WAVE tile in 32x32 MFMA tiles; WM x 2 waves per workgroup -> workgroup tile (32*MR*WM) x (64*NR).
 // WM = 2: 4 waves (256 threads).  WM = 4: 8 waves (512 threads).  NS: LDS ring stages (NS-1 K tiles in flight).
-// HEAD6 (256x256 tile only): the epilogue applies a 6-channel 1x1 head to the activated pixels and stores that instead of y
-// (srcnn_conv_desc.head_w).
-template <int MR, int NR, bool OUT_SPLIT, int WM, int NS, bool HEAD6 = false>
+// HEAD: 0 = none; 1 (256x256 tile only) = the epilogue applies a 6-channel 1x1 head to the activated pixels with fp32 FMAs and
+// stores that instead of y (srcnn_conv_desc.head_w); 2 = the MFMA form of a narrow head (<= 32 outputs, srcnn_conv_desc.head_wf):
+// a second GEMM over the tile's columns on the matrix pipe, final or as per-(eye, N tile) partial sums.
+template <int MR, int NR, bool OUT_SPLIT, int WM, int NS, int HEAD = 0>
 __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_kernel(const ConvArgs p)
 {
+    constexpr bool HEAD6 = HEAD == 1;
     static_assert(!HEAD6 || (MR == 2 && NR == 4 && WM == 4 && NS == 2 && !OUT_SPLIT), "the fused head lives in the 256x256 tile");
+    static_assert(HEAD != 2 || (!OUT_SPLIT && WM == 4 && NS == 2 && ((MR == 2 && NR == 4) || (MR == 1 && NR == 2))),
+                  "the MFMA-form head exists for the 256x256 and the 128x128 8-wave tiles");
     constexpr int NWAVES = 2 * WM, NTHREADS = 64 * NWAVES;
     constexpr int BM = 32 * MR * WM, BN = 64 * NR;
     constexpr int AG = BM / (16 * NWAVES), BG = BN / (16 * NWAVES);   // 16-row DMA groups per wave (A, B)
@@ -627,6 +631,7 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
             bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
             bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
         }
+        int head_slice = -1;                                     // HEAD 2: the eye whose W2 slice + bias sit in LDS (workgroup-uniform)
         // one pass as a function of the COMPILE-TIME pass index: a run-time `ps` loop that the optimizer declines to unroll
         // (it did, for the two-pass tiles) would index the accumulators dynamically and push all of them into scratch
         auto one_pass = [&](auto ps_c) __attribute__((always_inline)) {
@@ -659,12 +664,115 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const int r = rb + (e & 3) + 8 * (e >> 2) + 4 * lg;
-                            tile[r * BN + (wn * NR + j) * 32 + li] = acc[i][j][e] * os;
+                            const int c = (wn * NR + j) * 32 + li;
+                            // HEAD 2 reads the tile back one ROW per lane (MFMA A fragments): the 8-float groups of a row are
+                            // XOR-swizzled by the row so that 32 rows do not meet in one bank
+                            tile[r * BN + (HEAD == 2 ? (c ^ ((r & 7) << 3)) : c)] = acc[i][j][e] * os;
                         }
                 }
             }
             __syncthreads();
             if (p.stamp && ps == 0) st4 = __builtin_readcyclecounter();
+            if constexpr (HEAD == 2) {
+                // ---- narrow head as a second GEMM on the matrix pipe:  out[row][n] = sum_c act(tile[row][c] + bias[c]) * W2[n][c]
+                // over the BN columns of this tile.  A 32-row block per wave: lane (row li, k group lg) reads 8 consecutive tile
+                // columns per 16-wide K step, adds bias, ReLUs and splits into the hi / lo f16 fragments IN REGISTERS; the W2
+                // fragments of the tile's columns sit in LDS behind the tile in fragment order (one 16-byte read per lane, no
+                // conflicts).  3 products per step into one 32x32 accumulator whose lanes li < head_n hold 16 rows of output n = li.
+                // Mode 2 (stereo pair launch): rows of the second half of the batch are the other eye and meet another slice of W2 --
+                // a tile that straddles the halves runs the K steps once per eye with the other eye's rows zeroed.
+                constexpr int NBLK = RPP / 32, KS = BN / 16;
+                static_assert(NBLK <= NWAVES, "one 32-row block per wave");
+                float *hb = reinterpret_cast<float *>(smem + NS * STAGE);                 // [BN] bias of the tile's columns
+                half8 *hw = reinterpret_cast<half8 *>(hb + BN);                            // [KS][hi, lo][lg][head_rows] fragments
+                const int n2p = p.head_rows;
+                const int colbase = p.mode == 1 ? n0 - (n0 / cq) * cq : n0;               // first column's channel within the pixel
+                const int half_rows = (p.nimg >> 1) * p.OH * p.OW;
+                const int m_hi = min(mp + RPP, p.M);
+                if (mp < m_hi) {                                                            // (workgroup-uniform)
+                    const int pe_lo = (p.mode == 2 && mp >= half_rows) ? 1 : 0;
+                    const int pe_hi = (p.mode == 2 && m_hi - 1 >= half_rows) ? 1 : 0;
+                    floatx16 acc2;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+                    float gmax = 0.f;
+                    bool bad = false;
+                    const int row_l = wave * 32 + li;                                       // this lane's A row inside the pass
+                    const int row_g = mp + row_l;
+                    for (int eye = pe_lo; eye <= pe_hi; ++eye) {
+                        if (head_slice != eye) {                                            // (uniform) stage bias + W2 slice of this eye
+                            if (head_slice >= 0) __syncthreads();                           // readers of the previous slice are through
+                            for (int i = t; i < BN; i += NTHREADS)
+                                hb[i] = (p.bias && n0 + i < p.Cout) ? p.bias[colbase + i] : 0.f;
+                            const int s0 = ((p.mode == 2 ? eye * p.Cout : 0) + colbase) >> 4;
+                            const uint4 *src = reinterpret_cast<const uint4 *>(p.head_wf) + (size_t)s0 * n2p * 4;
+                            uint4 *dst = reinterpret_cast<uint4 *>(hw);
+                            for (int i = t; i < KS * n2p * 4; i += NTHREADS) dst[i] = src[i];
+                            __syncthreads();
+                            head_slice = eye;
+                        }
+                        if (wave < NBLK) {
+                            const bool mine = row_g < p.M && (p.mode != 2 || ((row_g >= half_rows) ? 1 : 0) == eye);
+                            const float *trow = tile + row_l * BN;
+                            const int sw = row_l & 7;
+#pragma unroll 2
+                            for (int s = 0; s < KS; ++s) {
+                                const int grp = (2 * s + lg) ^ sw;
+                                const float4 a0 = *reinterpret_cast<const float4 *>(trow + grp * 8);
+                                const float4 a1 = *reinterpret_cast<const float4 *>(trow + grp * 8 + 4);
+                                const float4 b0 = *reinterpret_cast<const float4 *>(hb + 16 * s + 8 * lg);
+                                const float4 b1 = *reinterpret_cast<const float4 *>(hb + 16 * s + 8 * lg + 4);
+                                float v[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+                                half8 ah, al;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    bad = bad || (v[i] != v[i]);                           // before the ReLU launders a NaN
+                                    if (p.relu) v[i] = fmaxf(v[i], 0.f);
+                                    if (!mine) v[i] = 0.f;
+                                    gmax = fmaxf(gmax, fabsf(v[i]));
+                                    ah[i] = (_Float16)v[i];
+                                    al[i] = (_Float16)(v[i] - (float)ah[i]);
+                                }
+                                half8 bh, bl;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) { bh[i] = (_Float16)0.f; bl[i] = (_Float16)0.f; }
+                                if (li < n2p) {
+                                    bh = hw[((s * 2 + 0) * 2 + lg) * n2p + li];
+                                    bl = hw[((s * 2 + 1) * 2 + lg) * n2p + li];
+                                }
+                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+                                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2, 0, 0, 0);
+                            }
+                        }
+                    }
+                    // the activations never reach memory, so the range guard of the SPLIT16 store is applied here (hi = f16(v))
+                    if (wave < NBLK && (bad || !(gmax <= 65504.f))) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
+                    if (wave < NBLK && li < p.head_n) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int row = mp + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+                            if (row >= p.M) continue;
+                            if (p.head_parts == 0) {
+                                size_t opix = (size_t)row;
+                                if (p.mode == 1) {                   // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j); the tile is one tap
+                                    const int ij2 = n0 / cq;
+                                    const int ohw2 = p.OH * p.OW;
+                                    const int bb = row / ohw2, rem = row - bb * ohw2;
+                                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                                    opix = ((size_t)bb * 2 * p.OH + 2 * oh + (ij2 >> 1)) * (2 * p.OW) + 2 * ow + (ij2 & 1);
+                                }
+                                p.head_y[opix * p.head_n + li] = fmaf(acc2[e], p.head_scale, p.head_b[li]);
+                            } else {
+                                const int eye = (p.mode == 2 && row >= half_rows) ? 1 : 0;
+                                const size_t px = (size_t)(row - eye * half_rows);
+                                p.head_y[(size_t)(eye * p.ntiles + nt) * p.head_plane + px * p.head_n + li] = acc2[e] * p.head_scale;
+                            }
+                        }
+                    }
+                }
+                return;
+            }
             if constexpr (HEAD6) {
                 // Fused 6-channel head (srcnn_conv_desc.head_w) instead of the y store.  GROUPS == 32 lanes hold the 256 channels
                 // of a pixel (lanes 0-31 / 32-63 of a wave: two pixels): 8 channels per lane in order, then a DPP scan over the
@@ -872,9 +980,24 @@ static void launch(const ConvArgs &a, int splits, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
+    if constexpr (WM == 4 && NS == 2 && ((MR == 2 && NR == 4) || (MR == 1 && NR == 2))) {
+        if (a.head_wf) {                       // MFMA-form narrow head: bias + W2 fragments of the tile's columns behind the tile
+            auto *kh = conv_f16s_kernel<MR, NR, false, WM, NS, 2>;
+            constexpr size_t BN_ = 64 * NR;
+            const size_t lds2 = lds + BN_ * 4 + (BN_ / 16) * (size_t)a.head_rows * 64;
+            static bool head2_configured = false;
+            if (!head2_configured) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kh), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(lds + BN_ * 4 + (BN_ / 16) * 32 * 64 > 163840 ? 163840 : lds + BN_ * 4 + (BN_ / 16) * 32 * 64));
+                head2_configured = true;
+            }
+            SRCNN_LAUNCH(kh, dim3(a.mtiles * a.ntiles, splits), dim3(128 * WM), lds2, st, a);
+            return;
+        }
+    }
     if constexpr (MR == 2 && NR == 4 && WM == 4 && NS == 2) {
         if (a.head_w) {                        // fused 6-channel head instead of the y store
-            auto *kh = conv_f16s_kernel<MR, NR, false, WM, NS, true>;
+            auto *kh = conv_f16s_kernel<MR, NR, false, WM, NS, 1>;
             static bool head_configured = false;
             if (!head_configured) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -324,6 +324,12 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
         h.mr = 4; h.nr = 4; h.waves = 8; h.stages = 2; h.splits = 1; h.kt_per_split = a.nkt;
         return h;
     }
+    if (a.head_wf) {               // MFMA-form head: the 256x256 tile or (partial form only) the 128x128 8-wave tile; 2-stage ring;
+        Plan h = pl;               // never split: the head needs the finished, activated sums
+        const bool small = a.head_parts > 0 && ((d->tile_mr == 2 && d->tile_nr == 2) || (d->tile_mr <= 0 && a.M < 256 * 8));
+        h.mr = small ? 2 : 4; h.nr = small ? 2 : 4; h.waves = 8; h.stages = 2; h.splits = 1; h.kt_per_split = a.nkt;
+        return h;
+    }
     if (d->tile_mr <= 0 || d->tile_nr <= 0) return pl;
     Plan req = pl;
     req.mr = d->tile_mr;
@@ -345,7 +351,7 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
 
 static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
 {
-    SRCNN_REQUIRE(d && d->x && d->w && (d->y || d->head_w), "null pointer");
+    SRCNN_REQUIRE(d && d->x && d->w && (d->y || d->head_w || d->head_wf), "null pointer");
     SRCNN_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, "Cin must be a positive multiple of 32");
     SRCNN_REQUIRE(d->x_cstride % 4 == 0, "x_cstride must be a multiple of 4 floats (16-B loads)");
     SRCNN_REQUIRE(d->B > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "bad output shape");
@@ -400,7 +406,22 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
         // offset that is not a multiple of 8 would skip it and leave head_y unwritten
         SRCNN_REQUIRE((d->y_cstride & 7) == 0 && (d->y_coffset & 7) == 0, "fused head: y_cstride and y_coffset must be multiples of 8");
     }
-    if (a.y_fmt == 1) {
+    a.head_wf = d->head_wf;
+    a.head_rows = d->head_rows; a.head_n = d->head_cout; a.head_parts = d->head_parts; a.head_plane = d->head_plane;
+    if (a.head_wf) {
+        const int cq = d->mode == 1 ? d->Cout / 4 : d->Cout;
+        SRCNN_REQUIRE(!a.head_w && d->precision == 1 && d->x_format == 1 && a.head_y && !d->x2 && !d->residual,
+                      "MFMA-form head: SPLIT16 f16x3 engine, no residual / second input, not together with head_w");
+        SRCNN_REQUIRE(d->head_rows >= 8 && d->head_rows <= 24 && (d->head_rows & 7) == 0 && d->head_cout >= 1 && d->head_cout <= d->head_rows,
+                      "MFMA-form head: head_rows a multiple of 8 up to 24, 1 <= head_cout <= head_rows");
+        SRCNN_REQUIRE((d->y_cstride & 7) == 0 && (d->y_coffset & 7) == 0 && (cq & 7) == 0, "MFMA-form head: channel counts / strides multiples of 8");
+        if (d->head_parts == 0)
+            SRCNN_REQUIRE(cq == 256 && a.head_b && d->mode != 2, "MFMA-form head, final form: 256-channel pixels (one 256x256 tile owns them), bias, not mode 2");
+        else
+            SRCNN_REQUIRE(d->mode != 1 && d->Cout % 256 == 0 && d->head_parts >= (d->mode == 2 ? 2 : 1) * (d->Cout / 128) && d->head_plane > 0,
+                          "MFMA-form head, partial form: Cout a multiple of 256, head_parts planes for every (eye, 128-column tile)");
+    }
+    if (a.y_fmt == 1 || a.head_wf) {
         a.range_flag = range_flag_word();
         SRCNN_REQUIRE(a.range_flag != nullptr, "range flag allocation failed");
     }

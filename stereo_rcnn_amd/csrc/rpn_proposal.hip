@@ -87,6 +87,57 @@ __global__ void rpn_score_levels_kernel(RpnLevels lv, int B, int hcs, float *__r
     }
 }
 
+// The same from the PARTIAL sums the RPN conv's fused head leaves (conv_f16s.hip, HEAD 2; srcnn_conv_desc.head_wf): level l has
+// nparts[l] planes of (B * hw_l, 24) floats -- one per (eye, N tile) of its launch --, added here in plane order, then the bias.
+struct RpnParts {
+    const float *part[5];
+    long long plane[5];     // floats per plane
+    int nparts[5];
+    int cum[6];
+    int n;
+};
+
+__global__ void rpn_score_parts_kernel(RpnParts lv, int B, const float *__restrict__ bias, float *__restrict__ probs,
+                                       float *__restrict__ deltas, int a_total)
+{
+    const int per = lv.cum[lv.n];
+    const int total = B * per;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += blockDim.x * gridDim.x) {
+        const int b = idx / per, g = idx - b * per;
+        int l = 0;
+        while (l + 1 < lv.n && g >= lv.cum[l + 1]) ++l;
+        const int hw = lv.cum[l + 1] - lv.cum[l], loc = g - lv.cum[l];
+        const float *p0 = lv.part[l] + ((size_t)b * hw + loc) * 24;
+        float h[24];
+#pragma unroll
+        for (int c = 0; c < 24; c += 4) {
+            float4 s = *reinterpret_cast<const float4 *>(p0 + c);
+            for (int q = 1; q < lv.nparts[l]; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(p0 + (size_t)q * lv.plane[l] + c);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            h[c] = s.x + bias[c]; h[c + 1] = s.y + bias[c + 1]; h[c + 2] = s.z + bias[c + 2]; h[c + 3] = s.w + bias[c + 3];
+        }
+        float pr[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s0 = h[c], s1 = h[c + 3];
+            const float m = fmaxf(s0, s1);
+            const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+            const float sum = e0 + e1;
+            pr[c] = e0 / sum;
+            pr[c + 3] = e1 / sum;
+        }
+        const size_t base = (size_t)b * a_total + ((size_t)lv.cum[l] + loc) * 3;
+        float *po = probs + base * 2;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) po[c] = pr[c];
+        float *dl = deltas + base * 6;
+#pragma unroll
+        for (int c = 0; c < 18; ++c) dl[c] = h[6 + c];
+    }
+}
+
 // ------------------------------------------------------------------ top-K + sort
 __device__ __forceinline__ unsigned score_key(float f)
 {
@@ -443,6 +494,33 @@ int srcnn_rpn_score_levels(const float *const *heads, const int *level_hw, int n
     SRCNN_LAUNCH(rpn_score_levels_kernel, dim3(std::min(cdiv(total, 256), 4096)), dim3(256), 0, as_stream(stream), lv, B,
                        head_cstride, probs, deltas, num_anchors_total);
     return check_launch("srcnn_rpn_score_levels");
+}
+
+int srcnn_rpn_score_parts(const float *const *parts, const int *nparts, const long long *plane_floats, const int *level_hw,
+                          int nlevels, int B, const float *bias24, float *probs, float *deltas, int num_anchors_total,
+                          srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(parts && nparts && plane_floats && level_hw && bias24 && probs && deltas && B > 0 && nlevels >= 1 && nlevels <= 5,
+                  "bad args");
+    RpnParts lv;
+    lv.n = nlevels;
+    lv.cum[0] = 0;
+    for (int l = 0; l < 5; ++l) {
+        const bool on = l < nlevels;
+        SRCNN_REQUIRE(!on || (parts[l] && nparts[l] >= 1 && level_hw[l] > 0 && plane_floats[l] >= (long long)B * level_hw[l] * 24 &&
+                              (reinterpret_cast<size_t>(parts[l]) & 15) == 0 && plane_floats[l] % 4 == 0),
+                      "null / misaligned partial planes, empty level, or planes smaller than B x hw x 24 floats");
+        lv.part[l] = on ? parts[l] : nullptr;
+        lv.nparts[l] = on ? nparts[l] : 0;
+        lv.plane[l] = on ? plane_floats[l] : 0;
+        lv.cum[l + 1] = lv.cum[l] + (on ? level_hw[l] : 0);
+    }
+    SRCNN_REQUIRE(3 * lv.cum[nlevels] == num_anchors_total, "num_anchors_total must be 3 x the locations of all levels");
+    const int total = B * lv.cum[nlevels];
+    SRCNN_LAUNCH(rpn_score_parts_kernel, dim3(std::min(cdiv(total, 128), 4096)), dim3(128), 0, as_stream(stream), lv, B, bias24, probs,
+                       deltas, num_anchors_total);
+    return check_launch("srcnn_rpn_score_parts");
 }
 
 size_t srcnn_proposal_workspace_bytes(int B, int num_anchors, int pre_nms, int post_nms)

@@ -97,6 +97,24 @@ def prep_linear_stack(ws, bs, device='cuda'):
     return ConvW(w.view(w.shape[0], 1, 1, w.shape[1]).to(device), b.to(device), 1, 1, 1, 0, False)
 
 
+def head_fragments(hcw):
+    """The weights of a narrow 1x1 head (ConvW (N2, 1, 1, C)) for the MFMA-form fused head (srcnn_conv_desc.head_wf): split into
+    hi / lo f16 like any weight of the f16x3 engine, rows zero-padded to a multiple of 8, and laid out in the order the kernel's
+    lanes read them: [C / 16 steps][hi, lo][k group 0, 1][rows][8 halves], element (s, g, n, i) = W[n][16 s + 8 g + i].
+    Returns (tensor, rows); cached on the ConvW."""
+    if getattr(hcw, '_frag', None) is None:
+        assert hcw.kh == 1 and hcw.kw == 1 and hcw.cin % 16 == 0 and hcw.cout <= 24
+        hcw.split_f16x3()
+        n2, C = hcw.cout, hcw.cin
+        rows = -(-n2 // 8) * 8
+        f = torch.zeros((2, rows, C), dtype=torch.float16, device=hcw.w_hi.device)
+        f[0, :n2] = hcw.w_hi.view(n2, C)
+        f[1, :n2] = hcw.w_lo.view(n2, C)
+        f = f.view(2, rows, C // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()        # (step, hi/lo, k group, row, 8)
+        hcw._frag = (f, rows)
+    return hcw._frag
+
+
 def conv_out_hw(h, w, k_h, k_w, stride, pad):
     return (h + 2 * pad - k_h) // stride + 1, (w + 2 * pad - k_w) // stride + 1
 
@@ -168,8 +186,12 @@ LIMIT_TUNE_ROIS = 64          # row-limited launches (the lazy keypoint head) ar
 RPN_PAIR_LAUNCH = _os.environ.get('SRCNN_RPN_PAIR', '1') != '0'     # A/B switch of the one-launch stereo RPN conv (conv mode 2)
 # A/B switch: the projection shortcut of a layer's first block computed inside that block's conv3 (prep_conv_shortcut)
 SHORTCUT_FUSION = _os.environ.get('SRCNN_SHORTCUT_FUSION', '1') != '0'
-# A/B switch: the keypoint branch's 6-channel classifier computed inside the epilogue of the deconvolution (conv2d(head=...))
-KPTS_HEAD_FUSION = _os.environ.get('SRCNN_KPTS_HEAD_FUSION', '1') != '0'
+# A/B switches: the keypoint branch's 6-channel classifier computed inside the epilogue of the deconvolution -- '1' / 'mfma' = as a
+# second GEMM on the matrix pipe (conv2d(head2=...), srcnn_conv_desc.head_wf), 'valu' = round 4's fp32-FMA form (conv2d(head=...)),
+# '0' = two launches; and the stereo RPN's 24-channel head computed inside the RPN conv's epilogue as per-(eye, N tile) partial sums
+KPTS_HEAD_FUSION = _os.environ.get('SRCNN_KPTS_HEAD_FUSION', '1')
+KPTS_HEAD_FUSION = {'0': False, '1': 'mfma'}.get(KPTS_HEAD_FUSION, KPTS_HEAD_FUSION)
+RPN_HEAD_FUSION = _os.environ.get('SRCNN_RPN_HEAD_FUSION', '1') != '0'
 
 
 # ---- what the tuner minimises.  'isolated': the latency of the launch alone on the chip (the right objective for one pair at a
@@ -246,8 +268,9 @@ def _set_plan(d, plan):
     d.tile_mr, d.tile_nr, d.tile_waves, d.tile_stages, d.splits = plan
 
 
-def _tune(d, key, device):
-    """Times each candidate plan with HIP events on the current stream: three interleaved passes, then a play-off."""
+def _tune(d, key, device, only=None):
+    """Times each candidate plan with HIP events on the current stream: three interleaved passes, then a play-off.
+    only: the (mr, nr, waves, stages) tiles to choose from, unsplit (launches with an MFMA-form fused head)."""
     L = _lib.lib()
     M = d.B * d.OH * d.OW
     nkt = (d.KH * d.KW * d.Cin + d.Cin2) // 32
@@ -255,18 +278,22 @@ def _tune(d, key, device):
     tiles = list(_CANDIDATES)
     if d.precision == 1 and d.x_format == 1:
         tiles = _CANDIDATES_F16S + tiles
+    if only is not None:
+        tiles = [t for t in only if not (t[0] >= 4 and M < 256 * 4)]or list(only)[-1:]
     for mr, nr, waves, stages in tiles:
         if plan_lds_kb(mr, nr, waves, stages) > MAX_LDS_KB:
             continue
-        if nr == 2 and d.Cout <= 64:
+        if nr == 2 and d.Cout <= 64 and only is None:
             continue
-        if nr == 4 and (d.Cout <= 128 or M < 256 * 64 or d.x2):   # the 256x256 tile: only where it still fills the chip (and no
-            continue                                              # second input: register budget)
-        if mr >= 2 and M <= 64 * (mr // 2):
+        # the 256x256 tile: not with a second input (register budget); few fat workgroups lose the latency contest of this tuner on the
+        # small-M layers but can win the several-in-flight step (tune.tune_throughput takes its candidates from this log)
+        if nr == 4 and only is None and (d.Cout <= 128 or M < 256 * 8 or d.x2):
+            continue
+        if mr >= 2 and M <= 64 * (mr // 2) and only is None:
             continue
         blocks = -(-M // (64 * mr)) * -(-d.Cout // (64 * nr))
         splits = [1]
-        if d.mode != 1 and not d.x2:
+        if d.mode != 1 and not d.x2 and only is None:
             for s in (2, 3, 4, 6, 8, 12, 16):
                 if blocks * s <= 4096 and nkt // s >= 4 and blocks < 1024:
                     splits.append(s)
@@ -358,7 +385,7 @@ def _tune_candidates(d, key, device, cands, log, L, st):
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
            res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None,
-           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None, head=None):
+           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None, head=None, head2=None):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
     *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h).
     in_shift / out_shift (f16x3 engine): the input tensor holds its values x 2^in_shift, the output (and the residual, which
@@ -368,7 +395,11 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     m_limit (device int32 tensor) / m_limit_mul: only rows m < m_limit[0] * m_limit_mul are needed (srcnn_conv_desc.m_limit).
     x2 / H2 / W2 (weights from prep_conv_shortcut): the second input (B, H2, W2, cin2) SPLIT16, stored with the SAME scale as x.
     head = (cw_head, y_head) (f16x3 SPLIT16 engine): a 6-channel 1x1 conv applied to the activated output pixels inside this
-    launch's epilogue (srcnn_conv_desc.head_w); y_head (pixels, 6) float32 receives it, y is not written (may be None)."""
+    launch's epilogue (srcnn_conv_desc.head_w); y_head (pixels, 6) float32 receives it, y is not written (may be None).
+    head2 = (cw_head, y_head, parts) (f16x3 SPLIT16 engine): the MFMA form of such a head (srcnn_conv_desc.head_wf), up to 24
+    channels.  parts = 0: final (256-channel pixels; bias added; y_head (pixels, n) float32); parts > 0: y_head (parts, pixels, n)
+    float32 receives one plane of partial sums per (eye, N tile) of the launch -- the caller adds them and the bias.
+    Returns the plan the launch ran with: (tile_mr, tile_nr, waves, stages, splits)."""
     L = _lib.lib()
     d = _lib.ConvDesc()
     d.x = x.data_ptr() + 4 * x_offset_elems
@@ -394,6 +425,16 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         assert hy.dtype == torch.float32 and hy.is_contiguous()
         d.head_w, d.head_bias, d.head_y = hcw.weight.data_ptr(), hcw.bias.data_ptr(), hy.data_ptr()
         d.head_cout, d.head_scale = 6, 2.0 ** -out_shift
+        y_fmt = _lib.FMT_F32
+    if head2 is not None:
+        hcw, hy, parts = head2
+        assert head is None and precision == 'f16x3' and x_fmt == _lib.FMT_SPLIT16 and hcw.kh == 1 and hcw.kw == 1
+        assert hy.dtype == torch.float32 and hy.is_contiguous()
+        frag, rows = head_fragments(hcw)
+        d.head_wf, d.head_rows, d.head_cout, d.head_parts = frag.data_ptr(), rows, hcw.cout, int(parts)
+        d.head_plane = hy.numel() // parts if parts else 0
+        d.head_bias = hcw.bias.data_ptr() if (hcw.bias is not None and not parts) else None
+        d.head_y, d.head_scale = hy.data_ptr(), hcw.inv_scale * 2.0 ** -out_shift
         y_fmt = _lib.FMT_F32
     d.B, d.H, d.W, d.Cin = B, H, W, cw.cin
     d.x_cstride = cw.cin if x_cstride is None else x_cstride
@@ -421,6 +462,30 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         if FlopCounter.rows is not None:
             FlopCounter.rows.append({'name': name or 'conv %dx%d %d->%d' % (cw.kh, cw.kw, cw.cin, cw.cout), 'M': B * OH * OW,
                                      'N': cw.cout, 'K': cw.alg_k, 'flops': 2.0 * B * OH * OW * cw.cout * cw.alg_k, 'bytes': nbytes})
+    if head2 is not None and FlopCounter.enabled:
+        # the head's own flops; its output (final: hn floats per pixel; partial: one plane per 256 conv channels) instead of y
+        hn, taps = head2[0].cout, (4 if cw.mode == 1 else 1)
+        fl = 2.0 * B * OH * OW * hn * cw.cout                       # (mode 1: 4 taps x Cout / 4 channels each)
+        out_b = 4.0 * B * OH * OW * (taps * hn * (max(1, cw.cout // 256) if head2[2] else 1) - cw.cout)
+        FlopCounter.flops += fl
+        FlopCounter.bytes += out_b
+        if FlopCounter.rows is not None:
+            FlopCounter.rows[-1]['flops'] += fl
+            FlopCounter.rows[-1]['bytes'] = nbytes + out_b
+    if head2 is not None and plan is None and AUTOTUNE:
+        # final form: the 256x256 tile owns the pixel's channels -- nothing to tune; partial form: that or the 128x128 8-wave tile
+        if not head2[2]:
+            plan = (4, 4, 8, 2, 1)
+        else:
+            key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt) + ('head2', d.head_rows) + tune_mode_key())
+            plan = _TUNED.get(key)
+            if KEY_HITS is not None:
+                KEY_HITS[key] = KEY_HITS.get(key, 0) + 1
+            if plan is None:
+                if torch.cuda.is_current_stream_capturing() or _lib.lib().srcnn_program_recording():
+                    plan = (4, 4, 8, 2, 1) if B * OH * OW >= 2048 else (2, 2, 8, 2, 1)
+                else:
+                    plan = _tune(d, key, x.device, only=[(4, 4, 8, 2), (2, 2, 8, 2)])
     if head is not None:                   # the fused head lives in the 256x256 tile
         _set_plan(d, (4, 4, 8, 2, 1))
         if FlopCounter.enabled:            # the head's own (VALU) flops and its output instead of y
@@ -457,11 +522,13 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     need = L.srcnn_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _lib.workspace(need, x.device, "conv")
     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d")
+    used = (d.tile_mr, d.tile_nr, d.tile_waves, d.tile_stages, d.splits)
     if REPEAT and name:
         for rx, n in REPEAT:
             if rx.match(name):
                 for _ in range(n):
                     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d(repeat)")
+    return used
 
 
 def preprocess_size(H, W, target_short=600):

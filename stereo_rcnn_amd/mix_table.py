@@ -32,8 +32,8 @@ GROUPS = [          # (label, regex over the conv launch names of plan.py)
     ('layer4', r'layer4\.'),
     ('fpn.laterals+top', r'fpn\.(lateral|toplayer)'),
     ('fpn.smooth', r'fpn\.smooth'),
-    ('rpn_conv.P2', r'rpn_conv\.P2$'),
-    ('rpn_conv.P3-P6', r'rpn_conv\.P[3-6]$'),
+    ('rpn_conv.P2', r'rpn_conv(\+head)?\.P2$'),
+    ('rpn_conv.P3-P6', r'rpn_conv(\+head)?\.P[3-6]$'),
     ('rpn_head', r'rpn_head\.'),
     ('box head', r'box\.'),
     ('kpts.0-10', r'kpts\.\d+$'),

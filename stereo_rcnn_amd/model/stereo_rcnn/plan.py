@@ -140,6 +140,10 @@ class Plan(object):
         self.A = sum(3 * a * b for a, b in self.rpn_shapes)
         self.rpn_cat = [e(B, a, b, 1024) for a, b in self.rpn_shapes]
         self.rpn_hd = [e(B, a, b, 24) for a, b in self.rpn_shapes]
+        # fused RPN head (SPLIT16 engine): per level up to 8 planes of per-(eye, N tile) partial sums, (B * h * w, 24) floats each
+        self.rpn_part = [e(8, B * a * b, 24) for a, b in self.rpn_shapes]
+        self.rpn_nparts = [0] * len(self.rpn_shapes)
+        self._rpn_fused = False
         self.probs = e(B, self.A, 2)
         self.deltas = e(B, self.A, 6)
         self.post = cfg.TEST.RPN_POST_NMS_TOP_N
@@ -213,9 +217,9 @@ class Plan(object):
         """engine.conv2d with the scale bookkeeping: the input tensor belongs to `in_group`, the output (and the residual) to
         `out_group` (None = an unscaled tensor: the image, the F32 results that leave the network)."""
         ko = self._k(out_group)
-        engine.conv2d(cw, x, B, H, W, y, OH, OW, in_shift=self._k(in_group), out_shift=ko, **kw)
-        if kw.get('head') is not None:       # fused head: y itself is not written (as_f32 / calibration must not read it)
-            return
+        used = engine.conv2d(cw, x, B, H, W, y, OH, OW, in_shift=self._k(in_group), out_shift=ko, **kw)
+        if kw.get('head') is not None or kw.get('head2') is not None:   # fused head: y itself is not written (as_f32 / calibration must not read it)
+            return used
         self._buf_shift[y.data_ptr()] = ko
         if self._calib is not None and out_group is not None:
             ycs = kw.get('y_cstride')
@@ -224,6 +228,7 @@ class Plan(object):
             else:                          # a channel slice of a wider buffer: only what this launch wrote
                 c0 = kw.get('y_coffset', 0)
                 self._note(out_group, y.view(-1, ycs)[:, c0:c0 + cw.cout * (2 if cw.mode == 2 else 1)])
+        return used
 
     def _note(self, group, t):
         self._calib[group] = max(self._calib.get(group, 0.0), float(t.abs().max()))
@@ -357,6 +362,14 @@ class Plan(object):
         feats = [self.p2, self.p3, self.p4, self.p5, self.p6]
         h, w_ = self.rpn_shapes[l]
         cat, hd = self.rpn_cat[l], self.rpn_hd[l]
+        if self._rpn_fused:
+            # RPN_Conv on both eyes AND the 24-channel head (RPN_cls_score | RPN_bbox_pred_left_right over [left 512 | right 512],
+            # stereo_rpn.py:77-91) in one launch: the head runs in the conv's epilogue as a second GEMM on each tile and leaves
+            # partial sums per (eye, N tile); the (B, h, w, 1024) tensor is neither written nor read, five head launches are gone
+            used = self._conv(w.rpn_conv_pair, feats[l], 2 * B, h, w_, None, h, w_, 'P', 'rpn', x_fmt=f, name='rpn_conv+head.P%d' % (l + 2),
+                              head2=(w.rpn_head, self.rpn_part[l], 8))
+            self.rpn_nparts[l] = 2 * (w.rpn_conv_pair.cout // (64 * used[1]))
+            return
         if f and engine.RPN_PAIR_LAUNCH:       # SPLIT16 engine: both eyes in one launch (conv mode 2: the right half lands 512 channels further)
             self._conv(w.rpn_conv_pair, feats[l], 2 * B, h, w_, cat, h, w_, 'P', 'rpn', y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f,
                        name='rpn_conv.P%d' % (l + 2))
@@ -371,8 +384,15 @@ class Plan(object):
         """Pair softmax + NHWC flatten of every level's head output into probs / deltas (stereo_rpn.py:81-91): one launch for all
         five levels, after the last of them (on whatever stream it ran) has been joined."""
         nl = len(self.rpn_shapes)
-        heads = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.rpn_hd])
         hw = (ctypes.c_int * nl)(*[a * b for a, b in self.rpn_shapes])
+        if self._rpn_fused:
+            parts = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.rpn_part])
+            npl = (ctypes.c_int * nl)(*self.rpn_nparts)
+            planes = (ctypes.c_longlong * nl)(*[t.numel() // 8 for t in self.rpn_part])
+            _lib.check(_lib.lib().srcnn_rpn_score_parts(parts, npl, planes, hw, nl, self.B, self.w.rpn_head.bias.data_ptr(), self.probs.data_ptr(),
+                                                        self.deltas.data_ptr(), self.A, _lib.stream()), "srcnn_rpn_score_parts")
+            return
+        heads = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.rpn_hd])
         _lib.check(_lib.lib().srcnn_rpn_score_levels(heads, hw, nl, self.B, 24, self.probs.data_ptr(), self.deltas.data_ptr(), self.A,
                                                      _lib.stream()), "srcnn_rpn_score_levels")
 
@@ -383,6 +403,7 @@ class Plan(object):
         w, N, f = self.w, self.N, self.fmt
         (h2, w2), (h3, w3), (h4, w4), (h5, w5) = self.layer_hw
         c2, c3, c4, c5 = self.c
+        self._rpn_fused = bool(f and engine.RPN_HEAD_FUSION and engine.RPN_PAIR_LAUNCH)
         par = self._par()
         s_lat, s_rpn = self.side if par else (None, None)
         lat_done = []
@@ -440,6 +461,7 @@ class Plan(object):
 
     def rpn(self):
         """(kept for stage timing tools) the RPN head alone, serial."""
+        self._rpn_fused = bool(self.fmt and engine.RPN_HEAD_FUSION and engine.RPN_PAIR_LAUNCH)
         for l in range(5):
             self._rpn_level(l)
         self._rpn_scores()
@@ -497,7 +519,11 @@ class Plan(object):
             self._conv(cw, x, R, s, s, y, s, s, g, 'k%d' % i, x_fmt=f, y_fmt=f, name='kpts.%d' % (2 * i), **lim(s * s))
             x, g = y, 'k%d' % i
         G = cfg.KPTS_GRID
-        if f and engine.KPTS_HEAD_FUSION and w.kpts_class.cout == 6 and w.kpts_up.cout == 4 * 256:
+        if f and engine.KPTS_HEAD_FUSION == 'mfma' and w.kpts_class.cout <= 24 and w.kpts_up.cout == 4 * 256:
+            # ... the classifier as a second GEMM on the deconvolution's 256x256 tile (MFMA form, srcnn_conv_desc.head_wf)
+            self._conv(w.kpts_up, x, R, s, s, None, s, s, g, 'kup', x_fmt=f, name='kpts.deconv+class',
+                       head2=(w.kpts_class, self.kp_logits, 0), **lim(s * s))
+        elif f and engine.KPTS_HEAD_FUSION and w.kpts_class.cout == 6 and w.kpts_up.cout == 4 * 256:
             # SPLIT16 engine: ConvTranspose2d + ReLU + the 6-channel classifier (resnet.py:258-262) in ONE launch -- the classifier
             # runs in the deconvolution's epilogue on the pixels a workgroup has just activated; the (R, 28, 28, 256) upsampled
             # tensor is neither written nor read back (srcnn_conv_desc.head_w)

@@ -108,7 +108,16 @@ def tune_throughput(model, im_l, im_r, im_info, streams=3, top_shapes=40, cands_
         for key in order:
             logd = dict(engine._TUNE_LOG[key])
             cur = engine._TUNED[key]
-            cands = [pl for pl in sorted(logd, key=logd.get) if pl != cur][:cands_per_shape]
+            by_time = [pl for pl in sorted(logd, key=logd.get) if pl != cur]
+            # ... plus the FAT unsplit tiles (256 rows) whatever their isolated rank: few long-lived workgroups lose the latency
+            # contest on the small-M layers and can still win the mix (profiles/fat_tiles_r05.txt: layer3 conv1 / conv2 on the
+            # 256x128 tile + conv3 on 256x256: -2.5 % step time at four in flight)
+            fat = [pl for pl in by_time if pl[0] >= 4 and pl[4] == 1]
+            # ... and the LEAN 8-wave tiles (2-stage ring, 64 KB of LDS): they leave room on the CU for a workgroup of another
+            # forward's launch, which the deeper rings that win alone do not
+            lean = [pl for pl in by_time if pl[2] == 8 and pl[3] == 2 and pl[4] == 1 and pl[0] < 4]
+            cands = by_time[:cands_per_shape]
+            cands += [pl for pl in fat + lean if pl not in cands]
             for pl in cands:
                 engine.set_plan(key, pl)
                 t = run.measure(steps)

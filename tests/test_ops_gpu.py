@@ -709,3 +709,93 @@ def test_proposal_selection_batched_and_repeated(dev):
         for b in range(3):
             assert int(layer.last_num_valid[b]) == min(150, len(extra['keep'][b]))
         assert float((rl.cpu() - rl_ref).abs().max()) < 2e-3 and float((rr.cpu() - rr_ref).abs().max()) < 2e-3
+
+
+def _split16(x_nhwc):
+    from stereo_rcnn_amd import _lib, engine
+    return engine.act_convert(x_nhwc.contiguous(), _lib.FMT_F32, _lib.FMT_SPLIT16)
+
+
+@pytest.mark.parametrize("mode,n2", [(0, 6), (0, 20), (1, 6)])
+def test_fused_head_mfma_form_final_equals_two_launches(dev, mode, n2):
+    """srcnn_conv_desc.head_wf, final form: a 1x1 conv (or 2x2 / 2 deconvolution) to 256-channel pixels + bias + ReLU with an
+    n2-channel 1x1 head applied in its epilogue on the matrix pipe, against the two launches it replaces (activations stored as
+    SPLIT16, head conv on them): same 3-term split of the same hi / lo halves, only the summation order differs.  Ragged M
+    (rows beyond it in the last tile), B = 3."""
+    from stereo_rcnn_amd import _lib, engine
+    g = torch.Generator().manual_seed(100 * mode + n2)
+    B, H, W, cin = 3, 9, 13, 64                                   # M = 351: one full 256-row tile + a ragged one
+    x = torch.randn(B, H, W, cin, generator=g).to(dev)
+    xs = _split16(x)
+    if mode == 0:
+        cw = engine.prep_conv(torch.randn(256, cin, 1, 1, generator=g) * 0.2, torch.randn(256, generator=g) * 0.1, 1, 0, True, device=dev)
+        OH, OW, opix = H, W, B * H * W
+    else:
+        cw = engine.prep_deconv2x2(torch.randn(cin, 256, 2, 2, generator=g) * 0.2, torch.randn(256, generator=g) * 0.1, True, device=dev)
+        OH, OW, opix = H, W, B * 2 * H * 2 * W
+    hcw = engine.prep_conv(torch.randn(n2, 256, 1, 1, generator=g) * 0.1, torch.randn(n2, generator=g) * 0.1, 1, 0, False, device=dev)
+    mid = torch.zeros(opix, 256, device=dev)
+    engine.conv2d(cw, xs, B, H, W, mid, OH, OW, precision='f16x3', x_fmt=1, y_fmt=1, plan=(4, 4, 8, 2, 1))
+    two = torch.zeros(opix, n2, device=dev)
+    side = (2 * H, 2 * W) if mode == 1 else (H, W)
+    engine.conv2d(hcw, mid, B, side[0], side[1], two, side[0], side[1], precision='f16x3', x_fmt=1, y_fmt=0, plan=(1, 1, 4, 2, 1))
+    one = torch.full((opix, n2), float('nan'), device=dev)
+    used = engine.conv2d(cw, xs, B, H, W, None, OH, OW, precision='f16x3', x_fmt=1, head2=(hcw, one, 0))
+    torch.cuda.synchronize()
+    assert used[:4] == (4, 4, 8, 2)
+    assert torch.isfinite(one).all()
+    scale = float(two.abs().max())
+    err = float((one - two).abs().max())
+    print('fused head (mode %d, %d channels) vs two launches: %.2e of %.2e' % (mode, n2, err, scale))
+    assert err < 3e-6 * max(scale, 1.0)
+    again = torch.zeros_like(one)
+    engine.conv2d(cw, xs, B, H, W, None, OH, OW, precision='f16x3', x_fmt=1, head2=(hcw, again, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(one, again)                                 # fixed summation order
+
+
+@pytest.mark.parametrize("plan", [(4, 4, 8, 2, 1), (2, 2, 8, 2, 1)])
+@pytest.mark.parametrize("B,H,W", [(1, 19, 63), (2, 10, 32), (1, 3, 8)])
+def test_fused_rpn_head_partial_form_equals_two_launches(dev, plan, B, H, W):
+    """srcnn_conv_desc.head_wf, partial form under conv mode 2: RPN_Conv on [left images | right images] with the 24-channel stereo
+    head (over [left 512 | right 512]) applied per tile; every (eye, N tile) leaves a plane of partial sums that
+    srcnn_rpn_score_parts adds (+ bias) before the pair softmax.  Against: the pair launch writing the (B, h, w, 1024) tensor, the
+    head as its own launch, srcnn_rpn_score_levels.  Both tile forms; B * h * w is never a multiple of the tile height, so a tile
+    straddles the two eyes (its rows meet different halves of the head's weights)."""
+    import ctypes
+    from stereo_rcnn_amd import _lib, engine
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(2 * B, H, W, 256, generator=g).to(dev)          # [left images | right images]
+    xs = _split16(x)
+    wt, bs = (torch.randn(512, 256, 3, 3, generator=g) * 0.03), torch.randn(512, generator=g) * 0.1
+    cw = engine.prep_conv(wt, bs, 1, 1, True, device=dev)
+    pair = engine.ConvW(cw.weight, cw.bias, 3, 3, 1, 1, True, mode=2)
+    hcw = engine.prep_conv(torch.randn(24, 1024, 1, 1, generator=g) * 0.05, torch.randn(24, generator=g) * 0.1, 1, 0, False, device=dev)
+    cat = torch.zeros(B, H, W, 1024, device=dev)
+    engine.conv2d(pair, xs, 2 * B, H, W, cat, H, W, y_cstride=1024, y_coffset=0, precision='f16x3', x_fmt=1, y_fmt=1, plan=(2, 2, 4, 2, 1))
+    hd = torch.zeros(B, H * W, 24, device=dev)
+    engine.conv2d(hcw, cat, B, H, W, hd, H, W, precision='f16x3', x_fmt=1, y_fmt=0, plan=(1, 1, 4, 2, 1))
+    A = 3 * H * W
+    pa, da = torch.zeros(B, A, 2, device=dev), torch.zeros(B, A, 6, device=dev)
+    ptr1 = (ctypes.c_void_p * 1)(hd.data_ptr())
+    hw1 = (ctypes.c_int * 1)(H * W)
+    _lib.check(L.srcnn_rpn_score_levels(ptr1, hw1, 1, B, 24, pa.data_ptr(), da.data_ptr(), A, _lib.stream()))
+    parts = torch.full((8, B * H * W, 24), float('nan'), device=dev)
+    used = engine.conv2d(pair, xs, 2 * B, H, W, None, H, W, precision='f16x3', x_fmt=1, head2=(hcw, parts, 8), plan=plan)
+    assert used[:2] == plan[:2]
+    npl = 2 * (512 // (64 * used[1]))
+    torch.cuda.synchronize()
+    assert torch.isfinite(parts[:npl]).all() and torch.isnan(parts[npl:]).all()
+    summed = parts[:npl].sum(0) + hcw.bias.view(1, 24)
+    scale = float(hd.abs().max())
+    err = float((summed.view(B, H * W, 24) - hd).abs().max())
+    print('fused RPN head %s B=%d %dx%d: %d planes, max |d| %.2e of %.2e' % (plan[:2], B, H, W, npl, err, scale))
+    assert err < 3e-6 * max(scale, 1.0)
+    pb, db = torch.zeros(B, A, 2, device=dev), torch.zeros(B, A, 6, device=dev)
+    pp = (ctypes.c_void_p * 1)(parts.data_ptr())
+    np1 = (ctypes.c_int * 1)(npl)
+    pl1 = (ctypes.c_longlong * 1)(parts.numel() // 8)
+    _lib.check(L.srcnn_rpn_score_parts(pp, np1, pl1, hw1, 1, B, hcw.bias.data_ptr(), pb.data_ptr(), db.data_ptr(), A, _lib.stream()))
+    torch.cuda.synchronize()
+    assert float((pb - pa).abs().max()) < 1e-6 and float((db - da).abs().max()) < 3e-6 * max(scale, 1.0)
