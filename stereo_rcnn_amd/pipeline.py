@@ -239,10 +239,15 @@ def _now():
     return time.perf_counter() if TIMERS is not None else 0.0
 
 
-def step_3d(st):
-    """solver='host' handles: run the next host phase (blocks until the device work it needs has finished).  Phase 1: 4-DoF
-    solves on the pinned record, record back to the device, dense alignment launched.  Phase 2: 3-DoF solves."""
+def step_3d(st, block=True):
+    """solver='host' handles: run the next host phase.  Phase 1: 4-DoF solves on the pinned record, record back to the device,
+    dense alignment launched.  Phase 2: 3-DoF solves.  block=True waits for the device work the phase needs; block=False (the
+    streamed flow's opportunistic pass over the pairs in flight) returns at once when that work has not finished -- the host then
+    goes on launching the next pair's forward instead of sitting in front of an event, and the phase is run on a later pass or,
+    at the latest, when the pair's slot is needed (collect_3d blocks)."""
     if st.phase == 0:
+        return
+    if not block and not st.event.query():
         return
     L = _lib.lib()
     stream, iml, imr, scale, cal, im_h, im_w, thresh, dense = st.ctx
@@ -593,12 +598,13 @@ def _slot_streams(n):
     return have[:n]
 
 
-def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=3, solver='host'):
+def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=4, solver='host'):
     """Generator form for a sequence of pairs: yields one object list per frame, in order, with up to `slots` pairs in flight
     on their own HIP streams.  frames: iterable of (im_left_data, im_right_data, im_info, calib, im_shape[, scale]) with device
     tensors, or (img_left_u8, img_right_u8, calib) with uint8 device images (fused preprocessing).  Per pair the results are
     those of detect_3d (same launches).  solver='host': the Newton-CG solves of the pairs in flight run on the host between
-    the launches (one phase per pair per new frame), use slots >= 3.  solver='scipy' (needs `pool`) keeps the staged
+    the launches (a phase of every pair whose device work has finished, per new frame: never waiting), use slots >= 4 (measured:
+    profiles/config3_plans_slots_r05.txt).  solver='scipy' (needs `pool`) keeps the staged
     host/scipy arrangement."""
     prev_n = _streams.pairs_in_flight()
     try:
@@ -661,8 +667,8 @@ def _detect_3d_stream(model, frames, pool, eval_thresh, class_index, dense_align
                 out = model(l, r, info, slot=slot, kpts=not lazy, alias_outputs=True)
                 st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot, solver,
                                lazy=_plan_of(model, l, slot) if lazy else None)
-        for older, _ in inflight:                              # solver='host': one host phase of every pair already in flight
-            step_3d(older)
+        for older, _ in inflight:                              # solver='host': a host phase of every pair in flight whose device
+            step_3d(older, block=False)                        # work has finished -- never waiting for one that has not
         inflight.append((st, frame))
     while inflight:
         yield finish(inflight.popleft())

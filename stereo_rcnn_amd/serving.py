@@ -30,6 +30,8 @@ USE_SHIPPED_PLANS = os.environ.get('SRCNN_SHIPPED_PLANS', '1') != '0'
 
 # the shipped plan files and the GPU they were tuned on: (gcnArchName prefix, compute units)
 SHIPPED = {'mi355x.json': ('gfx950', 256)}
+# A/B (dev): SRCNN_SHIPPED_PLANS_FILE=<name in plans/> is read in place of mi355x.json (same gating)
+PLANS_FILE = os.environ.get('SRCNN_SHIPPED_PLANS_FILE', 'mi355x.json')
 
 _loaded = {}          # plan file -> number of plans adopted (0: looked at, not applicable)
 
@@ -60,7 +62,7 @@ def load_shipped_plans(name='mi355x.json', device=None, force=False):
     if name in _loaded and not force:
         return 0
     _loaded[name] = 0
-    p = shipped_plans_path(name)
+    p = shipped_plans_path(PLANS_FILE if name == 'mi355x.json' else name)
     if not USE_SHIPPED_PLANS or not os.path.exists(p):
         return 0
     if not device_matches(name, device):

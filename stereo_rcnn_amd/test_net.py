@@ -64,7 +64,7 @@ class _PinnedPool(object):
 
 
 def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4,
-              solver='host', slots=3, detect_stream=None, records=None, timers=None):
+              solver='host', slots=4, detect_stream=None, records=None, timers=None):
     """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds).
     `detect_stream(frames)`: replaces the detector (a generator of object lists, one per frame) -- the CPU tests drive the
     sharding / writer / gather logic with it; `records`: a list that receives one detection record per frame

@@ -44,10 +44,15 @@ class StepRunner(object):
         self.streams = _streams.main_streams(self.S) if self.S > 1 else [None]
 
     def step(self, slot):
+        """kpts=True: the headline step (keypoint branch for all 300 rois inside the forward).  kpts=False: the pipeline's default
+        form of the same step -- forward without the branch, decode + class NMS, then the branch on the kept detections only."""
         im_l, im_r, im_info = self.inputs
         out = self.model(im_l, im_r, im_info, slot=slot, kpts=self.kpts, alias_outputs=True)
         det = hpost.decode_detections(out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], im_info[0:1])
-        hpost.class_nms_device(det, 1, 0.05)
+        keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
+        if not self.kpts:
+            plan = self.model._get_plan(int(im_l.shape[0]), int(im_l.shape[2]), int(im_l.shape[3]), slot)
+            plan.kpts_for_kept(out[0][0].contiguous(), keep_idx, num, im_info[0:1].contiguous(), det['kpts'], self.model.precision)
 
     def run(self, n):
         _streams.set_pairs_in_flight(self.S)      # (the tuner itself starts from whatever plans are loaded: it does not call serving.enter)
