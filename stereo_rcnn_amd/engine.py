@@ -186,11 +186,13 @@ LIMIT_TUNE_ROIS = 64          # row-limited launches (the lazy keypoint head) ar
 RPN_PAIR_LAUNCH = _os.environ.get('SRCNN_RPN_PAIR', '1') != '0'     # A/B switch of the one-launch stereo RPN conv (conv mode 2)
 # A/B switch: the projection shortcut of a layer's first block computed inside that block's conv3 (prep_conv_shortcut)
 SHORTCUT_FUSION = _os.environ.get('SRCNN_SHORTCUT_FUSION', '1') != '0'
-# A/B switches: the keypoint branch's 6-channel classifier computed inside the epilogue of the deconvolution -- '1' / 'mfma' = as a
-# second GEMM on the matrix pipe (conv2d(head2=...), srcnn_conv_desc.head_wf), 'valu' = round 4's fp32-FMA form (conv2d(head=...)),
+# A/B switches: the keypoint branch's 6-channel classifier computed inside the epilogue of the deconvolution -- '1' / 'valu' = round
+# 4's fp32-FMA + DPP form (conv2d(head=...), srcnn_conv_desc.head_w), 'mfma' = as a second GEMM on the matrix pipe (conv2d(head2=...),
+# srcnn_conv_desc.head_wf: the form the RPN head needs; for this 6-channel head on a K = 256 launch it is 10 % slower alone --
+# 183 vs 166 us: the weight slice's load and four of eight waves computing -- and equal in the mix, profiles/kpts_head_form_r05.txt),
 # '0' = two launches; and the stereo RPN's 24-channel head computed inside the RPN conv's epilogue as per-(eye, N tile) partial sums
 KPTS_HEAD_FUSION = _os.environ.get('SRCNN_KPTS_HEAD_FUSION', '1')
-KPTS_HEAD_FUSION = {'0': False, '1': 'mfma'}.get(KPTS_HEAD_FUSION, KPTS_HEAD_FUSION)
+KPTS_HEAD_FUSION = {'0': False, '1': 'valu'}.get(KPTS_HEAD_FUSION, KPTS_HEAD_FUSION)
 RPN_HEAD_FUSION = _os.environ.get('SRCNN_RPN_HEAD_FUSION', '1') != '0'
 
 

@@ -316,8 +316,8 @@ def test_projection_shortcut_inside_conv3_equals_separate_launches(dev):
 
 
 def test_keypoint_classifier_inside_the_deconvolution_equals_separate_launches(dev):
-    """The keypoint branch with the 6-channel classifier computed in the epilogue of the ConvTranspose2d launch -- the default MFMA
-    form (engine.KPTS_HEAD_FUSION = 'mfma': a second GEMM on the tile, srcnn_conv_desc.head_wf) and round 4's fp32-FMA form
+    """The keypoint branch with the 6-channel classifier computed in the epilogue of the ConvTranspose2d launch -- the MFMA form
+    (engine.KPTS_HEAD_FUSION = 'mfma': a second GEMM on the tile, srcnn_conv_desc.head_wf) and the default fp32-FMA form
     ('valu': srcnn_conv_desc.head_w) -- against the same branch as two launches with the upsampled (R, 28, 28, 256) tensor written
     and read back: the logits agree to fp32 rounding, the probabilities to 1e-5, one conv launch goes -- also through the
     device-side row limit of the lazy form, and the default form run twice for bit-repeatability (fixed summation order)."""
