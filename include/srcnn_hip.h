@@ -41,7 +41,7 @@ typedef void *srcnn_stream_t; /* hipStream_t */
 
 #define SRCNN_API __attribute__((visibility("default")))
 
-SRCNN_API int srcnn_version(void);   /* 220 = round 5: srcnn_conv_desc.head_wf / head_rows / head_parts / head_plane appended, srcnn_rpn_score_levels / _parts, srcnn_box_head_tail, srcnn_proposal_workspace_layout; 210 = round 4: stream creation, placement probe, srcnn_conv_desc.head_* appended (older callers that zero the struct are unaffected) */
+SRCNN_API int srcnn_version(void);   /* 230 = round 5, second half: srcnn_conv_desc.up_top / up_format / up_H / up_W appended, srcnn_stem_pack_pair, srcnn_pool2x2_s1; 220 = round 5: srcnn_conv_desc.head_wf / head_rows / head_parts / head_plane appended, srcnn_rpn_score_levels / _parts, srcnn_box_head_tail, srcnn_proposal_workspace_layout; 210 = round 4: stream creation, placement probe, srcnn_conv_desc.head_* appended (older callers that zero the struct are unaffected) */
 SRCNN_API const char *srcnn_last_error(void);
 
 /* ------------------------------------------------------------------ NMS (A6)
@@ -82,6 +82,10 @@ SRCNN_API int roi_align_forward_cuda(int aligned_height, int aligned_width, floa
                            const float *features, int batch, int channels, int height, int width,
                            const float *rois, int num_rois, int roi_cols, float *output,
                            srcnn_stream_t stream);
+/* The reduction behind RoIAlignAvg / RoIAlignMax (modules/roi_align.py:26-29, 41-44: avg_pool2d / max_pool2d(kernel 2,
+ * stride 1) of the (A+1) x (A+1) lattice roi_align_forward_cuda returns): x (planes, h, w) -> y (planes, h-1, w-1).
+ * take_max 0: ((a + b) + c) + d over rows then columns, x 0.25 (ATen's order); 1: the maximum (NaN propagates). */
+SRCNN_API int srcnn_pool2x2_s1(const float *x, long long planes, int h, int w, float *y, int take_max, srcnn_stream_t stream);
 /* Fused PyramidRoI_Feat (stereo_rcnn.py:110-139) = level routing (natural log, round half away)
  * + RoIAlignAvg (modules/roi_align.py:26-29: (A+1)^2 lattice, then 2x2/s1 avg-pool), NHWC maps.
  * maps[l] is the level-(l+2) map (B, mh[l], mw[l], C) NHWC.  out is (n, A, A, out_cstride) NHWC and
@@ -183,6 +187,15 @@ typedef struct srcnn_conv_desc {
     int head_rows;
     int head_parts;
     long long head_plane;
+    /* Fused _upsample_add (SPLIT16 f16x3 engine, mode 0, no residual / head / split-K, channel counts multiples of 8; NULL = none):
+     *   y = bilinear_align_corners(up_top -> (OH, OW)) + act(conv(x) + bias)
+     * with up_top the coarser pyramid level, (B, up_H, up_W, Cout) NHWC in up_format -- the FPN lateral 1x1 conv and the
+     * top-down addition behind it (stereo_rcnn.py:91-108, 161-167) in ONE launch: the float32 lateral map is neither written nor
+     * read back.  The interpolation is srcnn_upsample_add's arithmetic operation by operation, and the conv's value is rounded to
+     * float32 exactly as the two-launch form stores it, so the result is bit-identical to srcnn_conv2d (y float32) followed by
+     * srcnn_upsample_add.  Not available on the 256x256 tile (an override asking for it falls back to the heuristic plan). */
+    const void *up_top;
+    int up_format, up_H, up_W;
 } srcnn_conv_desc;
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
@@ -220,6 +233,10 @@ SRCNN_API int srcnn_preprocess(const unsigned char *img_rgb, int H, int W, doubl
  * written -- the stem never reads it), which is what the DMA form of the f16x3 engine takes as x_format. */
 SRCNN_API int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, int out_format,
                               srcnn_stream_t stream);
+/* ... of a stereo batch in one launch: out (2B, H+6, W+8, 4) = the B left images, then the B right ones -- the batch order
+ * the shared trunk runs on (stereo_rcnn.py:155-158 feeds both eyes through the same RCNN_layer0..4). */
+SRCNN_API int srcnn_stem_pack_pair(const float *left_nchw, const float *right_nchw, int B, int H, int W, float *out,
+                                   int out_format, srcnn_stream_t stream);
 /* MaxPool2d(3, stride 2, pad 0, ceil_mode) NHWC (resnet.py:113). */
 SRCNN_API int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y, int OH, int OW,
                             int y_format, srcnn_stream_t stream);

@@ -35,7 +35,8 @@ class ConvDesc(ctypes.Structure):
                 ("m_limit", c_void_p), ("m_limit_mul", c_int),
                 ("x2", c_void_p), ("Cin2", c_int), ("H2", c_int), ("W2", c_int), ("x2_cstride", c_int), ("stride2", c_int),
                 ("head_w", c_void_p), ("head_bias", c_void_p), ("head_y", c_void_p), ("head_cout", c_int), ("head_scale", c_float),
-                ("head_wf", c_void_p), ("head_rows", c_int), ("head_parts", c_int), ("head_plane", ctypes.c_longlong)]
+                ("head_wf", c_void_p), ("head_rows", c_int), ("head_parts", c_int), ("head_plane", ctypes.c_longlong),
+                ("up_top", c_void_p), ("up_format", c_int), ("up_H", c_int), ("up_W", c_int)]
 
 
 _SIGNATURES = {
@@ -53,6 +54,7 @@ _SIGNATURES = {
     "srcnn_pyramid_roi_align": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                         c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p]),
+    "srcnn_pool2x2_s1": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_act_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p]),
     "srcnn_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_decode_kept_kpts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
@@ -64,6 +66,7 @@ _SIGNATURES = {
     "srcnn_range_flag_bind": (c_int, [c_void_p]),
     "srcnn_preprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_stem_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "srcnn_stem_pack_pair": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "srcnn_maxpool3x3s2_ceil": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "srcnn_upsample_add": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                    c_int, c_void_p]),

@@ -116,6 +116,8 @@ unsigned long long *debug_stamp_buffer();
 // ... or, while a stamp ARENA is set (core.hip), a region of this launch's own; nullptr = do not stamp
 unsigned long long *debug_stamp_region(int wgs, int tag, int lds_bytes, int threads, int M, int N, int K);
 
+int debug_skip_mask();          // core.hip: srcnn_debug_skip_mask (measurement hook of tools/skip_probe.py; 0 in production)
+
 // profiling hooks (conv engine)
 bool prof_enabled();
 void prof_begin(hipStream_t s);

@@ -47,6 +47,10 @@ struct ConvArgs {
     const void *head_wf;
     int head_rows, head_n, head_parts;
     long long head_plane;
+    // SPLIT16 engine, every tile but 256x256: the FPN top-down addition in the lateral conv's epilogue (srcnn_conv_desc.up_top):
+    // y = bilinear_align_corners(up_top (nimg, up_TH, up_TW, Cout) -> (OH, OW)) + (conv + bias); nullptr = none
+    const void *up_top;
+    int up_fmt, up_TH, up_TW;
 };
 
 

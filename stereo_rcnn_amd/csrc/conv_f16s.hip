@@ -886,6 +886,37 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
                             for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
                         }
                         if (OUT_SPLIT && nan_pre) atomicMax(p.range_flag, (unsigned)(p.tag + 1));
+                        if constexpr (MR * NR < 8) {
+                            if (p.up_top) {
+                                // FPN top-down addition (stereo_rcnn.py:91-108): the coarser level, bilinear with align_corners, added
+                                // to this lateral.  upsample_add_kernel's arithmetic (pool_resize.hip) operation by operation -- this
+                                // file is built without contraction too --, on the value the two-launch form would have stored as
+                                // float32: the sum is bit-identical to srcnn_conv2d + srcnn_upsample_add.
+                                const int TH = p.up_TH, TW = p.up_TW;
+                                const float rh = p.OH > 1 ? (float)(TH - 1) / (float)(p.OH - 1) : 0.f;
+                                const float rw = p.OW > 1 ? (float)(TW - 1) / (float)(p.OW - 1) : 0.f;
+                                const int ohw = p.OH * p.OW;
+                                const int bi = row / ohw, rem = row - bi * ohw;
+                                const int h = rem / p.OW, w = rem - h * p.OW;
+                                const float h1r = rh * (float)h;
+                                const int h1 = (int)h1r;
+                                const int h1p = (h1 < TH - 1) ? 1 : 0;
+                                const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+                                const size_t trow0 = ((size_t)bi * TH + h1) * TW, trow1 = trow0 + (size_t)h1p * TW;
+                                const float w1r = rw * (float)w;
+                                const int w1 = (int)w1r;
+                                const int w1p = (w1 < TW - 1) ? 1 : 0;
+                                const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+                                const int gg = col >> 3;
+                                const float8 ta = act_load8(p.up_top, p.up_fmt, trow0 + w1, p.Cout, gg);
+                                const float8 tb = act_load8(p.up_top, p.up_fmt, trow0 + w1 + w1p, p.Cout, gg);
+                                const float8 tc = act_load8(p.up_top, p.up_fmt, trow1 + w1, p.Cout, gg);
+                                const float8 td = act_load8(p.up_top, p.up_fmt, trow1 + w1 + w1p, p.Cout, gg);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    v.v[e] = (h0l * (w0l * ta.v[e] + w1l * tb.v[e]) + h1l * (w0l * tc.v[e] + w1l * td.v[e])) + v.v[e];
+                            }
+                        }
                         size_t opix = (size_t)row;
                         if (p.mode == 1) {                           // 2x2 stride-2 scatter: pixel (2*oh + i, 2*ow + j)
                             const int ohw = p.OH * p.OW;
@@ -1023,7 +1054,7 @@ bool conv_f16s_plan_ok(const Plan &pl, const ConvArgs &a)
     case 428: return pl.stages == 3;
     case 448: {                               // 256x256 on 8 waves of 64x128 (two waves per SIMD, 256 registers each):
         const int cq = a.mode == 1 ? (a.Cout >> 2) : a.Cout;      // vector epilogue only (see the kernel's general path)
-        return pl.stages == 2 && !a.x2 && (cq & 7) == 0 && (a.ycs & 7) == 0 && (a.yco & 7) == 0 && (!a.res || (a.rcs & 7) == 0);
+        return pl.stages == 2 && !a.x2 && !a.up_top && (cq & 7) == 0 && (a.ycs & 7) == 0 && (a.yco & 7) == 0 && (!a.res || (a.rcs & 7) == 0);
     }
     default: return false;
     }

@@ -315,8 +315,8 @@ static Plan make_plan(int M, int N, int nkt, int mode, int precision)
 static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
 {
     Plan pl = make_plan(a.M, a.Cout, a.nkt, a.mode, d->precision);
-    if (a.x2) {                    // the K walk of a second input has no mid-K entry points: never split
-        pl.splits = 1;
+    if (a.x2 || a.up_top) {        // the K walk of a second input has no mid-K entry points: never split; the fused top-down
+        pl.splits = 1;             // addition lives in the conv kernel's epilogue, not in the split-K reduction
         pl.kt_per_split = a.nkt;
     }
     if (a.head_w) {                // the fused head exists for the 256x256 tile only (a workgroup owns all 256 channels of its pixels)
@@ -342,7 +342,7 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
                          : (req.mr <= 2 && req.nr <= 2 && req.waves == 4 && req.stages == 2);
     if (!ok) return pl;            // unknown override: fall back to the heuristic plan (never an error)
     int s = d->splits >= 1 ? d->splits : 1;
-    if (a.mode == 1 || a.x2) s = 1;
+    if (a.mode == 1 || a.x2 || a.up_top) s = 1;
     s = min(s, a.nkt);
     req.kt_per_split = cdiv(a.nkt, s);
     req.splits = cdiv(a.nkt, req.kt_per_split);
@@ -420,6 +420,16 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
         else
             SRCNN_REQUIRE(d->mode != 1 && d->Cout % 256 == 0 && d->head_parts >= (d->mode == 2 ? 2 : 1) * (d->Cout / 128) && d->head_plane > 0,
                           "MFMA-form head, partial form: Cout a multiple of 256, head_parts planes for every (eye, 128-column tile)");
+    }
+    a.up_top = d->up_top;
+    a.up_fmt = d->up_format; a.up_TH = d->up_H; a.up_TW = d->up_W;
+    if (a.up_top) {
+        SRCNN_REQUIRE(d->precision == 1 && d->x_format == 1 && d->mode == 0 && !d->residual && !a.head_w && !a.head_wf && !a.m_limit,
+                      "up_top: SPLIT16 f16x3 engine, mode 0, no residual / fused head / row limit");
+        SRCNN_REQUIRE((unsigned)d->up_format <= 1 && d->up_H > 0 && d->up_W > 0 && d->up_H <= d->OH && d->up_W <= d->OW,
+                      "up_top: bad format / the top map must not be larger than the output");
+        SRCNN_REQUIRE((d->Cout & 7) == 0 && (d->y_cstride & 7) == 0 && (d->y_coffset & 7) == 0 && d->y,
+                      "up_top: channel counts / strides multiples of 8 (the addition lives in the vector epilogue)");
     }
     if (a.y_fmt == 1 || a.head_wf) {
         a.range_flag = range_flag_word();

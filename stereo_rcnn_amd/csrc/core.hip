@@ -1,5 +1,6 @@
 // Library core: error text, version, conv-engine profiling hooks.
 #include "conv_common.h"
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -138,6 +139,11 @@ unsigned long long *debug_stamp_buffer() { return g_stamp; }
 // its own (16 x u64 per workgroup), so that the launches of SEVERAL forwards in flight can be told apart after the run: the
 // per-layer residency table of the regime the headline is measured in (tools/mix_layers.py).  A replayed program writes the
 // regions its launches got at record time, every replay anew: after a run the arena holds the LAST execution of every launch.
+__global__ void null_kernel(int) {}
+
+std::atomic<int> g_debug_skip{0};       // srcnn_debug_skip_mask (measurement hook; 0 in production)
+int debug_skip_mask() { return g_debug_skip.load(std::memory_order_relaxed); }
+
 struct StampLogRow { long long off_words; int wgs, tag, lds_bytes, threads, M, N, K; };
 static unsigned long long *g_arena = nullptr;
 static size_t g_arena_words = 0, g_arena_cursor = 0;
@@ -166,6 +172,19 @@ SRCNN_API void srcnn_debug_set_stamp_buffer(void *buf) { srcnn::g_stamp = static
 // debug hooks of the stamp arena (see above): buf = device buffer of `words` u64 (zero it first), or NULL to switch off.
 // srcnn_debug_stamp_log copies up to max_rows rows of 8 x int64 {offset in words, workgroups, layer tag, LDS bytes, threads, M, N, K}
 // and returns the number of launches logged since the arena was set.
+// debug hook (tools/skip_probe.py): launches of the proposal layer left out while the mask is set -- 1: top-K selection chain,
+// 2: gather + decode, 4: pair mask, 8: greedy scan, 16: intersect + pad.  Their outputs keep the previous call's values; the
+// step-time difference is what the launch costs inside the several-forwards-in-flight mix.  0 in production.
+SRCNN_API void srcnn_debug_skip_mask(int mask) { srcnn::g_debug_skip.store(mask); }
+
+// debug hook (tools/skip_probe.py): n empty one-wave kernels on `stream` -- what does a kernel boundary (dispatch, the release at
+// its end, the acquire of the next launch) cost the OTHER forwards in flight?
+SRCNN_API int srcnn_debug_null_launches(int n, srcnn_stream_t stream)
+{
+    for (int i = 0; i < n; ++i) SRCNN_LAUNCH(srcnn::null_kernel, dim3(1), dim3(64), 0, srcnn::as_stream(stream), i);
+    return srcnn::check_launch("srcnn_debug_null_launches");
+}
+
 SRCNN_API void srcnn_debug_set_stamp_arena(void *buf, size_t words)
 {
     std::lock_guard<std::mutex> lk(srcnn::g_arena_mu);
@@ -187,7 +206,7 @@ SRCNN_API int srcnn_debug_stamp_log(long long *rows, int max_rows)
     return n;
 }
 
-int srcnn_version(void) { return 220; }   // 210: srcnn_stream_create*, srcnn_probe_placement, srcnn_conv_desc.head_* (appended fields)
+int srcnn_version(void) { return 230; }   // 210: srcnn_stream_create*, srcnn_probe_placement, srcnn_conv_desc.head_* (appended fields)
 
 int srcnn_range_flag_read(int reset)
 {

@@ -317,7 +317,9 @@ static int launch_nms(int *keep_out, const float *dets, int *num_out, const int 
     }
     SRCNN_REQUIRE((size_t)(paired ? 2 : 1) * (SCAN_RING + (size_t)n) * 4 + 128 <= 160 * 1024, "n too large for the LDS kept list");
     auto *mask = static_cast<unsigned long long *>(ws);
-    SRCNN_LAUNCH(pair_mask_kernel, dim3(cb, cb, nb), dim3(64), 0, st, dets, n, dim, thresh, mask, cb, mask + words);
+    const int skip = debug_skip_mask();
+    if (!(skip & 4)) SRCNN_LAUNCH(pair_mask_kernel, dim3(cb, cb, nb), dim3(64), 0, st, dets, n, dim, thresh, mask, cb, mask + words);
+    if (skip & 8) return check_launch("nms");
     if (paired) launch_scan<2>(mask, mask + words, nb, n, cb, n_valid, keep_out, num_out, stop_after, st);
     else launch_scan<1>(mask, mask + words, nb, n, cb, n_valid, keep_out, num_out, 0, st);
     return check_launch("nms");

@@ -10,7 +10,9 @@
 namespace srcnn {
 
 // NCHW (B,3,H,W) -> NHWC4 with a zero border: out (B, H+6, W+8, 4); pixel (y,x) -> (y+3, x+3).
-__global__ void stem_pack_kernel(const float *__restrict__ im, int B, int H, int W, float4 *__restrict__ out)
+// (im2: images b >= B1 come from there -- the right eyes of a stereo batch packed behind the left ones in ONE launch; B1 = B: none)
+__global__ void stem_pack_kernel(const float *__restrict__ im, const float *__restrict__ im2, int B1, int B, int H, int W,
+                                 float4 *__restrict__ out)
 {
     const int HP = H + 6, WP = W + 8;
     const size_t total = (size_t)B * HP * WP;
@@ -22,7 +24,7 @@ __global__ void stem_pack_kernel(const float *__restrict__ im, int B, int H, int
         const int y = yp - 3, x = xp - 3;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-            const float *p = im + (size_t)b * 3 * H * W + (size_t)y * W + x;
+            const float *p = (b < B1 ? im + (size_t)b * 3 * H * W : im2 + (size_t)(b - B1) * 3 * H * W) + (size_t)y * W + x;
             v.x = p[0];
             v.y = p[(size_t)H * W];
             v.z = p[(size_t)2 * H * W];
@@ -36,8 +38,8 @@ __global__ void stem_pack_kernel(const float *__restrict__ im, int B, int H, int
 // start of each ROW (the row pitch, (W+8)*16 B, need not be a multiple of 32 B): every 8-pixel tap run of the stride-2
 // stem starts on an even pixel, i.e. on a group boundary.  An odd last pixel of a row is never read by the stem and
 // is not written.
-__global__ void stem_pack_split16_kernel(const float *__restrict__ im, int B, int H, int W, char *__restrict__ out,
-                                        unsigned *__restrict__ range_flag)
+__global__ void stem_pack_split16_kernel(const float *__restrict__ im, const float *__restrict__ im2, int B1, int B, int H, int W,
+                                        char *__restrict__ out, unsigned *__restrict__ range_flag)
 {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const int HP = H + 6, WP = W + 8, GP = WP / 2;
@@ -56,7 +58,7 @@ __global__ void stem_pack_split16_kernel(const float *__restrict__ im, int B, in
             for (int q = 0; q < 2; ++q) {
                 const int x = 2 * gp + q - 3;
                 if ((unsigned)x < (unsigned)W) {
-                    const float *p = im + (size_t)b * 3 * H * W + (size_t)y * W + x;
+                    const float *p = (b < B1 ? im + (size_t)b * 3 * H * W : im2 + (size_t)(b - B1) * 3 * H * W) + (size_t)y * W + x;
                     v[4 * q + 0] = p[0];
                     v[4 * q + 1] = p[(size_t)H * W];
                     v[4 * q + 2] = p[(size_t)2 * H * W];
@@ -308,21 +310,37 @@ static inline int grid_for(size_t total, int threads) { return (int)std::min<siz
 
 extern "C" {
 
+static int stem_pack_launch(const float *im, const float *im2, int B1, int B, int H, int W, float *out, int out_format,
+                            srcnn_stream_t stream, const char *what)
+{
+    using namespace srcnn;
+    if (out_format == 1) {
+        const size_t groups = (size_t)B * (H + 6) * ((W + 8) / 2);
+        SRCNN_LAUNCH(stem_pack_split16_kernel, dim3(grid_for(groups, 256)), dim3(256), 0, as_stream(stream), im, im2, B1, B,
+                           H, W, reinterpret_cast<char *>(out), range_flag_word());
+        return check_launch(what);
+    }
+    const size_t total = (size_t)B * (H + 6) * (W + 8);
+    SRCNN_LAUNCH(stem_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), im, im2, B1, B, H, W,
+                       reinterpret_cast<float4 *>(out));
+    return check_launch(what);
+}
+
 int srcnn_stem_pack(const float *im_nchw, int B, int H, int W, float *out, int out_format, srcnn_stream_t stream)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(im_nchw && out && B > 0 && H > 0 && W > 0, "bad args");
     SRCNN_REQUIRE((unsigned)out_format <= 1, "bad format");
-    if (out_format == 1) {
-        const size_t groups = (size_t)B * (H + 6) * ((W + 8) / 2);
-        SRCNN_LAUNCH(stem_pack_split16_kernel, dim3(grid_for(groups, 256)), dim3(256), 0, as_stream(stream), im_nchw, B,
-                           H, W, reinterpret_cast<char *>(out), range_flag_word());
-        return check_launch("srcnn_stem_pack");
-    }
-    const size_t total = (size_t)B * (H + 6) * (W + 8);
-    SRCNN_LAUNCH(stem_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), im_nchw, B, H, W,
-                       reinterpret_cast<float4 *>(out));
-    return check_launch("srcnn_stem_pack");
+    return stem_pack_launch(im_nchw, im_nchw, B, B, H, W, out, out_format, stream, "srcnn_stem_pack");
+}
+
+int srcnn_stem_pack_pair(const float *left_nchw, const float *right_nchw, int B, int H, int W, float *out, int out_format,
+                         srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(left_nchw && right_nchw && out && B > 0 && H > 0 && W > 0, "bad args");
+    SRCNN_REQUIRE((unsigned)out_format <= 1, "bad format");
+    return stem_pack_launch(left_nchw, right_nchw, B, 2 * B, H, W, out, out_format, stream, "srcnn_stem_pack_pair");
 }
 
 int srcnn_maxpool3x3s2_ceil(const float *x, int B, int H, int W, int C, float *y, int OH, int OW, int y_format,

@@ -205,7 +205,47 @@ __global__ void pyramid_roi_align8_kernel(PyramidArgs pa, int channels, const fl
 
 }  // namespace srcnn
 
+// avg_pool2d / max_pool2d (kernel 2, stride 1) over the (planes, h, w) lattice of the legacy op: the reduction behind
+// RoIAlignAvg / RoIAlignMax (modules/roi_align.py:26-29, 41-44).  Sum order of ATen's avg_pool2d (rows, then columns), x 0.25.
+__global__ void pool2x2_s1_kernel(const float *__restrict__ x, size_t planes, int h, int w, float *__restrict__ y, int take_max)
+{
+    const int oh = h - 1, ow = w - 1;
+    const size_t total = planes * oh * ow;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int px = (int)(idx % ow);
+        const int py = (int)((idx / ow) % oh);
+        const size_t pl = idx / ((size_t)ow * oh);
+        const float *q = x + (pl * h + py) * w + px;
+        const float a = q[0], b = q[1], c = q[w], d = q[w + 1];
+        if (take_max) {
+            // max_pool2d propagates NaN; fmaxf would drop it
+            float m = a;
+            m = (b > m || b != b) ? b : m;
+            m = (c > m || c != c) ? c : m;
+            m = (d > m || d != d) ? d : m;
+            y[idx] = m;
+        } else {
+            float s = a;
+            s = s + b;
+            s = s + c;
+            s = s + d;
+            y[idx] = s * 0.25f;
+        }
+    }
+}
+
 extern "C" {
+
+int srcnn_pool2x2_s1(const float *x, long long planes, int h, int w, float *y, int take_max, srcnn_stream_t stream)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(x && y && planes >= 0 && h >= 2 && w >= 2, "bad args (the lattice must be at least 2 x 2)");
+    const size_t total = (size_t)planes * (h - 1) * (w - 1);
+    if (total == 0) return SRCNN_OK;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    SRCNN_LAUNCH(pool2x2_s1_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, (size_t)planes, h, w, y, take_max);
+    return check_launch("srcnn_pool2x2_s1");
+}
 
 int roi_align_forward_cuda(int aligned_height, int aligned_width, float spatial_scale, const float *features,
                            int batch, int channels, int height, int width, const float *rois, int num_rois,

@@ -162,6 +162,22 @@ struct TkState {
 __device__ void tk_pick_wave(TkState *state, unsigned *__restrict__ hist, int b, int lane, int kind, int shift, int last,
                              int first, unsigned K);
 
+// LDS histogram increment of the lanes that `take`.  The scores of a frame cluster: every pass but the first looks at ONE digit
+// prefix, and a freshly initialised RPN puts all of them into one bin of the first pass as well -- 64 lanes adding to one LDS
+// address serialise (25 us per pass on the synthetic frames of bench.py).  The lanes that agree with the first taker's bin add
+// once, together; the others use plain atomics.  The histogram is the same either way.
+__device__ __forceinline__ void tk_hist_add(unsigned *lh, bool take, unsigned bin)
+{
+    const unsigned long long todo = __ballot(take);
+    if (!todo) return;
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned lb = (unsigned)__shfl((int)bin, leader);
+    const bool same = take && bin == lb;
+    const unsigned long long sm = __ballot(same);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[lb], (unsigned)__popcll(sm));
+    if (take && !same) atomicAdd(&lh[bin], 1u);
+}
+
 // One radix pass = ONE launch: grid-wide LDS histograms of a digit, and the workgroup that finishes last (arrival counter behind a
 // device-scope fence) walks the 2048 bins with its first wave -- what used to be the separate one-wave tk_pick launch.  `first`:
 // the state's `remaining` is still the memset's zero and stands for K (the tk_set_remaining launch is gone as well).
@@ -180,23 +196,27 @@ __global__ __launch_bounds__(256) void tk_hist_kernel(const float *__restrict__ 
     const unsigned dmask = (1u << width) - 1u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A; i += gridDim.x * blockDim.x) {
         const unsigned k = score_key(sc[(size_t)i * 2]);
-        if (kind == 0) {
-            if ((k & mask_above) == st.prefix) atomicAdd(&lh[(k >> shift) & dmask], 1u);
-        } else {
-            if (k == st.T && (((unsigned)i) & mask_above) == st.iprefix) atomicAdd(&lh[((unsigned)i >> shift) & dmask], 1u);
-        }
+        if (kind == 0) tk_hist_add(lh, (k & mask_above) == st.prefix, (k >> shift) & dmask);
+        else tk_hist_add(lh, k == st.T && (((unsigned)i) & mask_above) == st.iprefix, ((unsigned)i >> shift) & dmask);
     }
     __syncthreads();
     unsigned *gh = hist + (size_t)b * TK_BINS;
+    // Merge + arrival WITHOUT a device-scope fence: __threadfence() is a release at agent scope, which on this chip writes the
+    // XCD's whole L2 back (buffer_wbl2) -- with other forwards in flight that is megabytes of THEIR dirty conv outputs, twice per
+    // workgroup, 256 workgroups, five passes: 116 us per forward in the four-in-flight mix (profiles/skip_probe_r05.txt).
+    // Everything the workgroups exchange goes through agent-scope atomics instead, which are performed at the coherence point:
+    // a wave waits until its own merges have been performed (they return a value: vmcnt(0)), then the workgroup arrives; the
+    // workgroup that arrives last reads the bins with agent-scope atomic loads.
+    unsigned sink = 0;
     for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x)
-        if (lh[i]) atomicAdd(&gh[i], lh[i]);
-    // the last workgroup to arrive picks the digit (every image of the batch has its own arrival counter)
-    __threadfence();
+        if (lh[i]) sink += __hip_atomic_fetch_add(&gh[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink) : "memory");        // (the operand keeps the returning form of the atomics alive)
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&arrivals[b], 1u) == gridDim.x - 1 ? 1 : 0;
+    // the last workgroup to arrive picks the digit (every image of the batch has its own arrival counter)
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&arrivals[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();                                   // the other workgroups' histogram atomics are visible from here on
     if (threadIdx.x < 64) tk_pick_wave(state, hist, b, threadIdx.x, kind, shift, last, first, K);
     if (threadIdx.x == 0) arrivals[b] = 0;             // ready for the next pass (next launch on this stream)
 }
@@ -210,7 +230,11 @@ __device__ void tk_pick_wave(TkState *state, unsigned *__restrict__ hist, int b,
     if (first) st.remaining = K;
     unsigned mine[32], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { mine[i] = gh[lane * 32 + i]; sum += mine[i]; gh[lane * 32 + i] = 0; }
+    for (int i = 0; i < 32; ++i) {       // agent-scope loads: the other workgroups' merges were atomics performed at the coherence point
+        mine[i] = __hip_atomic_load(&gh[lane * 32 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sum += mine[i];
+        gh[lane * 32 + i] = 0;
+    }
     // position of lane in walking order: kind 0 walks from the top bin down, kind 1 from the bottom up
     const int ord = kind == 0 ? 63 - lane : lane;
     unsigned before = 0;   // elements in lanes walked before mine
@@ -585,34 +609,37 @@ int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num
         TkState *state = reinterpret_cast<TkState *>(ws + L.state);
         unsigned *hist = reinterpret_cast<unsigned *>(ws + L.hist);
         unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + L.cand);
-        SRCNN_HIP_TRY(memset_async(ws + L.state, 0, L.cand - L.state, st));
+        const int skip = debug_skip_mask();       // measurement hook (srcnn_debug_skip_mask): 0 in production
+        if (!(skip & (1 | 128))) SRCNN_HIP_TRY(memset_async(ws + L.state, 0, L.cand - L.state, st));
         const int ksel = n;
         const int G = 256;
         static const int sshift[3] = {21, 10, 0}, swidth[3] = {11, 11, 10};
         static const unsigned smask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
         SRCNN_REQUIRE(B <= 64, "batches of more than 64 pairs not supported by the proposal layer");
         unsigned *arrivals = hist + (size_t)B * TK_BINS;
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 3 && !(skip & 1); ++p)
             SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, arrivals, 0,
                                sshift[p], swidth[p], smask[p], p == 2 ? 1 : 0, p == 0 ? 1 : 0, (unsigned)ksel);
         static const int ishift[2] = {11, 0};
         static const unsigned imask[2] = {0u, 0xFFFFF800u};
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 2 && !(skip & 1); ++p)
             SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, arrivals, 1,
                                ishift[p], 11, imask[p], p == 1 ? 1 : 0, 0, (unsigned)ksel);
-        SRCNN_LAUNCH(tk_compact_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, cand, TK_MAXK);
-        SRCNN_LAUNCH(tk_rank_kernel, dim3(cdiv(ksel, 64), B), dim3(1024), 0, st, cand, TK_MAXK, ksel, n, order);
+        if (!(skip & 32)) SRCNN_LAUNCH(tk_compact_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, cand, TK_MAXK);
+        if (!(skip & 64)) SRCNN_LAUNCH(tk_rank_kernel, dim3(cdiv(ksel, 64), B), dim3(1024), 0, st, cand, TK_MAXK, ksel, n, order);
     }
-    SRCNN_LAUNCH(gather_decode_kernel, dim3(cdiv(B * n, 256)), dim3(256), 0, st, probs, deltas, num_anchors, B,
-                       n, n, order, lt, im_info, dets);
+    if (!(debug_skip_mask() & 2))
+        SRCNN_LAUNCH(gather_decode_kernel, dim3(cdiv(B * n, 256)), dim3(256), 0, st, probs, deltas, num_anchors, B,
+                           n, n, order, lt, im_info, dets);
     int rc = check_launch("proposal: select/decode");
     if (rc != SRCNN_OK) return rc;
     // left/right problems of an image scanned in lockstep; stop once `post_nms` boxes survive in both
     rc = nms_pairs_until(keep, dets, num, nullptr, 2 * B, n, 5, nms_thresh, ws + L.nms, workspace_bytes - L.nms,
                          post_nms, st);
     if (rc != SRCNN_OK) return rc;
-    SRCNN_LAUNCH(intersect_pad_kernel, dim3(B), dim3(1024), 0, st, keep, num, dets, n, post_nms, rois_left,
-                       rois_right, num_valid);
+    if (!(debug_skip_mask() & 16))
+        SRCNN_LAUNCH(intersect_pad_kernel, dim3(B), dim3(1024), 0, st, keep, num, dets, n, post_nms, rois_left,
+                           rois_right, num_valid);
     return check_launch("proposal: intersect");
 }
 

@@ -194,6 +194,13 @@ SHORTCUT_FUSION = _os.environ.get('SRCNN_SHORTCUT_FUSION', '1') != '0'
 KPTS_HEAD_FUSION = _os.environ.get('SRCNN_KPTS_HEAD_FUSION', '1')
 KPTS_HEAD_FUSION = {'0': False, '1': 'valu'}.get(KPTS_HEAD_FUSION, KPTS_HEAD_FUSION)
 RPN_HEAD_FUSION = _os.environ.get('SRCNN_RPN_HEAD_FUSION', '1') != '0'
+# A/B switch: the FPN top-down addition (_upsample_add) computed inside the lateral 1x1 conv's epilogue (conv2d(up=...),
+# srcnn_conv_desc.up_top) whenever the lateral is launched inline behind its top map -- i.e. with several forwards in flight; a
+# lone forward keeps the laterals on a side stream, early, and the separate srcnn_upsample_add.  Bit-identical either way.
+# Built, tested, and NOT the default: three launches and 0.4 GB of traffic per pair fewer, and 0.2-0.4 % SLOWER four in flight
+# (155.5 / 155.2 against 155.8 / 155.8 pairs/s, same box, profiles/upsample_fusion_ab_r05.txt) -- the mix is not short of HBM
+# bandwidth, and the four bilinear taps lengthen the epilogue of a launch whose workgroups hold the matrix pipe's LDS.
+UPSAMPLE_FUSION = _os.environ.get('SRCNN_UPSAMPLE_FUSION', '0') != '0'
 
 
 # ---- what the tuner minimises.  'isolated': the latency of the launch alone on the chip (the right objective for one pair at a
@@ -225,6 +232,12 @@ def tune_mode_key():
 # behind itself (same arguments: the output is simply rewritten).  The step-time increase per extra launch is that layer's
 # marginal cost INSIDE the several-forwards-in-flight mix, which no per-launch timing can give.  Empty in production.
 REPEAT = []
+
+# Measurement hook (tools/skip_probe.py): names of NON-conv stages of the forward that Plan leaves out while it records / runs
+# ('maxpool', 'upsample_add', 'subsample', 'rpn_scores', 'proposals', 'roi_align', 'box_tail', 'kpts_tail') -- the buffers they would
+# have written keep the previous frame's contents, so the step still runs on valid data; the step-time difference is what the
+# stage costs INSIDE the several-forwards-in-flight mix.  Empty in production.
+DEBUG_SKIP = frozenset()
 
 # Bumped by whoever rewrites _TUNED under a model that already recorded launch programs (tune.tune_throughput, load_plans):
 # every Plan compares it in run() and re-records.  KEY_HITS: while a dict, conv2d counts the launches per plan key.
@@ -289,13 +302,13 @@ def _tune(d, key, device, only=None):
             continue
         # the 256x256 tile: not with a second input (register budget); few fat workgroups lose the latency contest of this tuner on the
         # small-M layers but can win the several-in-flight step (tune.tune_throughput takes its candidates from this log)
-        if nr == 4 and only is None and (d.Cout <= 128 or M < 256 * 8 or d.x2):
+        if nr == 4 and only is None and (d.Cout <= 128 or M < 256 * 8 or d.x2 or d.up_top):
             continue
         if mr >= 2 and M <= 64 * (mr // 2) and only is None:
             continue
         blocks = -(-M // (64 * mr)) * -(-d.Cout // (64 * nr))
         splits = [1]
-        if d.mode != 1 and not d.x2 and only is None:
+        if d.mode != 1 and not d.x2 and not d.up_top and only is None:
             for s in (2, 3, 4, 6, 8, 12, 16):
                 if blocks * s <= 4096 and nkt // s >= 4 and blocks < 1024:
                     splits.append(s)
@@ -387,7 +400,7 @@ def _tune_candidates(d, key, device, cands, log, L, st):
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
            res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None,
-           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None, head=None, head2=None):
+           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None, head=None, head2=None, up=None):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
     *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h).
     in_shift / out_shift (f16x3 engine): the input tensor holds its values x 2^in_shift, the output (and the residual, which
@@ -401,6 +414,9 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     head2 = (cw_head, y_head, parts) (f16x3 SPLIT16 engine): the MFMA form of such a head (srcnn_conv_desc.head_wf), up to 24
     channels.  parts = 0: final (256-channel pixels; bias added; y_head (pixels, n) float32); parts > 0: y_head (parts, pixels, n)
     float32 receives one plane of partial sums per (eye, N tile) of the launch -- the caller adds them and the bias.
+    up = (top, TH, TW, top_fmt) (f16x3 SPLIT16 engine): the FPN top-down addition inside this launch (srcnn_conv_desc.up_top):
+    y = bilinear_align_corners(top (B, TH, TW, cout) -> (OH, OW)) + (conv + bias), top stored with the OUTPUT's scale; bit-identical
+    to conv2d (float32 y) followed by upsample_add.
     Returns the plan the launch ran with: (tile_mr, tile_nr, waves, stages, splits)."""
     L = _lib.lib()
     d = _lib.ConvDesc()
@@ -455,11 +471,20 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         assert precision == 'f16x3' and x_fmt == _lib.FMT_SPLIT16, "the second input belongs to the SPLIT16 engine"
         d.x2, d.Cin2, d.H2, d.W2, d.stride2 = x2.data_ptr(), cw.cin2, H2, W2, cw.stride2
         d.x2_cstride = cw.cin2 if x2_cstride is None else x2_cstride
+    if up is not None:
+        top, th, tw, top_fmt = up
+        assert precision == 'f16x3' and x_fmt == _lib.FMT_SPLIT16 and residual is None and head is None and head2 is None and cw.mode == 0
+        d.up_top, d.up_format, d.up_H, d.up_W = top.data_ptr(), int(top_fmt), int(th), int(tw)
+        if plan is not None and tuple(plan) != (0, 0, 0, 0, 0):
+            # the addition lives in the conv kernel's epilogue of every tile but 256x256, never in the split-K reduction: an explicit
+            # plan is rewritten here (not silently replaced by the library's heuristic), so that the returned plan is the one that ran
+            plan = ((4, 2, 8, 3) if tuple(plan[:2]) == (4, 4) else tuple(plan[:4])) + (1,)
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
         px_in = B * OH * OW if (cw.kh == 1 and cw.kw == 1) else B * H * W
-        nbytes = 4.0 * (px_in * cw.cin + B * OH * OW * cw.cin2 + cw.cout * cw.alg_k + B * OH * OW * cw.cout * (2 if residual is not None else 1))
+        nbytes = 4.0 * (px_in * cw.cin + B * OH * OW * cw.cin2 + cw.cout * cw.alg_k + B * OH * OW * cw.cout * (2 if residual is not None else 1)
+                        + (B * up[1] * up[2] * cw.cout if up is not None else 0))
         FlopCounter.bytes += nbytes
         if FlopCounter.rows is not None:
             FlopCounter.rows.append({'name': name or 'conv %dx%d %d->%d' % (cw.kh, cw.kw, cw.cin, cw.cout), 'M': B * OH * OW,
@@ -502,7 +527,7 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
         # a launch with a device-side row limit is tuned WITH a typical limit (LIMIT_TUNE_ROIS of its units): what is fastest for
         # the whole shape (the biggest tile, one round of CUs) is not what is fastest for a fifth of it
         key = _shape_key(cw, B, H, W, OH, OW, d.x_cstride, precision, (x_fmt, y_fmt, res_fmt) + (('lim', m_limit_mul) if m_limit is not None else ())
-                         + (('x2', cw.cin2, cw.stride2, H2, W2) if x2 is not None else ()) + tune_mode_key())
+                         + (('x2', cw.cin2, cw.stride2, H2, W2) if x2 is not None else ()) + (('up',) if up is not None else ()) + tune_mode_key())
         plan = _TUNED.get(key)
         if KEY_HITS is not None:
             KEY_HITS[key] = KEY_HITS.get(key, 0) + 1
@@ -568,6 +593,14 @@ def stem_pack(im_nchw, out, batch_offset=0, out_fmt=0):
     off = batch_offset * (H + 6) * (W + 8) * 4 * 4
     _lib.check(L.srcnn_stem_pack(_lib.ptr(im_nchw), B, H, W, out.data_ptr() + off, out_fmt, _lib.stream()),
                "srcnn_stem_pack")
+
+
+def stem_pack_pair(left_nchw, right_nchw, out, out_fmt=0):
+    """Both eyes of a stereo batch in one launch: out (2B, H+6, W+8, 4) = lefts, then rights."""
+    B, C, H, W = left_nchw.shape
+    assert C == 3 and tuple(right_nchw.shape) == tuple(left_nchw.shape)
+    _lib.check(_lib.lib().srcnn_stem_pack_pair(_lib.ptr(left_nchw), _lib.ptr(right_nchw), B, H, W, out.data_ptr(), out_fmt, _lib.stream()),
+               "srcnn_stem_pack_pair")
 
 
 def maxpool3x3s2_ceil(x, B, H, W, C, y, OH, OW, y_fmt=0):

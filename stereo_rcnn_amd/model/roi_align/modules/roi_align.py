@@ -5,10 +5,20 @@ One implementation, three pooling policies: the native lattice op samples an (ah
 bilinear taps per roi; 'avg' / 'max' reduce every 2x2 neighbourhood of that grid (stride 1) back to ah x aw.  These are
 the op-level drop-ins (NCHW in, NCHW out); `_StereoRCNN.forward` itself uses the fused NHWC pyramid kernel
 (`srcnn_pyramid_roi_align`), which performs the lattice + average in one pass."""
+import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from .... import _lib
 from ..functions.roi_align import RoIAlignFunction
+
+
+def _pool2x2_s1(lattice, take_max):
+    """avg_pool2d / max_pool2d(kernel_size=2, stride=1) of the (n, C, h, w) lattice as a library launch (srcnn_pool2x2_s1)."""
+    n, c, h, w = lattice.shape
+    out = torch.empty((n, c, h - 1, w - 1), dtype=torch.float32, device=lattice.device)
+    _lib.check(_lib.lib().srcnn_pool2x2_s1(lattice.data_ptr(), n * c, h, w, out.data_ptr(), int(take_max), _lib.stream()),
+               "srcnn_pool2x2_s1")
+    return out
 
 
 class _LatticeAlign(nn.Module):
@@ -35,10 +45,10 @@ class RoIAlign(_LatticeAlign):
 class RoIAlignAvg(_LatticeAlign):
     """(A+1) x (A+1) lattice, mean of each 2x2 neighbourhood: what the Stereo R-CNN heads use."""
     extra = 1
-    reduce = staticmethod(lambda t: F.avg_pool2d(t, kernel_size=2, stride=1))
+    reduce = staticmethod(lambda t: _pool2x2_s1(t, False))
 
 
 class RoIAlignMax(_LatticeAlign):
     """(A+1) x (A+1) lattice, max of each 2x2 neighbourhood."""
     extra = 1
-    reduce = staticmethod(lambda t: F.max_pool2d(t, kernel_size=2, stride=1))
+    reduce = staticmethod(lambda t: _pool2x2_s1(t, True))

@@ -294,13 +294,13 @@ class Plan(object):
         H, W = self.H, self.W
         f = self.fmt                                  # SPLIT16 activations (f16x3 engine) or F32
         if self.packed_fmt != f:                      # set_images() / pack_inputs() already wrote the stem input in this format otherwise
-            engine.stem_pack(self._src[0], self.packed, 0, out_fmt=f)
-            engine.stem_pack(self._src[1], self.packed, self.B, out_fmt=f)
+            engine.stem_pack_pair(self._src[0], self._src[1], self.packed, out_fmt=f)
         self.packed_fmt = -1                          # consumed: the next forward packs again unless set_images() / pack_inputs() ran
         sh, sw = self.stem_hw
         self._conv(w.stem, self.packed, N, H + 6, W + 8, self.stem_out, sh, sw, None, 'stem', x_cstride=4, x_fmt=f, name='stem')   # F32 out
         ph, pw = self.c1_hw
-        engine.maxpool3x3s2_ceil(self.stem_out, N, sh, sw, 64, self.c1, ph, pw, y_fmt=f)
+        if 'maxpool' not in engine.DEBUG_SKIP:
+            engine.maxpool3x3s2_ceil(self.stem_out, N, sh, sw, 64, self.c1, ph, pw, y_fmt=f)
         self._buf_shift[self.c1.data_ptr()] = self._k('stem')
         x, xh, xw, xg = self.c1, ph, pw, 'stem'
         for li, blocks in enumerate(w.layers):
@@ -385,6 +385,8 @@ class Plan(object):
         five levels, after the last of them (on whatever stream it ran) has been joined."""
         nl = len(self.rpn_shapes)
         hw = (ctypes.c_int * nl)(*[a * b for a, b in self.rpn_shapes])
+        if 'rpn_scores' in engine.DEBUG_SKIP:
+            return
         if self._rpn_fused:
             parts = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.rpn_part])
             npl = (ctypes.c_int * nl)(*self.rpn_nparts)
@@ -416,7 +418,8 @@ class Plan(object):
                     lat_done.append(self._signal(s_lat))
         self._conv(w.toplayer, c5, N, h5, w5, self.p5, h5, w5, 'L4', 'P', x_fmt=f, y_fmt=f, name='fpn.toplayer')
         h6, w6 = self.rpn_shapes[4]
-        engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                              # stereo_rcnn.py:168
+        if 'subsample' not in engine.DEBUG_SKIP:
+            engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                          # stereo_rcnn.py:168
         self._buf_shift[self.p6.data_ptr()] = self._k('P')
         if par:
             self._fork(s_rpn)
@@ -432,9 +435,15 @@ class Plan(object):
             top, th, tw = tops[i]
             if par:
                 self._wait(torch.cuda.current_stream(), lat_done[i])
+            elif f and engine.UPSAMPLE_FUSION:
+                # lateral conv + top-down addition in one launch (srcnn_conv_desc.up_top): the float32 lateral map is neither written
+                # nor read back, three launches and 0.4 GB per pair go; bit-identical to the two-launch form below
+                self._conv(w.lateral[i], cin, N, h, w_, self.summed[i], h, w_, 'L%d' % (3 - i), 'P', x_fmt=f, y_fmt=f,
+                           up=(top, th, tw, f), name='fpn.lateral%d' % (i + 1))
             else:
                 self._conv(w.lateral[i], cin, N, h, w_, self.lat[i], h, w_, 'L%d' % (3 - i), 'P', x_fmt=f, name='fpn.lateral%d' % (i + 1))
-            engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i], top_fmt=f, y_fmt=f)   # stereo_rcnn.py:91-108
+            if (par or not (f and engine.UPSAMPLE_FUSION)) and 'upsample_add' not in engine.DEBUG_SKIP:
+                engine.upsample_add(top, th, tw, self.lat[i], N, h, w_, 256, self.summed[i], top_fmt=f, y_fmt=f)   # stereo_rcnn.py:91-108
             if self._calib is not None:
                 self._note('P', self.summed[i])
             self._conv(w.smooth[i], self.summed[i], N, h, w_, out, h, w_, 'P', 'P', x_fmt=f, y_fmt=f, name='fpn.smooth%d' % (i + 1))
@@ -467,6 +476,8 @@ class Plan(object):
         self._rpn_scores()
 
     def proposals(self):
+        if 'proposals' in engine.DEBUG_SKIP:
+            return
         L = _lib.lib()
         nl = len(self.rpn_shapes)
         hw = (ctypes.c_int * (2 * nl))(*[int(v) for s in self.rpn_shapes for v in s])
@@ -479,6 +490,8 @@ class Plan(object):
                    "srcnn_proposal_layer")
 
     def _pyramid(self, right, rois, A, out, cstride, coffset, n_rois=None, limit=None):
+        if 'roi_align' in engine.DEBUG_SKIP or ('roi_align%d' % A) in engine.DEBUG_SKIP:
+            return
         maps = [self.p2, self.p3, self.p4, self.p5]
         hw = self.rpn_shapes[:4]
         ptrs = (ctypes.c_void_p * 4)()
@@ -499,7 +512,8 @@ class Plan(object):
         self._conv(w.top0, self.sem, R, 1, 1, self.h1, 1, 1, 'P', 'h1', x_fmt=f, y_fmt=f, name='box.top0')   # 7x7/7 conv == GEMM (resnet.py:257)
         self._conv(w.top3, self.h1, R, 1, 1, self.h2, 1, 1, 'h1', 'h2', x_fmt=f, y_fmt=f, name='box.top3')
         self._conv(w.fc, self.h2, R, 1, 1, self.fc, 1, 1, 'h2', None, x_fmt=f, name='box.fc')
-        _lib.check(_lib.lib().srcnn_box_head_tail(self.fc.data_ptr(), R, w.n_bbox, w.n_dim, w.n_cls, w.fc.cout, self.bbox_pred.data_ptr(),
+        if 'box_tail' not in engine.DEBUG_SKIP:
+            _lib.check(_lib.lib().srcnn_box_head_tail(self.fc.data_ptr(), R, w.n_bbox, w.n_dim, w.n_cls, w.fc.cout, self.bbox_pred.data_ptr(),
                                                   self.dim_orien.data_ptr(), self.cls_prob.data_ptr(), _lib.stream()), "srcnn_box_head_tail")
 
     def kpts_head(self, rois=None, n_rois=None, limit=None, outs=None):
@@ -533,8 +547,9 @@ class Plan(object):
             self._conv(w.kpts_up, x, R, s, s, self.kp_up, s, s, g, 'kup', x_fmt=f, y_fmt=f, name='kpts.deconv', **lim(s * s))
             self._conv(w.kpts_class, self.kp_up, R, G, G, self.kp_logits, G, G, 'kup', None, x_fmt=f, name='kpts.class', **lim(G * G))
         kp, lp, rp = (self.kpts_prob, self.left_prob, self.right_prob) if outs is None else outs
-        _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, kp.data_ptr(), lp.data_ptr(), rp.data_ptr(),
-                                              None if limit is None else limit.data_ptr(), _lib.stream()), "srcnn_kpts_tail")
+        if 'kpts_tail' not in engine.DEBUG_SKIP:
+            _lib.check(_lib.lib().srcnn_kpts_tail(self.kp_logits.data_ptr(), R, G, kp.data_ptr(), lp.data_ptr(), rp.data_ptr(),
+                                                  None if limit is None else limit.data_ptr(), _lib.stream()), "srcnn_kpts_tail")
 
     def kpts_for_kept(self, rois_left_b, keep_idx, num, im_info_b, det_kpts, precision):
         """The keypoint head for the detections of ONE image that survived class NMS (postprocess.class_nms_device: keep_idx
@@ -619,8 +634,7 @@ class Plan(object):
     def pack_inputs(self, fmt):
         """Issue the stem-input pack of the current sources NOW (outside a recorded launch program: the program's own launch list
         then starts at the stem conv and never holds a pointer to a caller's tensor)."""
-        engine.stem_pack(self._src[0], self.packed, 0, out_fmt=fmt)
-        engine.stem_pack(self._src[1], self.packed, self.B, out_fmt=fmt)
+        engine.stem_pack_pair(self._src[0], self._src[1], self.packed, out_fmt=fmt)
         self.packed_fmt = fmt
 
     def set_images(self, img_left_u8, img_right_u8, precision='f32', target_short=600):

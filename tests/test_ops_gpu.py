@@ -101,6 +101,12 @@ def test_roi_align_avg_module(dev):
     ref = oops.roi_align_avg(feat, rois, 7, 7, 38 / 600.0)
     got = RoIAlignAvg(7, 7, 1 / 16.0)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev), 38 / 600.0)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-6)
+    # the 2x2 / stride-1 reductions are library launches (srcnn_pool2x2_s1): bit-equal to ATen's poolings of the same lattice
+    from stereo_rcnn_amd.model.roi_align.modules.roi_align import RoIAlign, RoIAlignMax
+    lattice = RoIAlign(8, 8, 1 / 16.0)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev), 38 / 600.0)
+    assert torch.equal(got.cpu(), F.avg_pool2d(lattice.cpu(), kernel_size=2, stride=1))
+    gmax = RoIAlignMax(7, 7, 1 / 16.0)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev), 38 / 600.0)
+    assert torch.equal(gmax.cpu(), F.max_pool2d(lattice.cpu(), kernel_size=2, stride=1))
 
 
 @pytest.mark.parametrize("A,pad_c", [(7, 0), (14, 0), (7, 4), (14, 4)])
@@ -799,3 +805,60 @@ def test_fused_rpn_head_partial_form_equals_two_launches(dev, plan, B, H, W):
     _lib.check(L.srcnn_rpn_score_parts(pp, np1, pl1, hw1, 1, B, hcw.bias.data_ptr(), pb.data_ptr(), db.data_ptr(), A, _lib.stream()))
     torch.cuda.synchronize()
     assert float((pb - pa).abs().max()) < 1e-6 and float((db - da).abs().max()) < 3e-6 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("plan", [(1, 1, 4, 2, 1), (2, 1, 4, 2, 1), (2, 2, 4, 2, 1), (2, 2, 8, 4, 1), (4, 2, 8, 3, 1), (4, 4, 8, 2, 1), (1, 1, 4, 4, 3),
+                                  None])
+@pytest.mark.parametrize("B,H,W,TH,TW,cin", [(2, 38, 125, 19, 63, 64), (2, 11, 17, 6, 9, 96), (1, 5, 1, 3, 1, 32), (1, 7, 9, 7, 9, 32)])
+def test_fused_upsample_add_in_the_lateral_conv_equals_two_launches(dev, plan, B, H, W, TH, TW, cin):
+    """srcnn_conv_desc.up_top (the FPN top-down addition of stereo_rcnn.py:91-108 inside the lateral 1x1 conv's epilogue) against
+    the two launches it replaces -- srcnn_conv2d into a float32 lateral map, then srcnn_upsample_add: bit-identical, on every tile
+    the kernel has it for (engine.conv2d turns a request for the 256x256 tile into 256x128 and a split-K plan into its unsplit form), odd map
+    sizes (KITTI's 38x125 from 19x63), a one-column map, and a top map of the output's own size (all weights 1 / 0)."""
+    from stereo_rcnn_amd import _lib, engine
+    g = torch.Generator().manual_seed(H * 7 + W)
+    S = _lib.FMT_SPLIT16
+    C = 256
+    w = torch.randn(C, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(C, generator=g)
+    cw = engine.prep_conv(w, b, 1, 0, False, None, dev)
+    x = engine.act_convert(torch.randn(B, H, W, cin, generator=g).to(dev), 0, S)
+    top = engine.act_convert(torch.randn(B, TH, TW, C, generator=g).to(dev), 0, S)
+    lat = torch.empty(B, H, W, C, device=dev)
+    want = torch.zeros(B, H, W, C, device=dev)
+    got = torch.zeros_like(want)
+    used = engine.conv2d(cw, x, B, H, W, got, H, W, precision='f16x3', x_fmt=S, y_fmt=S, plan=plan, up=(top, TH, TW, S))
+    assert used[4] == 1 and used[:2] != (4, 4), used
+    # the two launches on the plan the fused launch actually ran with (another tile may add the K products in another order)
+    used0 = engine.conv2d(cw, x, B, H, W, lat, H, W, precision='f16x3', x_fmt=S, y_fmt=0, plan=used)
+    engine.upsample_add(top, TH, TW, lat, B, H, W, C, want, top_fmt=S, y_fmt=S)
+    torch.cuda.synchronize()
+    assert tuple(used0) == tuple(used)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (used0, used)
+    ref = F.interpolate(engine.act_convert(top, S, 0).permute(0, 3, 1, 2), size=(H, W), mode='bilinear', align_corners=True) \
+        + lat.permute(0, 3, 1, 2)
+    assert float((engine.act_convert(got, S, 0).permute(0, 3, 1, 2) - ref).abs().max()) < 2e-5
+    # float32 top map (the exact-fp32 engine's pyramid), float32 result
+    topf = engine.act_convert(top, S, 0)
+    engine.upsample_add(topf, TH, TW, lat, B, H, W, C, want, top_fmt=0, y_fmt=0)
+    engine.conv2d(cw, x, B, H, W, got, H, W, precision='f16x3', x_fmt=S, y_fmt=0, plan=used, up=(topf, TH, TW, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("B,H,W", [(1, 37, 131), (3, 20, 50)])
+def test_stem_pack_pair_equals_one_launch_per_eye(dev, fmt, B, H, W):
+    """srcnn_stem_pack_pair (both eyes of the batch behind each other in one launch) == srcnn_stem_pack of the lefts into images
+    [0, B) and of the rights into [B, 2B), byte for byte, both formats, odd padded row length."""
+    from stereo_rcnn_amd import engine
+    g = torch.Generator().manual_seed(B + W)
+    l = torch.randn(B, 3, H, W, generator=g).to(dev)
+    r = torch.randn(B, 3, H, W, generator=g).to(dev)
+    want = torch.full((2 * B, H + 6, W + 8, 4), 7.0, device=dev)
+    got = torch.full_like(want, 7.0)
+    engine.stem_pack(l, want, 0, out_fmt=fmt)
+    engine.stem_pack(r, want, B, out_fmt=fmt)
+    engine.stem_pack_pair(l, r, got, out_fmt=fmt)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))

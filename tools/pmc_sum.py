@@ -1,7 +1,7 @@
 """Sums rocprofv3 --pmc counters per kernel family over the steady-state bench steps (dev tool).
 
     python tools/pmc_sum.py <dir with pass*/ or <COUNTER>/ sub-directories>  [skip_first_steps]  [traffic.json]
-Counts steps by stem_pack_kernel launches (2 per step); the first `skip` steps (autotuning, warm-up) are dropped.
+Counts steps by their leading stem_pack_kernel launch(es); the first `skip` steps (autotuning, warm-up) are dropped.
 """
 import collections, csv, glob, os, sys
 
@@ -12,14 +12,14 @@ steps_seen = {}
 for f in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True)):
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    step, seen = -1, set()
-    for r in rows:
+    step, last_pack = -1, -10
+    for i, r in enumerate(rows):
         name = r['Kernel_Name']
-        if 'stem_pack' in name and r['Dispatch_Id'] not in seen:
-            # two stem_pack launches per step: count pairs
-            seen.add(r['Dispatch_Id'])
-            if len(seen) % 2 == 1:
+        if 'stem_pack' in name:
+            # a step starts with its stem_pack launch (one for both eyes; two back to back before srcnn_stem_pack_pair)
+            if i - last_pack > 3:
                 step += 1
+            last_pack = i
         if step < skip:
             continue
         short = name.replace('void ', '').replace('srcnn::', '')
