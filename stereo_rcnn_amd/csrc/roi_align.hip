@@ -15,6 +15,7 @@
 // The float/double promotion pattern of the reference kernel (its `1.` literals) is
 // reproduced operation by operation; the library is built with -ffp-contract=off.
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace srcnn {
 
@@ -203,6 +204,105 @@ __global__ void pyramid_roi_align8_kernel(PyramidArgs pa, int channels, const fl
     }
 }
 
+
+// The form the forward uses since round 5: ONE workgroup per roi, thread (g, ry) = 8-channel group g of LATTICE row ry (A+1 rows).
+// Every lattice point is computed once (the row-pair form above computes each lattice row twice, for the output rows above and
+// below it: twice the tap loads and twice the double-precision blends); neighbouring rows meet through a double-buffered LDS
+// slot per lattice column, behind a barrier that leaves global loads in flight, and the taps of column px + 1 are requested
+// before column px is blended.  Same arithmetic per lattice point and the same sum order as above: bit-identical output.
+struct LatticeTaps {
+    float8 ul, ur, dl, dr;
+    float w_ratio;
+    bool ok;
+};
+
+template <int A>
+__global__ __launch_bounds__(32 * (A + 1)) void pyramid_roi_align8_roi_kernel(PyramidArgs pa, int channels, const float *__restrict__ rois,
+                                                                              float *__restrict__ out, int out_cstride, int out_coffset,
+                                                                              int mfmt, int ofmt)
+{
+    __shared__ float4 lat[2][A + 1][32][2];                     // [column parity][lattice row][group][8 floats]
+    const int n = blockIdx.x, ry = threadIdx.y, g = threadIdx.x;
+    if (pa.roi_limit && n >= *pa.roi_limit) return;             // (uniform: the whole workgroup leaves)
+    const float *r = rois + (size_t)n * 5;
+    // level routing, stereo_rcnn.py:113-119 (natural log; round half away from zero; clamp 2..5)
+    float bh = r[4] - r[2] + 1.0f;
+    float bw = r[3] - r[1] + 1.0f;
+    float lv = logf(sqrtf(bh * bw) / 224.0f) + 4.0f;
+    lv = copysignf(floorf(fabsf(lv) + 0.5f), lv);
+    lv = fminf(fmaxf(lv, 2.0f), 5.0f);
+    const int l = __builtin_amdgcn_readfirstlane((int)lv - 2);   // same roi for the whole block
+    const int height = pa.mh[l], width = pa.mw[l];
+    const RoiGeom geo = roi_geom(r, pa.scale[l], A + 1, A + 1);
+    const float *base = pa.maps[l];
+    const size_t img = (size_t)geo.batch * height * width;
+    const bool live = g * 8 < channels;                          // (channels < 256: the upper groups only keep the barriers company)
+    const float h = (float)ry * geo.bin_h + geo.start_h;
+    const bool h_ok = !(h < 0 || h >= height);
+    const int hstart = h_ok ? (int)fminf(floorf(h), (float)(height - 2)) : 0;
+    const float h_ratio = h - (float)hstart;
+    const double hr1 = 1. - (double)h_ratio;
+    auto request = [&](int px) {
+        LatticeTaps t;
+        const float w = (float)px * geo.bin_w + geo.start_w;
+        t.ok = h_ok && !(w < 0 || w >= width);                   // roi_align_kernel.cu:54-55
+        const int wstart = t.ok ? (int)fminf(floorf(w), (float)(width - 2)) : 0;
+        t.w_ratio = w - (float)wstart;
+        const size_t p0 = img + (size_t)hstart * width + wstart; // (a point outside the map reads the map's first pixels and drops them)
+        const int gl = live ? g : 0;
+        t.ul = act_load8(base, mfmt, p0, channels, gl);
+        t.ur = act_load8(base, mfmt, p0 + 1, channels, gl);
+        t.dl = act_load8(base, mfmt, p0 + width, channels, gl);
+        t.dr = act_load8(base, mfmt, p0 + width + 1, channels, gl);
+        return t;
+    };
+    auto blend = [&](const LatticeTaps &t) {                     // lattice_point8's arithmetic
+        float8 v;
+        const double wr1 = 1. - (double)t.w_ratio;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dl_h = t.dl.v[e] * h_ratio;
+            const float dr_hw = t.dr.v[e] * h_ratio * t.w_ratio;
+            const double d = (double)t.ul.v[e] * hr1 * wr1 + (double)t.ur.v[e] * hr1 * (double)t.w_ratio + (double)dl_h * wr1 + (double)dr_hw;
+            v.v[e] = t.ok ? (float)d : 0.0f;
+        }
+        return v;
+    };
+    LatticeTaps cur = request(0);
+    float8 top_prev, bot_prev;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) top_prev.v[e] = bot_prev.v[e] = 0.f;
+#pragma unroll 1
+    for (int px = 0; px <= A; ++px) {
+        LatticeTaps nxt = cur;
+        if (px < A) nxt = request(px + 1);                       // in flight across the barrier below
+        const float8 top = blend(cur);
+        float4 *slot = &lat[px & 1][ry][g][0];
+        slot[0] = make_float4(top.v[0], top.v[1], top.v[2], top.v[3]);
+        slot[1] = make_float4(top.v[4], top.v[5], top.v[6], top.v[7]);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS visibility only: the next column's taps stay in flight
+        if (ry < A) {
+            const float4 b0 = lat[px & 1][ry + 1][g][0], b1 = lat[px & 1][ry + 1][g][1];
+            const float8 bot = {{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}};
+            if (px >= 1 && live) {
+                float8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float s = top_prev.v[e];
+                    s = s + top.v[e];
+                    s = s + bot_prev.v[e];
+                    s = s + bot.v[e];
+                    o.v[e] = s * 0.25f;
+                }
+                act_store8(out, ofmt, (size_t)(n * A + ry) * A + (px - 1), out_cstride, (out_coffset >> 3) + g, o);
+            }
+            bot_prev = bot;
+        }
+        top_prev = top;
+        cur = nxt;
+    }
+}
+
 }  // namespace srcnn
 
 // avg_pool2d / max_pool2d (kernel 2, stride 1) over the (planes, h, w) lattice of the legacy op: the reduction behind
@@ -286,6 +386,18 @@ int srcnn_pyramid_roi_align(const float *const *maps_host, const int *mh_host, c
         pa.mw[l] = mw_host[l];
         // python: feat_maps[i].size(2) / im_info[0][0] -> double, narrowed to float at the C boundary
         pa.scale[l] = (float)((double)mh_host[l] / (double)im_height);
+    }
+    static const int roi_form = [] { const char *e = std::getenv("SRCNN_ROI_ALIGN_FORM"); return e ? std::atoi(e) : 1; }();   // A/B switch
+    if (roi_form && out_cstride % 8 == 0 && out_coffset % 8 == 0 && channels <= 256) {
+        // one workgroup per roi, one thread row per lattice row: every lattice point computed once
+        dim3 grid(num_rois), block(32, A + 1);
+        if (A == 7)
+            SRCNN_LAUNCH(pyramid_roi_align8_roi_kernel<7>, grid, block, 0, as_stream(stream), pa, channels, rois, out,
+                               out_cstride, out_coffset, maps_format, out_format);
+        else
+            SRCNN_LAUNCH(pyramid_roi_align8_roi_kernel<14>, grid, block, 0, as_stream(stream), pa, channels, rois, out,
+                               out_cstride, out_coffset, maps_format, out_format);
+        return check_launch("srcnn_pyramid_roi_align");
     }
     if (out_cstride % 8 == 0 && out_coffset % 8 == 0) {
         const int G = channels / 8, rows = G <= 32 ? 64 / G : 1;   // one or two wavefronts per block: thousands of small blocks
