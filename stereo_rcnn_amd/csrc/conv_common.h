@@ -51,6 +51,7 @@ struct ConvArgs {
     // y = bilinear_align_corners(up_top (nimg, up_TH, up_TW, Cout) -> (OH, OW)) + (conv + bias); nullptr = none
     const void *up_top;
     int up_fmt, up_TH, up_TW;
+    int nt_out;                  // SPLIT16 engine: results leave with non-temporal stores (A/B switch SRCNN_NT_STORES)
 };
 
 
@@ -104,9 +105,31 @@ __device__ __forceinline__ float8 act_load8(const void *base, int fmt, size_t pi
     return r;
 }
 
+// (NT: non-temporal stores -- results no wave of this launch reads again; behind a kernel boundary the next launch finds nothing in
+//  the XCDs' L2s anyway, so the lines only displace the operands this launch is still re-reading)
+template <bool NT = false>
 __device__ __forceinline__ void act_store8(void *base, int fmt, size_t pixel, int cstride, int group, const float8 &r)
 {
     char *p = reinterpret_cast<char *>(base) + (pixel * (size_t)cstride + (size_t)group * 8) * 4;
+    if constexpr (NT) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        if (fmt == 0) {
+            const f4 a = {r.v[0], r.v[1], r.v[2], r.v[3]}, b = {r.v[4], r.v[5], r.v[6], r.v[7]};
+            __builtin_nontemporal_store(a, reinterpret_cast<f4 *>(p));
+            __builtin_nontemporal_store(b, reinterpret_cast<f4 *>(p + 16));
+        } else {
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (_Float16)r.v[e];
+                lo[e] = (_Float16)(r.v[e] - (float)hi[e]);
+            }
+            __builtin_nontemporal_store(hi, reinterpret_cast<h8 *>(p));
+            __builtin_nontemporal_store(lo, reinterpret_cast<h8 *>(p + 16));
+        }
+        return;
+    }
     if (fmt == 0) {
         *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
         *reinterpret_cast<float4 *>(p + 16) = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]);

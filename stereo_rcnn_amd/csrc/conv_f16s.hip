@@ -933,7 +933,8 @@ __global__ __launch_bounds__(128 * WM, (MR * NR >= 16 ? 1 : 2)) void conv_f16s_k
                             }
                         }
                         if (OUT_SPLIT) split16_guard(v, p.range_flag, p.tag);
-                        act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + eye_off + co) >> 3, v);
+                        if (p.nt_out) act_store8<true>(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + eye_off + co) >> 3, v);
+                        else act_store8(p.y, OUT_SPLIT ? 1 : 0, opix, p.ycs, (p.yco + eye_off + co) >> 3, v);
                     }
                 }
             }

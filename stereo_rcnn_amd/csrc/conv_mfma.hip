@@ -421,6 +421,10 @@ static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
             SRCNN_REQUIRE(d->mode != 1 && d->Cout % 256 == 0 && d->head_parts >= (d->mode == 2 ? 2 : 1) * (d->Cout / 128) && d->head_plane > 0,
                           "MFMA-form head, partial form: Cout a multiple of 256, head_parts planes for every (eye, 128-column tile)");
     }
+    {
+        static const int nt_default = [] { const char *e = std::getenv("SRCNN_NT_STORES"); return e ? std::atoi(e) : 0; }();   // A/B switch
+        a.nt_out = nt_default;
+    }
     a.up_top = d->up_top;
     a.up_fmt = d->up_format; a.up_TH = d->up_H; a.up_TW = d->up_W;
     if (a.up_top) {
