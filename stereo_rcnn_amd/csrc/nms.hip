@@ -29,26 +29,29 @@ __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b)
     return inter / (sa + sb - inter);
 }
 
-// grid: (col_blocks, col_blocks, nb); block: 64 threads (one wavefront == one mask word)
-__global__ __launch_bounds__(64) void pair_mask_kernel(const float *__restrict__ dets, int n, int dim,
-                                                       float thresh, unsigned long long *__restrict__ mask,
-                                                       int col_blocks, unsigned long long *__restrict__ zero_word)
+// grid: (col_blocks, ceil(col_blocks / PM_ROWS), nb); block: PM_ROWS wavefronts = PM_ROWS row blocks against ONE column block
+// (one wavefront == one 64x64 tile == one mask word per lane; the column block's boxes are staged once per workgroup).
+// 6000 boxes are 94 x 94 tiles per problem: one wavefront per workgroup was 17.7 k workgroups, dispatch-bound (44 us alone).
+constexpr int PM_ROWS = 4;
+__global__ __launch_bounds__(64 * PM_ROWS) void pair_mask_kernel(const float *__restrict__ dets, int n, int dim,
+                                                                 float thresh, unsigned long long *__restrict__ mask,
+                                                                 int col_blocks, unsigned long long *__restrict__ zero_word)
 {
-    const int col_start = blockIdx.x, row_start = blockIdx.y;
+    const int col_start = blockIdx.x, row_start = blockIdx.y * PM_ROWS + (threadIdx.x >> 6);
     if ((blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) *zero_word = 0ULL;   // read by the scan's dummy DMAs
-    if (row_start > col_start) return;
+    if ((int)blockIdx.y * PM_ROWS > col_start) return;              // (uniform) every row block of this workgroup lies below the diagonal
     const float *d = dets + (size_t)blockIdx.z * n * dim;
     unsigned long long *m = mask + (size_t)blockIdx.z * n * col_blocks;
-    const int row_size = min(n - row_start * 64, 64);
+    const int row_size = min(n - row_start * 64, 64);               // (<= 0 for a row block past the end)
     const int col_size = min(n - col_start * 64, 64);
     __shared__ float4 cols[64];
-    const int t = threadIdx.x;
-    if (t < col_size) {
-        const float *p = d + (size_t)(col_start * 64 + t) * dim;
-        cols[t] = make_float4(p[0], p[1], p[2], p[3]);
+    const int t = threadIdx.x & 63;
+    if (threadIdx.x < col_size) {
+        const float *p = d + (size_t)(col_start * 64 + threadIdx.x) * dim;
+        cols[threadIdx.x] = make_float4(p[0], p[1], p[2], p[3]);
     }
     __syncthreads();
-    if (t < row_size) {
+    if (row_start <= col_start && t < row_size) {
         const int cur = row_start * 64 + t;
         const float *p = d + (size_t)cur * dim;
         const float4 me = make_float4(p[0], p[1], p[2], p[3]);
@@ -318,7 +321,8 @@ static int launch_nms(int *keep_out, const float *dets, int *num_out, const int 
     SRCNN_REQUIRE((size_t)(paired ? 2 : 1) * (SCAN_RING + (size_t)n) * 4 + 128 <= 160 * 1024, "n too large for the LDS kept list");
     auto *mask = static_cast<unsigned long long *>(ws);
     const int skip = debug_skip_mask();
-    if (!(skip & 4)) SRCNN_LAUNCH(pair_mask_kernel, dim3(cb, cb, nb), dim3(64), 0, st, dets, n, dim, thresh, mask, cb, mask + words);
+    if (!(skip & 4))
+        SRCNN_LAUNCH(pair_mask_kernel, dim3(cb, cdiv(cb, PM_ROWS), nb), dim3(64 * PM_ROWS), 0, st, dets, n, dim, thresh, mask, cb, mask + words);
     if (skip & 8) return check_launch("nms");
     if (paired) launch_scan<2>(mask, mask + words, nb, n, cb, n_valid, keep_out, num_out, stop_after, st);
     else launch_scan<1>(mask, mask + words, nb, n, cb, n_valid, keep_out, num_out, 0, st);
