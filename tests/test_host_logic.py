@@ -381,3 +381,30 @@ def test_serving_regime_gates_the_shipped_plans(monkeypatch):
         assert serving.enter(4)['shipped_plans'] == 0 and not engine._TUNED
     finally:
         streams.set_pairs_in_flight(prev)
+
+
+def test_no_kernel_carries_a_device_scope_fence(tmp_path):
+    """a `__threadfence()` (agent-scope release = `buffer_wbl2`: the XCD's whole L2 written back) in a kernel that runs
+    beside other forwards' launches cost the four-in-flight mix 116 us per forward for a pass that took 25 us alone.  Grid-wide
+    hand-offs in this library go through agent-scope atomics or a kernel boundary: no kernel source calls a fence, and the ISA of
+    the radix-select passes (the one kernel with such a hand-off) has no L2 write-back / invalidate instruction."""
+    import glob
+    import os
+    import re
+    import shutil
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'stereo_rcnn_amd', 'csrc')
+    srcs = sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')))
+    assert len(srcs) >= 10
+    fence = re.compile(r'__threadfence(_system|_block)?\s*\(|__atomic_thread_fence|__builtin_amdgcn_fence|atomic_thread_fence')
+    for f in srcs:
+        code = '\n'.join(l.split('//')[0] for l in open(f).read().split('\n'))          # comments may talk about fences
+        assert not fence.search(code), 'device-scope fence in %s' % os.path.basename(f)
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not available: source check only')
+    out = str(tmp_path / 'rpn.s')
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-S', '--cuda-device-only', '-o', out,
+                           os.path.join(csrc, 'rpn_proposal.hip')], stderr=subprocess.DEVNULL)
+    isa = open(out).read()
+    assert 'tk_hist_kernel' in isa and 'global_atomic_add' in isa
+    assert 'buffer_wbl2' not in isa and 'buffer_inv' not in isa
