@@ -200,6 +200,30 @@ typedef struct srcnn_conv_desc {
 SRCNN_API size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d);
 SRCNN_API int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_bytes, srcnn_stream_t stream);
 
+/* CHAIN: up to three convolutions over the SAME output rows in ONE launch (SPLIT16 f16x3 engine, SPLIT16 in and out, mode 0,
+ * unsplit).  descs[0] is any convolution; descs[i > 0] must be a 1x1 / stride 1 / pad 0 convolution whose input is exactly the
+ * tensor descs[i-1] writes (same pointer, channel stride = y_cstride, y_coffset 0).  A workgroup owns one M tile and computes
+ * every N tile of descs[0], then of descs[1], then of descs[2]: what a phase reads is what the SAME workgroup has just
+ * written (read back from the L2), so nothing but a workgroup barrier orders the phases and the results are bit-identical to
+ * the same convolutions launched one after the other with the same tiles.  This is the ResNet bottleneck
+ * (/root/reference/lib/model/stereo_rcnn/resnet.py:82-102) SHIFTED BY ONE convolution -- [conv2 3x3 -> conv3 (+ residual or
+ * projection shortcut) -> conv1 of the next block] -- so that the only convolution with a spatial footprint comes first and
+ * reads a tensor the previous launch completed.  No phase may write the tensor descs[0] reads (other workgroups still need its
+ * halo rows): the caller double-buffers it.  Residuals / second inputs are read at the workgroup's own rows and must be
+ * tensors no phase writes.
+ * Tile: descs[i].tile_mr / tile_waves / tile_stages must agree; tile_nr may take two values (the narrow and the wide
+ * convolutions of a bottleneck); srcnn_conv2d_chain_supported says whether (tile_mr, waves, stages, narrow nr, wide nr) is
+ * instantiated: (2,4,2,1,2) (2,4,2,1,1) (2,4,2,2,2) (2,8,2,2,2) (2,8,4,2,2) (4,8,3,2,2) (4,8,2,4,4).  Returns SRCNN_ERR_ARG otherwise
+ * -- an explicit request is never silently replaced. */
+SRCNN_API int srcnn_conv2d_chain_supported(int tile_mr, int tile_waves, int tile_stages, int nr_narrow, int nr_wide);
+SRCNN_API int srcnn_conv2d_chain(const srcnn_conv_desc *descs, int n, srcnn_stream_t stream);
+/* GROUP: up to five independent convolutions with ONE tile configuration in one launch (SPLIT16 f16x3 engine, unsplit; all with
+ * the same output format and, if any, the same MFMA-form head shape): the grid runs over the tiles of all of them.  The stereo
+ * RPN applies the shared RPN_Conv + heads to five pyramid levels (/root/reference/lib/model/rpn/stereo_rpn.py:73-95); the
+ * coarse levels are launches of 6 to 76 tiles.  Tiles: (2,2,8,2) (4,2,8,3) (4,4,8,2) (2,1,4,2) as (tile_mr, tile_nr, waves, stages).
+ * Each convolution's result is bit-identical to its own srcnn_conv2d launch with that tile. */
+SRCNN_API int srcnn_conv2d_group(const srcnn_conv_desc *descs, int n, srcnn_stream_t stream);
+
 /* SPLIT16 range guard.  The format stores hi = f16(v) unscaled: an activation beyond +-65504 (or a NaN) becomes inf and
  * poisons what it touches, where the fp32 engine would carry on.  Every kernel that writes SPLIT16 from fresh arithmetic
  * records it: a library-owned device word keeps max(layer_tag + 1) over the launches that produced such a value since

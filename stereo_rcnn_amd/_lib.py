@@ -61,6 +61,9 @@ _SIGNATURES = {
                                        c_void_p]),
     "srcnn_conv2d_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "srcnn_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_size_t, c_void_p]),
+    "srcnn_conv2d_chain_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "srcnn_conv2d_chain": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),
+    "srcnn_conv2d_group": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),
     "srcnn_range_flag_read": (c_int, [c_int]),
     "srcnn_range_flag_device_word": (c_void_p, []),
     "srcnn_range_flag_bind": (c_int, [c_void_p]),

@@ -172,5 +172,7 @@ struct Plan {
 void launch_conv_f16x3(const ConvArgs &a, const Plan &pl, hipStream_t st);   // A operand fp32 in HBM
 void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st);    // A operand split16 in HBM
 bool conv_f16s_plan_ok(const Plan &pl, const ConvArgs &a);
+// conv_mfma.hip: validates a descriptor and fills the kernel arguments (everything but the tile counts / split-K fields)
+int conv_fill_args(const srcnn_conv_desc *d, ConvArgs &a);
 
 }  // namespace srcnn

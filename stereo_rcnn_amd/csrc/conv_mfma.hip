@@ -349,7 +349,7 @@ static Plan plan_for(const srcnn_conv_desc *d, const ConvArgs &a)
     return req;
 }
 
-static int fill_args(const srcnn_conv_desc *d, ConvArgs &a)
+int conv_fill_args(const srcnn_conv_desc *d, ConvArgs &a)
 {
     SRCNN_REQUIRE(d && d->x && d->w && (d->y || d->head_w || d->head_wf), "null pointer");
     SRCNN_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, "Cin must be a positive multiple of 32");
@@ -485,7 +485,7 @@ size_t srcnn_conv2d_workspace_bytes(const srcnn_conv_desc *d)
 {
     using namespace srcnn;
     ConvArgs a;
-    if (fill_args(d, a) != SRCNN_OK) return 0;
+    if (conv_fill_args(d, a) != SRCNN_OK) return 0;
     Plan pl = plan_for(d, a);
     if (pl.splits <= 1) return 256;
     return align_up((size_t)pl.splits * a.M * a.Cout * sizeof(float), 256);
@@ -495,7 +495,7 @@ int srcnn_conv2d(const srcnn_conv_desc *d, void *workspace, size_t workspace_byt
 {
     using namespace srcnn;
     ConvArgs a;
-    int rc = fill_args(d, a);
+    int rc = conv_fill_args(d, a);
     if (rc != SRCNN_OK) return rc;
     Plan pl = plan_for(d, a);
     a.kt_per_split = pl.kt_per_split;

@@ -206,7 +206,7 @@ SRCNN_API int srcnn_debug_stamp_log(long long *rows, int max_rows)
     return n;
 }
 
-int srcnn_version(void) { return 230; }   // 210: srcnn_stream_create*, srcnn_probe_placement, srcnn_conv_desc.head_* (appended fields)
+int srcnn_version(void) { return 240; }   // 210: srcnn_stream_create*, srcnn_probe_placement, srcnn_conv_desc.head_* (appended fields)
 
 int srcnn_range_flag_read(int reset)
 {

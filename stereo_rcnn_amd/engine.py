@@ -400,7 +400,8 @@ def _tune_candidates(d, key, device, cands, log, L, st):
 
 def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=0, residual=None,
            res_cstride=None, x_offset_elems=0, relu=None, precision=None, x_fmt=0, y_fmt=0, res_fmt=0, plan=None, name=None,
-           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None, head=None, head2=None, up=None):
+           in_shift=0, out_shift=0, m_limit=None, m_limit_mul=0, x2=None, H2=0, W2=0, x2_cstride=None, head=None, head2=None, up=None,
+           desc_only=False):
     """Launch the conv engine.  x / y / residual are device tensors (any shape; raw NHWC memory).
     *_fmt: _lib.FMT_F32 or _lib.FMT_SPLIT16 (f16x3 engine only; see include/srcnn_hip.h).
     in_shift / out_shift (f16x3 engine): the input tensor holds its values x 2^in_shift, the output (and the residual, which
@@ -417,6 +418,7 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
     up = (top, TH, TW, top_fmt) (f16x3 SPLIT16 engine): the FPN top-down addition inside this launch (srcnn_conv_desc.up_top):
     y = bilinear_align_corners(top (B, TH, TW, cout) -> (OH, OW)) + (conv + bias), top stored with the OUTPUT's scale; bit-identical
     to conv2d (float32 y) followed by upsample_add.
+    desc_only (with an explicit plan): nothing is launched or counted; returns the filled descriptor (conv_chain / conv_group).
     Returns the plan the launch ran with: (tile_mr, tile_nr, waves, stages, splits)."""
     L = _lib.lib()
     d = _lib.ConvDesc()
@@ -479,6 +481,10 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
             # the addition lives in the conv kernel's epilogue of every tile but 256x256, never in the split-K reduction: an explicit
             # plan is rewritten here (not silently replaced by the library's heuristic), so that the returned plan is the one that ran
             plan = ((4, 2, 8, 3) if tuple(plan[:2]) == (4, 4) else tuple(plan[:4])) + (1,)
+    if desc_only:
+        assert plan is not None and head is None and m_limit is None
+        _set_plan(d, plan)
+        return d
     if FlopCounter.enabled:
         FlopCounter.flops += 2.0 * B * OH * OW * cw.cout * cw.alg_k
         FlopCounter.launches += 1
@@ -556,6 +562,122 @@ def conv2d(cw, x, B, H, W, y, OH, OW, x_cstride=None, y_cstride=None, y_coffset=
                 for _ in range(n):
                     _lib.check(L.srcnn_conv2d(ctypes.byref(d), ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_conv2d(repeat)")
     return used
+
+
+# ---- chained bottleneck launches (csrc/conv_chain.hip: srcnn_conv2d_chain): [conv2 -> conv3 -> conv1 of the next block] as ONE launch
+# whose workgroups keep their rows through the three convolutions.  BOTTLENECK_CHAIN: '0' (default) = off, '1' = on, 'auto' = on while
+# several forwards are in flight.  Built, bit-identical (tests/test_conv_chain_gpu.py), measured, and NOT the default: the headline
+# step is the same with and without it (profiles/chain_ab_r06.txt: 6.35-6.39 ms off, 6.35-6.41 ms with layer1 / layer2 / layer3
+# chained on their best tiles, at 3, 4, 6 and 8 forwards in flight) -- the intermediates come back through the fabric all the
+# same (a layer3 block's weights alone are 4.4 MB, the XCD's whole L2), and the package power limit prices the step by its
+# MFMA work, which a chain does not change.  It removes 46 launches per forward.
+BOTTLENECK_CHAIN = _os.environ.get('SRCNN_BOTTLENECK_CHAIN', '0')
+# planes of the bottleneck (64, 128, 256, 512) -> (tile_mr, waves, stages, narrow nr, wide nr) or None = that layer keeps its
+# separate launches.  layer4 (M = 2394: 10 workgroups of 256 rows) stays unchained.
+CHAIN_TILES = {64: (2, 4, 2, 1, 1), 128: (4, 8, 3, 2, 2), 256: (4, 8, 3, 2, 2), 512: None}
+CHAIN_MIN_WGS = 32        # a chain launch with fewer workgroups than this is not worth its latency
+
+
+def chain_enabled():
+    if BOTTLENECK_CHAIN == 'auto':
+        from . import streams
+        return streams.pairs_in_flight() > 1
+    return BOTTLENECK_CHAIN not in ('0', '', 'off')
+
+
+def chain_tile(planes, M):
+    """The chain tile of a bottleneck with `planes` channels and M output rows, or None."""
+    t = CHAIN_TILES.get(planes)
+    if t is None or -(-M // (64 * t[0])) < CHAIN_MIN_WGS:
+        return None
+    return t
+
+
+def conv_chain(phases, tile, name=None):
+    """ONE launch for up to three convolutions over the same rows (srcnn_conv2d_chain): phases = [(args, kwargs)] exactly as they
+    would be passed to conv2d, in order; phase i > 0 must be a 1x1 / stride 1 convolution of phase i-1's output.  tile = (tile_mr,
+    waves, stages, narrow nr, wide nr): a phase runs on the wide N tile when its Cout fills it (Cout >= 64 * wide nr), else on the
+    narrow one.  Results are bit-identical to the separate launches with the same tiles."""
+    L = _lib.lib()
+    mr, waves, stages, na, nb = tile
+    descs = (_lib.ConvDesc * len(phases))()
+    flops = nbytes = 0.0
+    rows = []
+    for i, (args, kw) in enumerate(phases):
+        cw = args[0]
+        nr = nb if cw.cout >= 64 * nb else na
+        kw = dict(kw)
+        pname = kw.pop('name', None)
+        d = conv2d(*args, plan=(mr, nr, waves, stages, 1), desc_only=True, name=pname, **kw)
+        ctypes.memmove(ctypes.byref(descs[i]), ctypes.byref(d), ctypes.sizeof(d))
+        B, OH, OW = args[2], args[6], args[7]
+        M = B * OH * OW
+        fl = 2.0 * M * cw.cout * cw.alg_k
+        # compulsory bytes of the chain: the first phase's input, every weight, residuals / second inputs, every output once --
+        # what a later phase reads is what the workgroup has just written (L2)
+        px_in = M if (cw.kh == 1 and cw.kw == 1) else B * args[3] * args[4]
+        by = 4.0 * ((px_in * cw.cin if i == 0 else 0) + M * cw.cin2 + cw.cout * cw.alg_k
+                    + M * cw.cout * (2 if kw.get('residual') is not None else 1))
+        flops += fl
+        nbytes += by
+        rows.append((pname, M, cw.cout, cw.alg_k))
+    if FlopCounter.enabled:
+        FlopCounter.flops += flops
+        FlopCounter.bytes += nbytes
+        FlopCounter.launches += 1
+        if FlopCounter.rows is not None:
+            FlopCounter.rows.append({'name': name or '+'.join(str(r[0]) for r in rows), 'M': rows[0][1], 'N': max(r[2] for r in rows),
+                                     'K': sum(r[3] for r in rows), 'flops': flops, 'bytes': nbytes, 'plan': (mr, nb, waves, stages, 1),
+                                     'chain': rows})
+    _lib.check(L.srcnn_conv2d_chain(descs, len(phases), _lib.stream()), "srcnn_conv2d_chain")
+    if REPEAT and name:
+        for rx, n in REPEAT:
+            if rx.match(name):
+                for _ in range(n):
+                    _lib.check(L.srcnn_conv2d_chain(descs, len(phases), _lib.stream()), "srcnn_conv2d_chain(repeat)")
+    return tile
+
+
+def conv_group(problems, tile, name=None):
+    """ONE launch for up to five independent convolutions that share a tile (srcnn_conv2d_group): problems = [(args, kwargs)] as
+    for conv2d; tile = (tile_mr, tile_nr, waves, stages).  Each result is bit-identical to its own launch with that tile."""
+    L = _lib.lib()
+    descs = (_lib.ConvDesc * len(problems))()
+    flops = nbytes = 0.0
+    rows = []
+    for i, (args, kw) in enumerate(problems):
+        cw = args[0]
+        kw = dict(kw)
+        pname = kw.pop('name', None)
+        d = conv2d(*args, plan=tuple(tile) + (1,), desc_only=True, name=pname, **kw)
+        ctypes.memmove(ctypes.byref(descs[i]), ctypes.byref(d), ctypes.sizeof(d))
+        B, H, W, OH, OW = args[2], args[3], args[4], args[6], args[7]
+        M = B * OH * OW
+        fl = 2.0 * M * cw.cout * cw.alg_k
+        px_in = M if (cw.kh == 1 and cw.kw == 1) else B * H * W
+        by = 4.0 * (px_in * cw.cin + cw.cout * cw.alg_k + M * cw.cout * (2 if kw.get('residual') is not None else 1))
+        h2 = kw.get('head2')
+        if h2 is not None:                  # the head's own flops; its planes instead of y (as conv2d counts them)
+            hn = h2[0].cout
+            fl += 2.0 * M * hn * cw.cout
+            by += 4.0 * M * (hn * (max(1, cw.cout // 256) if h2[2] else 1) - cw.cout)
+        flops += fl
+        nbytes += by
+        rows.append((pname, M, cw.cout, cw.alg_k))
+    if FlopCounter.enabled:
+        FlopCounter.flops += flops
+        FlopCounter.bytes += nbytes
+        FlopCounter.launches += 1
+        if FlopCounter.rows is not None:
+            FlopCounter.rows.append({'name': name or '+'.join(str(r[0]) for r in rows), 'M': sum(r[1] for r in rows), 'N': rows[0][2],
+                                     'K': rows[0][3], 'flops': flops, 'bytes': nbytes, 'plan': tuple(tile) + (1,), 'group': rows})
+    _lib.check(L.srcnn_conv2d_group(descs, len(problems), _lib.stream()), "srcnn_conv2d_group")
+    if REPEAT and name:
+        for rx, n in REPEAT:
+            if rx.match(name):
+                for _ in range(n):
+                    _lib.check(L.srcnn_conv2d_group(descs, len(problems), _lib.stream()), "srcnn_conv2d_group(repeat)")
+    return tuple(tile) + (1,)
 
 
 def preprocess_size(H, W, target_short=600):

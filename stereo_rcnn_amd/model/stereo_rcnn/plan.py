@@ -125,7 +125,7 @@ class Plan(object):
             if li > 0:
                 h, w_ = engine.conv_out_hw(h, w_, 1, 1, 2, 0)
             self.layer_hw.append((h, w_))
-            self.layer_bufs.append({'m1': e(N, h, w_, planes), 'm2': e(N, h, w_, planes),
+            self.layer_bufs.append({'m1': e(N, h, w_, planes), 'm1b': e(N, h, w_, planes), 'm2': e(N, h, w_, planes),
                                     'a': e(N, h, w_, 4 * planes), 'b': e(N, h, w_, 4 * planes)})
         self.c = [None] * 4
         # FPN
@@ -230,6 +230,19 @@ class Plan(object):
                 self._note(out_group, y.view(-1, ycs)[:, c0:c0 + cw.cout * (2 if cw.mode == 2 else 1)])
         return used
 
+    def _conv_chain(self, phases, tile, name):
+        """engine.conv_chain with _conv's scale bookkeeping per phase: phases = [((cw, x, B, H, W, y, OH, OW, in_group, out_group), kwargs)]."""
+        ph = []
+        for a, kw in phases:
+            ko = self._k(a[9])
+            ph.append((a[:8], dict(kw, in_shift=self._k(a[8]), out_shift=ko)))
+            self._buf_shift[a[5].data_ptr()] = ko
+        engine.conv_chain(ph, tile, name=name)
+        if self._calib is not None:
+            for a, kw in phases:
+                if a[9] is not None:
+                    self._note(a[9], a[5])
+
     def _note(self, group, t):
         self._calib[group] = max(self._calib.get(group, 0.0), float(t.abs().max()))
 
@@ -308,25 +321,41 @@ class Plan(object):
             bufs = self.layer_bufs[li]
             cur, nxt = bufs['a'], bufs['b']
             lg = 'L%d' % (li + 1)                         # the residual stream of this layer: ONE scale for all its blocks
+            # A block = conv1 -> conv2 (3x3) -> conv3 (+ residual or projection shortcut).  Launch order, either way: conv1 of the
+            # layer's first block, then per block [conv2, conv3, conv1 of the NEXT block] -- as three launches, or (SPLIT16 engine,
+            # several forwards in flight: engine.chain_enabled) as ONE chained launch whose workgroups keep their rows through the
+            # three convolutions (csrc/conv_chain.hip).  conv1 writes the m1 buffers alternately: a chain's last phase must not
+            # overwrite the tensor its first phase reads (other workgroups' halo rows).
+            planes = blocks[0]['conv2'].cout
+            tile = engine.chain_tile(planes, N * h * w_) if (f and engine.chain_enabled()) else None
+            m1 = [bufs['m1'], bufs['m1b']]
+            g1 = lg + '.0.m1'
+            self._conv(blocks[0]['conv1'], x, N, xh, xw, m1[0], h, w_, xg, g1, x_fmt=f, y_fmt=f, name='layer%d.0.conv1' % (li + 1))
             for bi, blk in enumerate(blocks):
                 nm = 'layer%d.%d.' % (li + 1, bi)
-                g1, g2 = lg + '.%d.m1' % bi, lg + '.%d.m2' % bi
-                self._conv(blk['conv1'], x, N, xh, xw, bufs['m1'], h, w_, xg, g1, x_fmt=f, y_fmt=f, name=nm + 'conv1')
-                self._conv(blk['conv2'], bufs['m1'], N, h, w_, bufs['m2'], h, w_, g1, g2, x_fmt=f, y_fmt=f, name=nm + 'conv2')
+                g2 = lg + '.%d.m2' % bi
+                phs = [((blk['conv2'], m1[bi & 1], N, h, w_, bufs['m2'], h, w_, g1, g2), dict(x_fmt=f, y_fmt=f, name=nm + 'conv2'))]
                 if blk['down'] is not None and f and engine.SHORTCUT_FUSION and w.fuse_shortcut[li] and self._k(g2) == self._k(xg):
                     # the projection shortcut inside conv3: K = [conv2's output | the block's input], no residual round trip
-                    self._conv(blk['conv3_down'], bufs['m2'], N, h, w_, cur, h, w_, g2, lg, x2=x, H2=xh, W2=xw, x_fmt=f, y_fmt=f,
-                               name=nm + 'conv3+downsample')
-                    x, xh, xw, xg = cur, h, w_, lg
-                    cur, nxt = nxt, cur
-                    continue
-                if blk['down'] is not None:
-                    self._conv(blk['down'], x, N, xh, xw, nxt, h, w_, xg, lg, x_fmt=f, y_fmt=f, name=nm + 'downsample')
-                    res = nxt
+                    phs.append(((blk['conv3_down'], bufs['m2'], N, h, w_, cur, h, w_, g2, lg),
+                               dict(x2=x, H2=xh, W2=xw, x_fmt=f, y_fmt=f, name=nm + 'conv3+downsample')))
                 else:
-                    res = x
-                self._conv(blk['conv3'], bufs['m2'], N, h, w_, cur, h, w_, g2, lg, residual=res, x_fmt=f, y_fmt=f,
-                           res_fmt=f, name=nm + 'conv3')
+                    if blk['down'] is not None:
+                        self._conv(blk['down'], x, N, xh, xw, nxt, h, w_, xg, lg, x_fmt=f, y_fmt=f, name=nm + 'downsample')
+                        res = nxt
+                    else:
+                        res = x
+                    phs.append(((blk['conv3'], bufs['m2'], N, h, w_, cur, h, w_, g2, lg),
+                               dict(residual=res, x_fmt=f, y_fmt=f, res_fmt=f, name=nm + 'conv3')))
+                if bi + 1 < len(blocks):
+                    g1 = lg + '.%d.m1' % (bi + 1)
+                    phs.append(((blocks[bi + 1]['conv1'], cur, N, h, w_, m1[(bi + 1) & 1], h, w_, lg, g1),
+                               dict(x_fmt=f, y_fmt=f, name='layer%d.%d.conv1' % (li + 1, bi + 1))))
+                if tile is not None:
+                    self._conv_chain(phs, tile, nm + 'chain')
+                else:
+                    for a, kw in phs:
+                        self._conv(*a, **kw)
                 x, xh, xw, xg = cur, h, w_, lg
                 cur, nxt = nxt, cur
             self.c[li] = x
@@ -677,7 +706,7 @@ class Plan(object):
             self._rec = None
             _lib._recording_refs = None
             _lib.check(L.srcnn_program_end(prog), "srcnn_program_end")
-        self.programs[(precision, kpts, self._par())] = (prog, refs)
+        self.programs[(precision, kpts, self._par(), engine.chain_enabled())] = (prog, refs)
         return prog
 
     def run(self, use_graph=False, precision='f32', use_program=False, kpts=True):
@@ -703,7 +732,7 @@ class Plan(object):
             if use_program and not use_graph:
                 # the stem input is packed here, eagerly, from wherever the inputs are (set_inputs keeps references instead of
                 # copying; set_images wrote `packed` itself); the recorded list starts at the stem conv
-                ent = self.programs.get((precision, kpts, self._par()))      # one list per (engine, branch, stream regime)
+                ent = self.programs.get((precision, kpts, self._par(), engine.chain_enabled()))      # one list per (engine, branch, stream regime)
                 if ent is None:
                     prog = self._record_program(precision, kpts)             # (its warm-up run packs and consumes the input)
                     self.packed_fmt = -1
