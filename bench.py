@@ -151,6 +151,10 @@ def csrc_hash():
     return h.hexdigest()
 
 
+# kernel names of the conv engine's launches (single, grouped, chained; the stem's fp32-input form)
+CONV_KERNELS = ('conv_f16s_kernel', 'conv_f16x3_kernel', 'conv_group_kernel', 'conv_chain_kernel')
+
+
 def measure_traffic_live(plans_path, steps=3, timeout_s=240):
     """HBM-side bytes of the conv engine per step, measured in THIS run on THIS box: two child processes of this script
     (`--pmc-child`: plans preloaded, `steps` forwards one at a time, nothing else) under rocprofv3's counter collection, one
@@ -180,7 +184,7 @@ def measure_traffic_live(plans_path, steps=3, timeout_s=240):
             for f in files:
                 for row in csv.DictReader(open(f)):
                     name = row['Kernel_Name']
-                    if row['Counter_Name'] == counter and ('conv_f16s_kernel' in name or 'conv_f16x3_kernel' in name):
+                    if row['Counter_Name'] == counter and any(k in name for k in CONV_KERNELS):
                         total += float(row['Counter_Value'])
                         seen.add(row['Dispatch_Id'])
             # the child runs one untimed forward first (workspace sizing); every forward has the same launches

@@ -371,6 +371,14 @@ SRCNN_API int srcnn_pack_detections(const float *scores, const float *boxes_left
  * with status -1 (never silently truncated).  Outputs status (R: 1 ok, 0 no valid pixel, -1 overflow) and best_dis (R)
  * float32 on the device. */
 SRCNN_API size_t srcnn_dense_align_workspace_bytes(int H, int W, int R, int max_pixels);
+/* Where, inside the workspace of a finished srcnn_dense_align call with the same sizes, the intermediate results of the depth
+ * search live (byte offsets; for parity audits of the discrete argmin -- reference dense_align.py:225-232 -- and diagnostics):
+ *   offsets[0] = int32 cnt[2 R]: valid lattice pixels per object, then overflow flags
+ *   offsets[1], [2], [3] = coarse stage: float depth_enum[50][R], float cost[50][R] (sum over pixels and channels of |L - R|,
+ *                          workgroup-reduced in a fixed order), float best_depth[R] (first minimum)
+ *   offsets[4], [5], [6] = fine stage: depth_enum[20][R] (rows 20..49 unused), cost[20][R], best_depth[R]
+ * n_offsets must be >= 7. */
+SRCNN_API int srcnn_dense_align_workspace_layout(int H, int W, int R, int max_pixels, size_t *offsets, int n_offsets);
 SRCNN_API int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W, double scale,
                       double p2_00, double p2_02, double p2_12, double p2_03_minus_p3_03,
                       const float *boxes, const float *borders, const float *poses,

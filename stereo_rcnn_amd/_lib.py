@@ -94,6 +94,7 @@ _SIGNATURES = {
                                 c_void_p, c_size_t, c_void_p]),
     "srcnn_pack_detections": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srcnn_dense_align_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "srcnn_dense_align_workspace_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t), c_int]),
     "srcnn_dense_align": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_double,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

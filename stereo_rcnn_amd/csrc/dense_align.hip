@@ -17,6 +17,7 @@
 // -ffp-contract=off); Python-double scalars of the reference (f, bl, cx, cy, slice arithmetic
 // on torch-0.3 scalar-indexed values) are doubles here.
 #include "common.h"
+#include <cstdlib>
 
 namespace srcnn {
 
@@ -26,30 +27,41 @@ struct DaCalib {
 };
 
 // ------------------------------------------------------------------ 2x bilinear upsample (align_corners)
-__global__ void upsample2x_kernel(const float *__restrict__ a, const float *__restrict__ b, int H, int W,
-                                  float *__restrict__ oa, float *__restrict__ ob)
+// The element's arithmetic is F.upsample's, operation by operation; the taps come from the 29 MB source through the caches.
+// Round 5's form (one float per thread, flat index decomposed with 64-bit % and /) moved its 143 MB at 1.6 TB/s.
+// A flat-index form with four floats per thread and 32-bit unsigned divisions on the vector unit was bit-exact alone and
+// NOT repeatable beside other forwards' MFMA kernels: 13-41 of 306 frames of tests/test_pipeline_gpu.py's three-in-flight soak
+// came back with a neighbouring depth hypothesis for one or two objects (same box, same day: 0 of 306 with round 5's kernel,
+// 0 of 306 with the division-free form below) -- the second kernel of this file, after sample_kernel's box geometry (see
+// there), whose v_rcp-based sequences misbehave under that co-residency.  Cause not established; the soak test is the gate.
+__device__ __forceinline__ float upsample2x_at(const float *__restrict__ src, int H, int W, int x, int y, int c, float rh, float rw)
+{
+    const float h1r = rh * (float)y;
+    const int h1 = (int)h1r;
+    const int h1p = h1 < H - 1 ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float w1r = rw * (float)x;
+    const int w1 = (int)w1r;
+    const int w1p = w1 < W - 1 ? 1 : 0;
+    const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+    const float *p = src + ((size_t)c * H + h1) * W + w1;
+    return h0l * (w0l * p[0] + w1l * p[w1p]) + h1l * (w0l * p[(size_t)h1p * W] + w1l * p[(size_t)h1p * W + w1p]);
+}
+
+// grid (ceil(W / 256), 2H, 6): x = one SOURCE column pair per thread -> two output floats, one 8-byte store (2W is even: every row
+// starts 8-byte aligned); y = output row; z = image * 3 + plane.  No integer division on the vector unit.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float *__restrict__ a, const float *__restrict__ b, int H, int W,
+                                                         float *__restrict__ oa, float *__restrict__ ob)
 {
     const int H2 = 2 * H, W2 = 2 * W;
     const float rh = (float)(H - 1) / (float)(H2 - 1), rw = (float)(W - 1) / (float)(W2 - 1);
-    const float *src = blockIdx.z ? b : a;
-    float *dst = blockIdx.z ? ob : oa;
-    const size_t total = (size_t)3 * H2 * W2;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % W2);
-        const int y = (int)((idx / W2) % H2);
-        const int c = (int)(idx / ((size_t)W2 * H2));
-        const float h1r = rh * (float)y;
-        const int h1 = (int)h1r;
-        const int h1p = h1 < H - 1 ? 1 : 0;
-        const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
-        const float w1r = rw * (float)x;
-        const int w1 = (int)w1r;
-        const int w1p = w1 < W - 1 ? 1 : 0;
-        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-        const float *p = src + ((size_t)c * H + h1) * W + w1;
-        dst[idx] = h0l * (w0l * p[0] + w1l * p[w1p]) + h1l * (w0l * p[(size_t)h1p * W] + w1l * p[(size_t)h1p * W + w1p]);
-    }
+    const int img = blockIdx.z / 3, c = blockIdx.z - 3 * img, y = blockIdx.y;
+    const float *src = img ? b : a;
+    float *dst = (img ? ob : oa) + ((size_t)c * H2 + y) * W2;
+    const int x = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (x >= W2) return;
+    const float v0 = upsample2x_at(src, H, W, x, y, c, rh, rw), v1 = upsample2x_at(src, H, W, x + 1, y, c, rh, rw);
+    *reinterpret_cast<float2 *>(dst + x) = make_float2(v0, v1);
 }
 
 // ------------------------------------------------------------------ sample lattice + ray/box intersection
@@ -250,7 +262,7 @@ __global__ void make_enum_kernel(const float *__restrict__ poses, const float *_
     float d;
     if (stage == 0) {
         const float fbf = (float)cal.fb;
-        const float dis_init = fbf / poses[r * 7 + 2];                                  // dense_align.py:265
+        const float dis_init = (1.0f / poses[r * 7 + 2]) * fbf;         // dense_align.py:265: scalar / tensor = tensor.reciprocal() * scalar in torch
         d = (((1.0f / dis_init) * (float)cal.f) * (float)cal.bl - (float)(iters * 0.5 / 2)) + (float)(0.5 * i);   // :283
         if (d < 1.5f) d = 1.5f;                                                         // :285
     } else {
@@ -317,11 +329,11 @@ __global__ void finish_kernel(const float *__restrict__ poses, const float *__re
     const float fbf = (float)cal.fb;
     if (total == 0) {                                                    // dense_align.py:272-274
         status[r] = 0.f;
-        best_dis[r] = fbf / poses[r * 7 + 2];
+        best_dis[r] = (1.0f / poses[r * 7 + 2]) * fbf;                    // dis_init (:265), as above
         return;
     }
     status[r] = cnt[R + r] ? -1.f : (cnt[r] > 0 ? 1.f : 0.f);            // :276-277; -1 = lattice did not fit max_pixels
-    best_dis[r] = fbf / (best_depth[r] * (float)cal.scale2) + 0.5f;      // :298
+    best_dis[r] = (1.0f / (best_depth[r] * (float)cal.scale2)) * fbf + 0.5f;      // :298 (scalar / tensor again)
 }
 
 struct DaLayout {
@@ -357,6 +369,20 @@ size_t srcnn_dense_align_workspace_bytes(int H, int W, int R, int max_pixels)
     return srcnn::da_layout(H, W, R > 0 ? R : 1, max_pixels > 0 ? max_pixels : 1).total;
 }
 
+int srcnn_dense_align_workspace_layout(int H, int W, int R, int max_pixels, size_t *offsets, int n_offsets)
+{
+    using namespace srcnn;
+    SRCNN_REQUIRE(offsets && n_offsets >= 7 && H > 1 && W > 1 && R > 0 && max_pixels > 0, "7 offsets; positive sizes");
+    const DaLayout L = da_layout(H, W, R, max_pixels);
+    offsets[0] = L.cnt;
+    for (int stage = 0; stage < 2; ++stage) {
+        offsets[1 + 3 * stage] = L.depth_enum[stage];
+        offsets[2 + 3 * stage] = L.cost[stage];
+        offsets[3 + 3 * stage] = L.best[stage];
+    }
+    return SRCNN_OK;
+}
+
 int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W, double scale, double p2_00,
                       double p2_02, double p2_12, double p2_03_minus_p3_03, const float *boxes, const float *borders,
                       const float *poses, const float *valid, int R, int max_pixels, float *status, float *best_dis,
@@ -386,7 +412,7 @@ int srcnn_dense_align(const float *im_left, const float *im_right, int H, int W,
     int *cnt = reinterpret_cast<int *>(ws + L.cnt);
     float *best[2] = {reinterpret_cast<float *>(ws + L.best[0]), reinterpret_cast<float *>(ws + L.best[1])};
     hipStream_t st = as_stream(stream);
-    SRCNN_LAUNCH(upsample2x_kernel, dim3(4096, 1, 2), dim3(256), 0, st, im_left, im_right, H, W, up_l, up_r);
+    SRCNN_LAUNCH(upsample2x_kernel, dim3(cdiv(W, 256), 2 * H, 6), dim3(256), 0, st, im_left, im_right, H, W, up_l, up_r);
     SRCNN_LAUNCH(sample_kernel, dim3(R), dim3(256), 0, st, boxes, borders, poses, valid, cal, max_pixels, uvz, cnt);
     SRCNN_LAUNCH(left_sample_kernel, dim3(cdiv(max_pixels, 256), R), dim3(256), 0, st, up_l, uvz, cnt, max_pixels,
                        cal, left_val);

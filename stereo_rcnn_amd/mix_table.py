@@ -32,8 +32,9 @@ GROUPS = [          # (label, regex over the conv launch names of plan.py)
     ('layer4', r'layer4\.'),
     ('fpn.laterals+top', r'fpn\.(lateral|toplayer)'),
     ('fpn.smooth', r'fpn\.smooth'),
-    ('rpn_conv.P2', r'rpn_conv(\+head)?\.P2$'),
-    ('rpn_conv.P3-P6', r'rpn_conv(\+head)?\.P[3-6]$'),
+    ('layer3.chain', r'layer3\.\d+\.chain'),          # SRCNN_BOTTLENECK_CHAIN=1: [conv2, conv3, next conv1] per launch
+    ('rpn_conv.P2', r'rpn_conv(\+head)?\.P2'),         # (also the five-level grouped launch, SRCNN_RPN_GROUP=all)
+    ('rpn_conv.P3-P6', r'rpn_conv(\+head)?\.P[3-6]'),  # (one grouped launch by default: 'rpn_conv+head.P3+4+5+6')
     ('rpn_head', r'rpn_head\.'),
     ('box head', r'box\.'),
     ('kpts.0-10', r'kpts\.\d+$'),

@@ -16,7 +16,7 @@ def check_status(status_host):
     return status_host
 
 
-def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses, valid=None):
+def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses, valid=None, return_search=False):
     """Dense alignment for multiple objects, depth enumeration in parallel.
 
     Inputs (as the reference):
@@ -28,6 +28,9 @@ def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses, 
         poses: rois x 7 (x, y, z, w, h, l, theta)
         valid (extension): optional rois float32 mask; rows <= 0 are skipped (status 0) -- lets a fixed-size batch
                straight from the device-side 4-DoF solve be aligned without compacting it on the host
+        return_search (extension): also return the depth search itself (copies of the call's workspace,
+               srcnn_dense_align_workspace_layout): {'count' (rois) valid lattice pixels, 'coarse_depth' / 'coarse_cost' (50, rois),
+               'fine_depth' / 'fine_cost' (20, rois), 'coarse_best' / 'fine_best' (rois)} -- for auditing the discrete argmin
     Returns:
         solve_status: 1 = success, 0 = failed (no valid pixel), -1 = lattice overflow (see check_status)   (rois)
         best_dis: aligned disparity in the origin image          (rois)
@@ -53,4 +56,14 @@ def align_parallel(calib, scale, im_left, im_right, box_left, keypoints, poses, 
                                    poses.data_ptr(), valid.data_ptr() if valid is not None else None, R, MAX_PIXELS,
                                    status.data_ptr(), best_dis.data_ptr(),
                                    ws.data_ptr(), ws.numel(), _lib.stream()), "srcnn_dense_align")
+    if return_search:
+        import ctypes
+        off = (ctypes.c_size_t * 7)()
+        _lib.check(L.srcnn_dense_align_workspace_layout(H, W, R, MAX_PIXELS, off, 7), "srcnn_dense_align_workspace_layout")
+        raw = ws.view(torch.uint8)
+        f32 = lambda o, n: raw[o:o + 4 * n].view(torch.float32).clone()
+        search = {'count': raw[off[0]:off[0] + 4 * R].view(torch.int32).clone(),
+                  'coarse_depth': f32(off[1], 50 * R).view(50, R), 'coarse_cost': f32(off[2], 50 * R).view(50, R), 'coarse_best': f32(off[3], R),
+                  'fine_depth': f32(off[4], 20 * R).view(20, R), 'fine_cost': f32(off[5], 20 * R).view(20, R), 'fine_best': f32(off[6], R)}
+        return status, best_dis, search
     return status, best_dis

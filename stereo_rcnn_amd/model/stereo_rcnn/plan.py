@@ -141,7 +141,7 @@ class Plan(object):
         self.rpn_cat = [e(B, a, b, 1024) for a, b in self.rpn_shapes]
         self.rpn_hd = [e(B, a, b, 24) for a, b in self.rpn_shapes]
         # fused RPN head (SPLIT16 engine): per level up to 8 planes of per-(eye, N tile) partial sums, (B * h * w, 24) floats each
-        self.rpn_part = [e(8, B * a * b, 24) for a, b in self.rpn_shapes]
+        self.rpn_part = [torch.zeros((8, B * a * b, 24), dtype=torch.float32, device=dev) for a, b in self.rpn_shapes]   # zeroed: a plane count mismatch adds zeros, not garbage
         self.rpn_nparts = [0] * len(self.rpn_shapes)
         self._rpn_fused = False
         self.probs = e(B, self.A, 2)
@@ -397,7 +397,11 @@ class Plan(object):
             # partial sums per (eye, N tile); the (B, h, w, 1024) tensor is neither written nor read, five head launches are gone
             used = self._conv(w.rpn_conv_pair, feats[l], 2 * B, h, w_, None, h, w_, 'P', 'rpn', x_fmt=f, name='rpn_conv+head.P%d' % (l + 2),
                               head2=(w.rpn_head, self.rpn_part[l], 8))
-            self.rpn_nparts[l] = 2 * (w.rpn_conv_pair.cout // (64 * used[1]))
+            # planes the launch wrote = (eye, N tile) pairs of the tile that RAN: the library runs a head2 launch on the 128x128
+            # 8-wave tile when asked for exactly that (or, without a request, for small M), on the 256x256 tile otherwise
+            # (conv_mfma.hip: plan_for) -- whatever else the descriptor asked for
+            ran_small = (used[0] == 2 and used[1] == 2) or (used[0] <= 0 and 2 * B * h * w_ < 256 * 8)
+            self.rpn_nparts[l] = 2 * (w.rpn_conv_pair.cout // (128 if ran_small else 256))
             return
         if f and engine.RPN_PAIR_LAUNCH:       # SPLIT16 engine: both eyes in one launch (conv mode 2: the right half lands 512 channels further)
             self._conv(w.rpn_conv_pair, feats[l], 2 * B, h, w_, cat, h, w_, 'P', 'rpn', y_cstride=1024, y_coffset=0, x_fmt=f, y_fmt=f,
@@ -408,6 +412,22 @@ class Plan(object):
             self._conv(w.rpn_conv, feats[l], B, h, w_, cat, h, w_, 'P', 'rpn', y_cstride=1024, y_coffset=512,
                        x_offset_elems=B * h * w_ * 256, x_fmt=f, y_fmt=f, name='rpn_conv.P%d' % (l + 2))
         self._conv(w.rpn_head, cat, B, h, w_, hd, h, w_, 'rpn', None, x_fmt=f, name='rpn_head.P%d' % (l + 2))
+
+    def _rpn_group(self, levels):
+        """RPN_Conv + fused head of several pyramid levels in ONE grouped launch (shared weights; srcnn_conv2d_group): every level's
+        partial planes are the bits its own launch would write."""
+        w, B, f = self.w, self.B, self.fmt
+        feats = [self.p2, self.p3, self.p4, self.p5, self.p6]
+        tile = engine.RPN_GROUP_TILE
+        ki, ko = self._k('P'), self._k('rpn')
+        probs = []
+        for l in levels:
+            h, w_ = self.rpn_shapes[l]
+            probs.append(((w.rpn_conv_pair, feats[l], 2 * B, h, w_, None, h, w_),
+                          dict(x_fmt=f, head2=(w.rpn_head, self.rpn_part[l], 8), in_shift=ki, out_shift=ko, precision=engine.PRECISION,
+                               name='rpn_conv+head.P%d' % (l + 2))))
+            self.rpn_nparts[l] = 2 * (w.rpn_conv_pair.cout // (64 * tile[1]))
+        engine.conv_group(probs, tile, name='rpn_conv+head.P%s' % '+'.join(str(l + 2) for l in levels))
 
     def _rpn_scores(self):
         """Pair softmax + NHWC flatten of every level's head output into probs / deltas (stereo_rpn.py:81-91): one launch for all
@@ -450,7 +470,11 @@ class Plan(object):
         if 'subsample' not in engine.DEBUG_SKIP:
             engine.subsample2(self.p5, N, h5, w5, 256, self.p6, h6, w6)                          # stereo_rcnn.py:168
         self._buf_shift[self.p6.data_ptr()] = self._k('P')
-        if par:
+        # grouped RPN launches (engine.RPN_GROUP): the levels wait for the last one of their group
+        grp = engine.RPN_GROUP if (self._rpn_fused and engine.RPN_GROUP in ('all', 'small')) else None
+        if grp:
+            pass
+        elif par:
             self._fork(s_rpn)
             with torch.cuda.stream(s_rpn):
                 self._rpn_level(4)
@@ -479,7 +503,20 @@ class Plan(object):
             if i + 1 < 3:
                 tops[i + 1] = (out, h, w_)
             level = 2 - i                        # p4 -> RPN level 2, p3 -> 1, p2 -> 0
-            if par and level > 0:
+            if grp:
+                if grp == 'small' and level == 1:               # P3 exists: P3..P6 in one launch (on the side stream when forked)
+                    if par:
+                        self._fork(s_rpn)
+                        with torch.cuda.stream(s_rpn):
+                            self._rpn_group([1, 2, 3, 4])
+                    else:
+                        self._rpn_group([1, 2, 3, 4])
+                elif level == 0:
+                    if grp == 'all':
+                        self._rpn_group([0, 1, 2, 3, 4])
+                    else:
+                        self._rpn_level(0)
+            elif par and level > 0:
                 self._fork(s_rpn)                # side stream also waits for this level's smooth conv
                 with torch.cuda.stream(s_rpn):
                     self._rpn_level(level)
@@ -500,8 +537,14 @@ class Plan(object):
     def rpn(self):
         """(kept for stage timing tools) the RPN head alone, serial."""
         self._rpn_fused = bool(self.fmt and engine.RPN_HEAD_FUSION and engine.RPN_PAIR_LAUNCH)
-        for l in range(5):
-            self._rpn_level(l)
+        if self._rpn_fused and engine.RPN_GROUP == 'all':
+            self._rpn_group([0, 1, 2, 3, 4])
+        elif self._rpn_fused and engine.RPN_GROUP == 'small':
+            self._rpn_group([1, 2, 3, 4])
+            self._rpn_level(0)
+        else:
+            for l in range(5):
+                self._rpn_level(l)
         self._rpn_scores()
 
     def proposals(self):
@@ -706,8 +749,13 @@ class Plan(object):
             self._rec = None
             _lib._recording_refs = None
             _lib.check(L.srcnn_program_end(prog), "srcnn_program_end")
-        self.programs[(precision, kpts, self._par(), engine.chain_enabled())] = (prog, refs)
+        self.programs[self.program_key(precision, kpts)] = (prog, refs)
         return prog
+
+    def program_key(self, precision, kpts, par=None):
+        """Key of a recorded launch program in self.programs: one list per (engine, keypoint branch, branches on side streams,
+        chained bottlenecks)."""
+        return (precision, kpts, self._par() if par is None else bool(par), engine.chain_enabled())
 
     def run(self, use_graph=False, precision='f32', use_program=False, kpts=True):
         """precision: 'f32' (exact fp32 MFMA engine) or 'f16x3' (3-term split on the f16 MFMA).
@@ -732,7 +780,7 @@ class Plan(object):
             if use_program and not use_graph:
                 # the stem input is packed here, eagerly, from wherever the inputs are (set_inputs keeps references instead of
                 # copying; set_images wrote `packed` itself); the recorded list starts at the stem conv
-                ent = self.programs.get((precision, kpts, self._par(), engine.chain_enabled()))      # one list per (engine, branch, stream regime)
+                ent = self.programs.get(self.program_key(precision, kpts))      # one list per (engine, branch, stream regime)
                 if ent is None:
                     prog = self._record_program(precision, kpts)             # (its warm-up run packs and consumes the input)
                     self.packed_fmt = -1

@@ -176,3 +176,42 @@ def test_grouped_plain_convolutions(dev):
         torch.cuda.synchronize()
         for a, b in zip(one, grp):
             assert torch.equal(_bits(a), _bits(b)), tile
+
+
+def test_forward_with_chained_bottlenecks_equals_the_unchained_forward(dev):
+    """The whole network with layer1-3 on chained launches (SRCNN_BOTTLENECK_CHAIN=1) against the same forward unchained: the
+    chained trunk runs other tiles than the tuned single launches (another summation order: the engine's plan-to-plan rounding),
+    so proposals agree to 1e-3 px and the regressions to 2e-5 -- and the chained forward is bit-repeatable."""
+    from stereo_rcnn_amd import engine, fixture
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    m = resnet(('__background__', 'Car'), 101, pretrained=False)
+    m.create_architecture()
+    m.load_state_dict(fixture.make_state_dict(3))
+    m.cuda().eval()
+    m.precision = 'f16x3'
+    l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 120, 400, target_short=192)]
+    saved = engine.BOTTLENECK_CHAIN, engine.CHAIN_MIN_WGS
+    try:
+        with torch.no_grad():
+            engine.BOTTLENECK_CHAIN = '0'
+            ref = [t.clone() for t in m(l, r, info)[:8]]
+            engine.BOTTLENECK_CHAIN, engine.CHAIN_MIN_WGS = '1', 1
+            engine.PLAN_EPOCH += 1
+            engine.FlopCounter.enabled, engine.FlopCounter.rows = True, []
+            a = [t.clone() for t in m(l, r, info)[:8]]
+            rows, engine.FlopCounter.enabled, engine.FlopCounter.rows = engine.FlopCounter.rows, False, None
+            b = [t.clone() for t in m(l, r, info)[:8]]
+        torch.cuda.synchronize()
+    finally:
+        engine.BOTTLENECK_CHAIN, engine.CHAIN_MIN_WGS = saved
+        engine.PLAN_EPOCH += 1
+    chains = [x for x in rows if 'chain' in x]
+    assert len(chains) == 3 + 4 + 23, len(chains)               # every block of layer1-3 is one launch
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    d = (ref[0][0][:, None, 1:] - a[0][0][None, :, 1:]).abs().amax(2)      # proposals: matched by position (a tie may swap two)
+    best, idx = d.min(1)
+    ok = best < 1e-3
+    assert float(ok.float().mean()) > 0.98, float(ok.float().mean())
+    for i in (2, 3, 4):                                         # cls_prob, bbox_pred, dim_orien_pred of the matched rois
+        assert float((ref[i][0][ok] - a[i][0][idx[ok]]).abs().max()) < 2e-5

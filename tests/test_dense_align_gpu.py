@@ -27,30 +27,77 @@ def _scene(n, seed):
     return calib, poses, boxes, kp
 
 
-def _run_both(dev, l, r, info, calib, poses, boxes, kp):
+def _run_both(dev, l, r, info, calib, poses, boxes, kp, search=False):
     from oracle import dense_align as oda
     from stereo_rcnn_amd.model.dense_align.dense_align import align_parallel
     st_ref, dis_ref, ex = oda.align_parallel(calib, float(info[0, 2]), l, r, boxes, kp, poses, return_extra=True)
-    st, dis = align_parallel(calib, float(info[0, 2]), l.to(dev), r.to(dev), boxes.to(dev), kp.to(dev), poses.to(dev))
+    out = align_parallel(calib, float(info[0, 2]), l.to(dev), r.to(dev), boxes.to(dev), kp.to(dev), poses.to(dev), return_search=search)
     torch.cuda.synchronize()
-    return st.cpu(), dis.cpu(), st_ref, dis_ref, ex
+    if search:
+        return out[0].cpu(), out[1].cpu(), st_ref, dis_ref, ex, {k: v.cpu() for k, v in out[2].items()}
+    return out[0].cpu(), out[1].cpu(), st_ref, dis_ref, ex
 
 
-@pytest.mark.parametrize("seed,n", [(1, 1), (2, 6), (3, 12)])
+def _first_argmin(cost):
+    return torch.from_numpy(np.argmin(cost.numpy(), axis=0))            # first minimum, as dense_align.py:232 (torch.min of 0.3)
+
+
+def _order_bound(count):
+    """Largest relative difference two float32 evaluations of one object's cost may have: the cost is a sum of 3 * count
+    non-negative terms |L - R|; two summation orders differ by at most 2 gamma_n sum|x| (gamma_n = n u, u = 2^-24), and the
+    terms themselves (bilinear taps: four products and three additions) by a few u each."""
+    return (2.0 * 3.0 * count.double() + 16.0) * 2.0 ** -24
+
+
+def _tie_audit(search, ref_cost, stage, rows):
+    """Index-level parity of one stage's argmin over `rows`: same index, or -- a FLIP -- the two candidates' costs within the
+    summation-order bound in BOTH evaluations.  Returns (flips, largest relative margin of a flip); raises on a flip that is
+    not a near-tie."""
+    cg, co = search[stage + '_cost'], ref_cost
+    iters = co.shape[0]
+    ig, io = _first_argmin(cg[:iters]), _first_argmin(co)
+    bound = _order_bound(search['count'])
+    flips, worst = 0, 0.0
+    for r in rows:
+        a, b = int(ig[r]), int(io[r])
+        if a == b:
+            continue
+        flips += 1
+        for c in (cg, co):
+            rel = abs(float(c[a, r]) - float(c[b, r])) / max(float(c[a, r]), 1e-30)
+            worst = max(worst, rel)
+            assert rel <= float(bound[r]), "argmin flip that is not a near-tie: object %d, %s index %d vs %d, costs %r vs %r (bound %.2e)" % (
+                r, stage, a, b, float(c[a, r]), float(c[b, r]), float(bound[r]))
+    return flips, worst
+
+
+@pytest.mark.parametrize("seed,n", [(1, 1), (2, 6), (3, 12), (4, 24), (5, 48)])
 def test_align_parallel_matches_oracle(dev, seed, n):
+    """Status exact; the argmin INDEX of both stages exact or an audited near-tie (A16: dense_align.py:225-232 -- the cost vectors
+    come out of the call's workspace); where the indices agree, the aligned disparity agrees to float level."""
     from stereo_rcnn_amd import fixture
     l, r, info = fixture.make_inputs(seed, 375, 1242)
     calib, poses, boxes, kp = _scene(n, seed)
-    st, dis, st_ref, dis_ref, ex = _run_both(dev, l, r, info, calib, poses, boxes, kp)
+    st, dis, st_ref, dis_ref, ex, search = _run_both(dev, l, r, info, calib, poses, boxes, kp, search=True)
     assert torch.equal(st, st_ref)
+    assert torch.equal(search['count'].long(), ex['weight'].sum(1).long())           # same lattice pixels per object
+    live = [i for i in range(n) if st[i] == 1]
+    assert torch.equal(search['coarse_depth'], ex['depth_enum'])                      # hypotheses bit-equal
+    f_c, w_c = _tie_audit(search, ex['coarse_cost'], 'coarse', live)
+    same_c = [i for i in live if int(_first_argmin(search['coarse_cost'])[i]) == int(_first_argmin(ex['coarse_cost'])[i])]
+    f_f, w_f = _tie_audit(search, ex['fine_cost'], 'fine', same_c)
+    same = [i for i in same_c if int(_first_argmin(search['fine_cost'][:20])[i]) == int(_first_argmin(ex['fine_cost'])[i])]
     d = (dis - dis_ref).abs()
-    # the argmin over 50+20 hypotheses is discrete: identical index -> float-level agreement;
-    # a flipped near-tie moves the result by one 0.05 m fine step (a few 1e-2 px at most here)
-    exact = d < 1e-3
-    assert float(exact.float().mean()) >= 0.8, (d, dis, dis_ref)
-    fb = 721.5377 * 0.5327
-    step_px = fb * 0.05 / (ex['fine_depth'] ** 2) * 1.5 + 1e-3 if ex else None
-    assert bool((d <= torch.clamp(step_px, min=2e-3)).all()), (d, step_px)
+    dmax = float(d[same].max()) if same else 0.0
+    cost_rel = float(((search['coarse_cost'] - ex['coarse_cost']).abs() / ex['coarse_cost'].clamp(min=1e-30))[:, live].max()) if live else 0.0
+    print("dense-align argmin audit: %d objects, %d coarse / %d fine index flips (largest near-tie margin %.2e), max |cost - oracle| / cost "
+          "%.2e, max |disparity - oracle| on equal indices %.2e px" % (len(live), f_c, f_f, max(w_c, w_f), cost_rel, dmax))
+    assert dmax < 2e-5, dmax                                                          # float-level: same index, same formula
+    assert cost_rel < 1e-5, cost_rel
+    # measured on these fixtures (91 objects): NO flip at all, costs within 2.5e-7 of the oracle's, disparities bit-equal -- since
+    # dis_init / best_dis follow torch's scalar / tensor = tensor.reciprocal() * scalar (one ulp in the depth hypotheses was what
+    # round 5's "80 % exact" allowance covered).  The audit above stays as the rule for a flip on other data.
+    assert f_c == 0 and f_f == 0, (f_c, f_f)
 
 
 def test_align_parallel_no_valid_pixels(dev):
@@ -103,8 +150,9 @@ def test_planted_disparity_is_recovered(dev):
 @pytest.mark.parametrize("seed", [2, 3])
 def test_align_parallel_vs_reference_code_golden(dev, seed):
     """HIP dense alignment against the REFERENCE'S OWN align_parallel (tests/golden/reference_misc.npz, written by
-    tests/golden/make_reference_golden.py): same status, aligned disparity equal up to one fine depth step on a flipped
-    near-tie of the discrete argmin."""
+    tests/golden/make_reference_golden.py): same status; the depth the reference chose is the depth this search chose, or a
+    hypothesis whose cost -- in this call's own cost vectors -- ties with the chosen one within the summation-order bound (the
+    golden holds the reference's result, not its cost vectors)."""
     import os
     from oracle.dense_align import KITTI_DEMO_CALIB as calib       # calibration constants only (== the reference's demo/calib.txt)
     from stereo_rcnn_amd import fixture
@@ -112,11 +160,36 @@ def test_align_parallel_vs_reference_code_golden(dev, seed):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_misc.npz'))
     t = 'da%d_' % seed
     l, r, info = fixture.make_inputs(seed, 375, 1242)
-    st, dis = align_parallel(calib, float(info[0, 2]), l.to(dev), r.to(dev), torch.from_numpy(g[t + 'boxes']).to(dev),
-                             torch.from_numpy(g[t + 'kpts']).to(dev), torch.from_numpy(g[t + 'poses']).to(dev))
+    st, dis, search = align_parallel(calib, float(info[0, 2]), l.to(dev), r.to(dev), torch.from_numpy(g[t + 'boxes']).to(dev),
+                                     torch.from_numpy(g[t + 'kpts']).to(dev), torch.from_numpy(g[t + 'poses']).to(dev), return_search=True)
     torch.cuda.synchronize()
+    search = {k: v.cpu() for k, v in search.items()}
     assert np.array_equal(st.cpu().numpy(), g[t + 'status'])
-    d = np.abs(dis.cpu().numpy() - g[t + 'best_dis'])
-    z = g[t + 'poses'][:, 2]
-    step_px = 721.5377 * 0.5327 * 0.05 / np.maximum(z - 13.0, 1.5) ** 2 * 1.5 + 2e-3     # one fine step at the nearest bracket depth
-    assert float((d < 1e-3).mean()) >= 0.8 and bool((d <= step_px).all()), (d, step_px)
+    fbs = float(calib.p2[0, 3] - calib.p3[0, 3])                   # best_dis = fb / (z scale) + 0.5 = (p2_03 - p3_03) / z + 0.5
+    bound = _order_bound(search['count'])
+    ic, i_f = _first_argmin(search['coarse_cost']), _first_argmin(search['fine_cost'][:20])
+    dis, flips, worst, dmax = dis.cpu().numpy(), 0, 0.0, 0.0
+    for r_ in range(len(dis)):
+        if g[t + 'status'][r_] != 1:
+            continue
+        if abs(float(dis[r_]) - float(g[t + 'best_dis'][r_])) < 2e-5:
+            dmax = max(dmax, abs(float(dis[r_]) - float(g[t + 'best_dis'][r_])))
+            continue
+        flips += 1
+        z_ref = fbs / (float(g[t + 'best_dis'][r_]) - 0.5)
+        fd = search['fine_depth'][:, r_]
+        j = int((fd - z_ref).abs().argmin())
+        if abs(float(fd[j]) - z_ref) < 2e-3:                       # the reference's depth is one of this search's fine hypotheses
+            a, cost = int(i_f[r_]), search['fine_cost']
+        else:                                                      # ... or lies in the fine bracket of another coarse hypothesis
+            cd = search['coarse_depth'][:, r_]
+            m = torch.round((z_ref - (cd - 0.5)) / 0.05)
+            ok = ((cd - 0.5 + 0.05 * m - z_ref).abs() < 2e-3) & (m >= 0) & (m < 20)
+            assert bool(ok.any()), "object %d: the reference's depth %.4f is on none of this search's grids" % (r_, z_ref)
+            j = int(torch.nonzero(ok)[0])
+            a, cost = int(ic[r_]), search['coarse_cost']
+        rel = abs(float(cost[j, r_]) - float(cost[a, r_])) / max(float(cost[a, r_]), 1e-30)
+        worst = max(worst, rel)
+        assert rel <= float(bound[r_]), "object %d: the reference chose a hypothesis that does not tie with ours (%.3e > %.3e)" % (r_, rel, float(bound[r_]))
+    print("dense-align vs reference golden: %d objects, %d flips (largest near-tie margin %.2e), max |disparity - reference| elsewhere %.2e px"
+          % (int((g[t + 'status'] == 1).sum()), flips, worst, dmax))

@@ -190,7 +190,7 @@ def test_native_launch_program_replay_matches_eager(dev, precision):
             pa2 = [t.clone() for t in m(*a)[:8]]
         torch.cuda.synchronize()
     plan = m._get_plan(1, a[0].shape[2], a[0].shape[3])
-    prog = plan.programs[(precision, True, plan._par())][0]
+    prog = plan.programs[plan.program_key(precision, True)][0]
     n = _lib.lib().srcnn_program_size(prog)
     assert n > 150, n                       # ~230 kernel launches + the fork / join nodes
     for x, y, z, w_, v in zip(ea, pa1, pa2, eb, pb):
@@ -890,11 +890,11 @@ def test_calibration_over_several_frames_and_program_invalidation(dev):
         a = [t.clone() for t in m(l, r, info)[:8]]                        # calibrated on this pair, program recorded
         s1 = dict(m._weights.shifts)
         plan = m._get_plan(1, l.shape[2], l.shape[3])
-        assert ('f16x3', True, plan._par()) in plan.programs
+        assert plan.program_key('f16x3', True) in plan.programs
         s8 = m.calibrate_activation_scales([(l, r, info), (l * 8.0, r * 8.0, info)])
         assert m._weights.calib_epoch >= 2
         b = [t.clone() for t in m(l, r, info)[:8]]                        # stale program dropped, re-recorded with the new scales
-        assert plan._epoch[0] == m._weights.calib_epoch and ('f16x3', True, plan._par()) in plan.programs
+        assert plan._epoch[0] == m._weights.calib_epoch and plan.program_key('f16x3', True) in plan.programs
         c = [t.clone() for t in m(l * 8.0, r * 8.0, info)[:8]]
     torch.cuda.synchronize()
     assert engine.range_flag(reset=True) == (0, None)

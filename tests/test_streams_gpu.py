@@ -79,7 +79,7 @@ def test_forward_is_bit_identical_with_and_without_branch_streams(dev):
             torch.cuda.synchronize()
             plan = m._get_plan(1, l.shape[2], l.shape[3])
             assert plan._par() == (n == 1)
-            sizes[n] = _lib.lib().srcnn_program_size(plan.programs[('f16x3', True, n == 1)][0])
+            sizes[n] = _lib.lib().srcnn_program_size(plan.programs[plan.program_key('f16x3', True, par=(n == 1))][0])
             if n in outs:
                 for a, b in zip(outs[n], o):
                     assert torch.equal(a, b)
