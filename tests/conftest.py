@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, 'tests') not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
 def pytest_configure(config):
@@ -32,3 +34,15 @@ def _serving_plans():
         from stereo_rcnn_amd import serving
         serving.load_shipped_plans()
     yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Largest float deviations the parity tests observed (tests/tolerances.py): printed, and left in gpurun_out/ on a GPU box."""
+    try:
+        import tolerances
+    except ImportError:
+        from tests import tolerances
+    m = tolerances.measured()
+    if m:
+        print("\nmeasured maxima (tests/tolerances.py): " + ", ".join("%s %.2e" % (k, m[k]) for k in sorted(m)))
+        tolerances.dump(os.path.join(ROOT, 'gpurun_out', 'measured_tolerances.json'))

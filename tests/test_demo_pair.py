@@ -14,6 +14,8 @@ import numpy as np
 import pytest
 import torch
 
+import tolerances as tol_
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 NAMES = ['rois_right', 'cls_prob', 'bbox_pred', 'dim_orien_pred', 'kpts_prob', 'left_border_prob', 'right_border_prob']
 
@@ -160,17 +162,18 @@ def test_hip_forward_on_demo_pair_vs_reference_code(dev, pair, gold, precision):
     rl, rr = out[0][0].cpu(), out[1][0].cpu()
     d = (ref_l[:, None, 1:] - rl[None, :, 1:]).abs().amax(2)
     best, idx = d.min(1)
-    ok = best < 5e-2
+    ok = best < tol_.PROPOSAL_MATCH_PX
     frac = float(ok.float().mean())
-    errs = {'rois_right': float((rr[idx[ok]] - ref_r[ok]).abs().max())}
+    tol_.observe('proposal_match_px', best[ok].max())
+    errs = {'rois_right': tol_.observe('proposal_match_px', (rr[idx[ok]] - ref_r[ok]).abs().max())}
     for k, t in (('cls_prob', out[2][0]), ('bbox_pred', out[3][0]), ('dim_orien_pred', out[4][0]), ('kpts_prob', out[5]),
                  ('left_border_prob', out[6]), ('right_border_prob', out[7])):
-        errs[k] = float((t.cpu()[idx[ok]] - _rows(gold[k])[ok]).abs().max())
+        errs[k] = tol_.observe('e2e_' + k, (t.cpu()[idx[ok]] - _rows(gold[k])[ok]).abs().max())
     print('demo pair, %s engine vs reference code: matched proposals %d/300, max abs errors %s'
           % (precision, int(ok.sum()), {k: '%.1e' % v for k, v in errs.items()}))
     assert frac >= 0.97, frac
     assert errs['bbox_pred'] < 1e-4 and errs['dim_orien_pred'] < 1e-4, errs
-    assert all(v < 2e-3 for v in errs.values()), errs
+    assert errs.pop('rois_right') < tol_.PROPOSAL_MATCH_PX and all(v < tol_.HEAD_OUTPUT_E2E for v in errs.values()), errs
 
 
 @pytest.mark.gpu
@@ -211,9 +214,11 @@ def test_hip_decode_class_nms_and_borders_on_demo_pair(dev, pair, gold):
     info = torch.tensor([[600.0, 1987.0, 1.6]], device=dev)
     det = hpost.decode_detections(t('rois_left'), t('rois_right'), t('cls_prob'), t('bbox_pred'), t('dim_orien_pred'),
                                   t('kpts_prob'), t('left_border_prob'), t('right_border_prob'), info)
-    for a, b, tol in (('scores', 'dec_scores', 0.0), ('boxes_left', 'dec_boxes_left', 2e-3), ('boxes_right', 'dec_boxes_right', 2e-3),
-                      ('kpts', 'dec_kpts', 2e-3), ('dim_orien', 'dec_dim_orien', 1e-6)):
+    for a, b, tol in (('scores', 'dec_scores', 0.0), ('boxes_left', 'dec_boxes_left', tol_.DECODED_PX), ('boxes_right', 'dec_boxes_right', tol_.DECODED_PX),
+                      ('kpts', 'dec_kpts', tol_.DECODED_PX), ('dim_orien', 'dec_dim_orien', 1e-6)):
         err = float(np.abs(det[a].cpu().numpy() - gold[b].reshape(tuple(det[a].shape))).max())
+        if tol == tol_.DECODED_PX:
+            tol_.observe('decoded_px', err)
         assert err <= tol, (a, err)
     keep_idx, num = hpost.class_nms_device(det, 1, 0.05)
     k = int(num[0])
@@ -223,11 +228,11 @@ def test_hip_decode_class_nms_and_borders_on_demo_pair(dev, pair, gold):
     ws = torch.empty(int(L.srcnn_box3d_workspace_bytes(300, 1242)), dtype=torch.uint8, device=dev)
     _lib.check(L.srcnn_infer_boundary(rec.data_ptr(), 300, _lib.REC_COLS, 1242, ws.data_ptr(), ws.numel(), _lib.stream()))
     body = rec.cpu().numpy()[1:k + 1]
-    assert float(np.abs(body[:, 1:5] - gold['cls_dets_left'][:, :4]).max()) < 2e-3
-    assert float(np.abs(body[:, 5:9] - gold['cls_dets_right'][:, :4]).max()) < 2e-3
+    assert tol_.observe('decoded_px', np.abs(body[:, 1:5] - gold['cls_dets_left'][:, :4]).max()) < tol_.DECODED_PX
+    assert tol_.observe('decoded_px', np.abs(body[:, 5:9] - gold['cls_dets_right'][:, :4]).max()) < tol_.DECODED_PX
     assert np.array_equal(body[:, 0], gold['cls_dets_left'][:, 4])
     # borders: integers (image columns) or regressed values -- equal up to the decode's expf ulp
-    assert float(np.abs(body[:, 14:19] - gold['pipe_kpts_after_borders']).max()) < 2e-3
+    assert tol_.observe('decoded_px', np.abs(body[:, 14:19] - gold['pipe_kpts_after_borders']).max()) < tol_.DECODED_PX
 
 
 @pytest.mark.gpu
