@@ -53,6 +53,9 @@ def parse():
                     help='walk the Python launch code every forward instead of replaying the native launch list '
                          '(srcnn_program_run; default: replay -- same launches and streams, ~230 ctypes calls fewer per forward)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true',
+                    help='skip the `parity` block (demo pair, 3-D boxes, dense-alignment indices against the reference goldens / oracle; ~25 s)')
+    ap.add_argument('--no-sustained', action='store_true', help='skip the `sustained` leg (2 s soak + 300 steps of the headline loop)')
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f16x3',
                     help="conv engine: f16x3 = fp32-class error-compensated split on the f16 MFMA (default, "
                          "passes the same parity tests), f32 = exact fp32 MFMA")
@@ -155,13 +158,16 @@ def csrc_hash():
 CONV_KERNELS = ('conv_f16s_kernel', 'conv_f16x3_kernel', 'conv_group_kernel', 'conv_chain_kernel')
 
 
-def measure_traffic_live(plans_path, steps=3, timeout_s=240):
+def measure_traffic_live(plans_path, steps=3, timeout_s=240, per_kernel=None):
     """HBM-side bytes of the conv engine per step, measured in THIS run on THIS box: two child processes of this script
     (`--pmc-child`: plans preloaded, `steps` forwards one at a time, nothing else) under rocprofv3's counter collection, one
     pass per counter as the MI355X guide prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Returns
-    (fetch_kb_per_step, write_kb_per_step, conv_launches_per_step) or None when rocprofv3 is unavailable or a pass fails."""
+    (fetch_kb_per_step, write_kb_per_step, conv_launches_per_step) or None when rocprofv3 is unavailable or a pass fails.
+    per_kernel (a dict, filled in place): short kernel name -> {'calls', 'us', 'fetch_kb', 'write_kb'} per forward for EVERY kernel
+    of the forward (durations from the FETCH_SIZE pass's kernel trace: every launch alone on the chip) -- roofline.non_conv."""
     import csv
     import glob
+    import re
     import shutil
     import subprocess
     import tempfile
@@ -170,6 +176,21 @@ def measure_traffic_live(plans_path, steps=3, timeout_s=240):
         return None
     out = {}
     launches = None
+
+    def short(name):
+        name = re.sub(r'^void ', '', name)
+        name = re.sub(r'\(.*$', '', name)                     # drop the argument list
+        return name.replace('srcnn::', '')
+
+    def steady(rows, key):
+        """the rows of the `steps` measured forwards: the child brackets them with null_kernel marker launches (the warm-up
+        forwards before the first marker -- calibration on the fp32 engine, in-situ tuning -- are not the forward)"""
+        rows = sorted(rows, key=key)
+        marks = [i for i, r in enumerate(rows) if 'null_kernel' in r['Kernel_Name']]
+        if len(marks) != steps + 1:
+            raise ValueError('expected %d markers, found %d' % (steps + 1, len(marks)))
+        return [r for i, r in enumerate(rows) if marks[0] < i < marks[-1] and 'null_kernel' not in r['Kernel_Name']]
+
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix='srcnn_pmc_', dir='/tmp')
         try:
@@ -181,20 +202,95 @@ def measure_traffic_live(plans_path, steps=3, timeout_s=240):
             if r.returncode != 0 or not files:
                 return None
             total, seen = 0.0, set()
-            for f in files:
-                for row in csv.DictReader(open(f)):
-                    name = row['Kernel_Name']
-                    if row['Counter_Name'] == counter and any(k in name for k in CONV_KERNELS):
-                        total += float(row['Counter_Value'])
-                        seen.add(row['Dispatch_Id'])
-            # the child runs one untimed forward first (workspace sizing); every forward has the same launches
-            out[counter] = total / (steps + 1)
-            launches = len(seen) // (steps + 1)
+            crow = [row for f in files for row in csv.DictReader(open(f)) if row['Counter_Name'] == counter]
+            for row in steady(crow, lambda q: int(q['Dispatch_Id'])):
+                name = row['Kernel_Name']
+                if any(k in name for k in CONV_KERNELS):
+                    total += float(row['Counter_Value'])
+                    seen.add(row['Dispatch_Id'])
+                if per_kernel is not None:
+                    e = per_kernel.setdefault(short(name), {'calls': 0.0, 'us': 0.0, 'fetch_kb': 0.0, 'write_kb': 0.0})
+                    e['fetch_kb' if counter == 'FETCH_SIZE' else 'write_kb'] += float(row['Counter_Value']) / steps
+            if per_kernel is not None and counter == 'FETCH_SIZE':
+                trow = [row for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True) for row in csv.DictReader(open(f))]
+                for row in steady(trow, lambda q: int(q['Start_Timestamp'])):
+                    e = per_kernel.setdefault(short(row['Kernel_Name']), {'calls': 0.0, 'us': 0.0, 'fetch_kb': 0.0, 'write_kb': 0.0})
+                    e['calls'] += 1.0 / steps
+                    e['us'] += (float(row['End_Timestamp']) - float(row['Start_Timestamp'])) / 1e3 / steps
+            out[counter] = total / steps
+            launches = len(seen) // steps
         except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return out['FETCH_SIZE'], out['WRITE_SIZE'], launches
+
+
+# non-conv kernel families of one forward (roofline.non_conv): label -> (kernel-name prefixes, what bounds it)
+NON_CONV_FAMILIES = [
+    ('stem_pack', ('stem_pack',), 'hbm'),
+    ('max_pool', ('maxpool3x3s2',), 'hbm'),
+    ('fpn top-down add', ('upsample_add', 'subsample2'), 'hbm'),
+    ('split-K reductions', ('splitk_reduce',), 'hbm'),
+    ('rpn scores', ('rpn_score',), 'hbm'),
+    ('proposal: top-6000 selection', ('tk_hist', 'tk_compact', 'tk_rank', 'gather_decode', 'intersect_pad'), 'latency'),
+    ('proposal: NMS mask', ('pair_mask',), 'hbm'),
+    ('proposal: NMS greedy scan', ('greedy_scan',), 'latency'),
+    ('roi_align', ('pyramid_roi_align',), 'hbm'),
+    ('head tails', ('box_head_tail', 'kpts_tail'), 'hbm'),
+    ('decode + class NMS', ('decode_detections', 'class_select_sort', 'map_keep'), 'latency'),
+]
+HBM_ACHIEVABLE = 6.3e12          # B/s: MI355X_MICROARCH.md (float4 copy; the peak the guide quotes against)
+
+
+def non_conv_algorithmic_mb(plan):
+    """Compulsory bytes (MB) of the streaming non-conv families from the plan's shapes: every input element read once, every output
+    written once, 4 B each (both activation formats)."""
+    N, B = plan.N, plan.B
+    sh, sw = plan.stem_hw
+    ph, pw = plan.c1_hw
+    hw = plan.layer_hw
+    tops = [hw[3], hw[2], hw[1]]
+    fpn = sum(N * 256 * 4 * (t[0] * t[1] + 2 * l[0] * l[1]) for t, l in zip(tops, [hw[2], hw[1], hw[0]]))
+    fpn += N * 256 * 4 * (plan.rpn_shapes[4][0] * plan.rpn_shapes[4][1]) * 2                      # P6 = subsampled P5
+    rpn = sum(max(n, 1) * B * a * b * 24 * 4 for n, (a, b) in zip(plan.rpn_nparts, plan.rpn_shapes)) + B * plan.A * 8 * 4
+    G = plan.kp_logits.shape[1]
+    return {'max_pool': N * 64 * 4 * (sh * sw + ph * pw) / 1e6, 'fpn top-down add': fpn / 1e6, 'rpn scores': rpn / 1e6,
+            'stem_pack': (2 * B * 3 * plan.H * plan.W * 4 + N * (plan.H + 6) * (plan.W + 8) * 16) / 1e6,
+            'head tails': (plan.R * G * G * 6 * 4 + plan.R * (4 * G + 2 * G) * 4 + 2 * plan.R * plan.w.fc.cout * 4) / 1e6}
+
+
+def non_conv_table(per_kernel, alg_mb=None):
+    """roofline.non_conv from measure_traffic_live's per-kernel rows: per family the launches, the time alone on the chip, the
+    HBM-side bytes the PMC counters saw (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction), GB/s and the fraction of 6.3 TB/s."""
+    rows, used = [], set()
+    for label, prefixes, bound in NON_CONV_FAMILIES:
+        ks = [k for k in per_kernel if any(k.startswith(p) for p in prefixes)]
+        if not ks:
+            continue
+        used.update(ks)
+        us = sum(per_kernel[k]['us'] for k in ks)
+        by = sum(2.0 * per_kernel[k]['fetch_kb'] + per_kernel[k]['write_kb'] for k in ks) * 1024.0
+        alg = (alg_mb or {}).get(label)
+        use = alg * 1e6 if alg else by                      # the roofline figure uses the compulsory bytes where the shapes give them
+        rows.append({'family': label, 'kernels': sorted(ks), 'launches': round(sum(per_kernel[k]['calls'] for k in ks), 1), 'us': round(us, 1),
+                     'algorithmic_mb': (round(alg, 2) if alg else None), 'hbm_side_mb_pmc': round(by / 1e6, 2),
+                     'gb_per_s': round(use / max(us, 1e-9) / 1e3, 1),
+                     'frac_of_6.3_tb_s': round(use / max(us, 1e-9) * 1e6 / HBM_ACHIEVABLE, 4), 'bound': bound})
+    other = [k for k in per_kernel if k not in used and not any(c in k for c in CONV_KERNELS)]
+    if other:
+        us = sum(per_kernel[k]['us'] for k in other)
+        by = sum(2.0 * per_kernel[k]['fetch_kb'] + per_kernel[k]['write_kb'] for k in other) * 1024.0
+        rows.append({'family': 'other (runtime fills / copies)', 'kernels': sorted(other), 'launches': round(sum(per_kernel[k]['calls'] for k in other), 1),
+                     'us': round(us, 1), 'algorithmic_mb': None, 'hbm_side_mb_pmc': round(by / 1e6, 2), 'gb_per_s': round(by / max(us, 1e-9) / 1e3, 1),
+                     'frac_of_6.3_tb_s': round(by / max(us, 1e-9) * 1e6 / HBM_ACHIEVABLE, 4), 'bound': 'latency'})
+    return {'rows': sorted(rows, key=lambda r: -r['us']), 'total_us': round(sum(r['us'] for r in rows), 1),
+            'note': 'every non-conv kernel of one step (forward + decode + class NMS), each launch ALONE on the chip (one pair at a time, in-situ '
+                    'plans: rocprofv3 --kernel-trace --pmc children of this run, marker-bracketed steady-state steps).  gb_per_s = compulsory bytes '
+                    '(`algorithmic_mb`: every input read once, every output written once) / time where the shapes give them, else the HBM-side '
+                    'traffic the PMC counters saw (`hbm_side_mb_pmc` = 2 x FETCH_SIZE + WRITE_SIZE; the x 2 is calibrated for 16-byte-per-lane '
+                    'streaming reads only, MI355X_MICROARCH.md).  `latency` families are serial / few-workgroup kernels whose time is not their '
+                    'bytes; split-K reductions exist in this execution only (the shipped plans of the headline split K less often)'}
 
 
 def relaunch_under_torchrun(args):
@@ -610,9 +706,17 @@ def main():
         assert plans_loaded, "--pmc-child needs the parent's tuned plans"
         model.use_program = False
         with torch.no_grad():
-            for _ in range(args.pmc_child + 1):
-                model(im_l, im_r, im_info)
+            Lc = _lib.lib()
+            Lc.srcnn_debug_null_launches.argtypes, Lc.srcnn_debug_null_launches.restype = [ctypes.c_int, ctypes.c_void_p], ctypes.c_int
+            for k in range(args.pmc_child + 2):
+                if k >= 2:                                       # two warm-up forwards (calibration, in-situ tuning), then marker-bracketed ones
+                    Lc.srcnn_debug_null_launches(1, _lib.stream())
+                o = model(im_l, im_r, im_info)
+                det = hpost.decode_detections(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], im_info[0:1])     # the step's tail: decode + class NMS
+                hpost.class_nms_device(det, 1, 0.05)
                 torch.cuda.synchronize()
+            Lc.srcnn_debug_null_launches(1, _lib.stream())
+            torch.cuda.synchronize()
         return
     streams = sstreams.main_streams(S) if S > 1 else [None]
 
@@ -750,6 +854,26 @@ def main():
                                  'detection records runs on a side stream, one per %d steps, overlapped with the following forwards' % G}
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el[0])
+
+        # ---- `sustained`: the same headline loop once the chip is warm -- a 2 s soak, then >= 300 steps (the 20-step default region
+        #      is 0.13 s: boost clocks; profiles/bench_r04_f16x3_60steps.json put the warm figure ~3 % lower)
+        sustained = None
+        if not args.no_sustained and world == 1 and wl['flow'] != '3d':
+            ts = time.perf_counter()
+            soak_steps = 0
+            while time.perf_counter() - ts < 2.0:
+                run_steps(4 * S)
+                soak_steps += 4 * S
+                torch.cuda.synchronize()
+            ns = max(300, args.steps)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            run_steps(ns)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+            sustained = {'value': round(ns * B / dts, 3), 'unit': 'stereo pairs/s', 'steps': ns, 'ms_per_step': round(dts / ns * 1e3, 3),
+                         'soak': '%d steps over 2 s before the timed %d' % (soak_steps, ns),
+                         'note': 'the headline loop (same regime, same plans) after a warm soak; `value` is the driver\'s K steps'}
 
         def serial_step():
             step(0, gather=False)
@@ -903,13 +1027,14 @@ def main():
             import glob
             tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_*_traffic.json')))
             live = None
+            per_kernel = {}
             if args.config == 1 and world == 1 and not args.no_pmc and args.precision == 'f16x3':
                 import tempfile
                 pf = args.plans if plans_loaded else os.path.join(tempfile.gettempdir(), 'srcnn_bench_plans_%d.json' % os.getpid())
                 if not plans_loaded:
                     engine.save_plans(pf)
                 torch.cuda.synchronize()
-                live = measure_traffic_live(pf)
+                live = measure_traffic_live(pf, per_kernel=per_kernel)
             if live is not None and live[2] == launches:
                 traffic = round((2.0 * live[0] + live[1]) * 1024.0 / max(launches, 1))
                 traffic_note = ('bytes per conv launch, HBM side, MEASURED IN THIS RUN on these sources: (2 x FETCH_SIZE + WRITE_SIZE) of '
@@ -973,6 +1098,7 @@ def main():
                                            'headline_frac_of_it': round(alg_step / (head_ms * 1e-3) * issued / layer_table.SUSTAINED_MFMA_PEAK[args.precision], 4),
                                            'source': layer_table.SUSTAINED_SOURCE if args.precision == 'f16x3' else 'fp32 MFMA: the spec peak is sustained (MI355X_MICROARCH.md)',
                                            'note': '`frac` above stays against the 2.5 PF dense peak; this is what the same instruction stream sustains on this power-limited chip'},
+                        'non_conv': (non_conv_table(per_kernel, non_conv_algorithmic_mb(model._get_plan(B, int(im_l.shape[2]), int(im_l.shape[3]), 0))) if (live is not None and per_kernel) else None),
                         'backbone': layer_table.backbone(rows, args.precision),
                         'layers_summary': layer_table.summary(rows),
                         'layers_note': 'per conv launch alone on the chip: own bound = max(MFMA flops issued / dense MFMA peak, compulsory '
@@ -1114,6 +1240,11 @@ def main():
         }
         if args.config != 1:
             res['value_ms_note'] = 'ms_per_step is per batch of %d pairs; value = pairs/s' % B
+        if sustained is not None:
+            res['sustained'] = sustained
+        if not args.no_parity and world == 1 and args.config == 1:
+            import bench_parity
+            res['parity'] = bench_parity.parity_block(dev, args.precision)
         if not args.no_cpu_baseline and world == 1:          # the CPU path timed beside it: rank 0 at N = 1 only
             res['cpu_baseline'] = cpu_baseline(args.config, src_h, src_w)
         print(json.dumps(res), flush=True)

@@ -149,6 +149,8 @@ def lib():
             raise RuntimeError(
                 "libsrcnn_hip.so not found at %s - build it with `python -m stereo_rcnn_amd.csrc.build` "
                 "(or __graft_entry__.build()). The product path has no fallback." % LIB_PATH)
+        from . import streams
+        streams.hip_may_start()            # the hardware-queue count HIP will start with is decided no later than here
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is missing

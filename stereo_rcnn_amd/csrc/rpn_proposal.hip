@@ -211,6 +211,12 @@ __global__ __launch_bounds__(256) void tk_hist_kernel(const float *__restrict__ 
     for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x)
         if (lh[i]) sink += __hip_atomic_fetch_add(&gh[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink) : "memory");        // (the operand keeps the returning form of the atomics alive)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+    // under the HIP memory model relaxed atomics order nothing; that this hand-off needs no device-scope release is a
+    // property of gfx950 (agent-scope atomics and sc1 loads are performed at the cross-XCD coherence point; an atomic that has
+    // returned has been performed).  The library builds for gfx950 only -- any other target must not compile this silently.
+#error "tk_hist_kernel's fence-free grid hand-off is validated for gfx950 only (tests/test_host_logic.py checks its ISA)"
+#endif
     __syncthreads();
     // the last workgroup to arrive picks the digit (every image of the batch has its own arrival counter)
     if (threadIdx.x == 0)
@@ -615,7 +621,6 @@ int srcnn_proposal_layer(const float *probs, const float *deltas, int B, int num
         const int G = 256;
         static const int sshift[3] = {21, 10, 0}, swidth[3] = {11, 11, 10};
         static const unsigned smask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
-        SRCNN_REQUIRE(B <= 64, "batches of more than 64 pairs not supported by the proposal layer");
         unsigned *arrivals = hist + (size_t)B * TK_BINS;
         for (int p = 0; p < 3 && !(skip & 1); ++p)
             SRCNN_LAUNCH(tk_hist_kernel, dim3(G, B), dim3(256), 0, st, probs, num_anchors, state, hist, arrivals, 0,

@@ -198,7 +198,7 @@ RPN_HEAD_FUSION = _os.environ.get('SRCNN_RPN_HEAD_FUSION', '1') != '0'
 # (srcnn_conv2d_group): 'all' = one launch for P2..P6 behind the last smoothing conv, 'small' = P3..P6 in one launch (76 + 20 + 6 + 292
 # tiles of 256x256: launches that cannot fill 256 CUs on their own) and P2 by itself, '0' = one launch per level.  Bit-identical.
 RPN_GROUP = _os.environ.get('SRCNN_RPN_GROUP', 'small')
-RPN_GROUP_TILE = (4, 4, 8, 2)
+RPN_GROUP_TILE = tuple(int(c) for c in _os.environ.get('SRCNN_RPN_GROUP_TILE', '4482'))       # (tile_mr, tile_nr, waves, stages): 4482 or 2282
 # A/B switch: the FPN top-down addition (_upsample_add) computed inside the lateral 1x1 conv's epilogue (conv2d(up=...),
 # srcnn_conv_desc.up_top) whenever the lateral is launched inline behind its top map -- i.e. with several forwards in flight; a
 # lone forward keeps the laterals on a side stream, early, and the separate srcnn_upsample_add.  Bit-identical either way.

@@ -145,7 +145,12 @@ class _StereoRCNN(nn.Module):
         streams (each stream uses its own slot).
         `kpts=False` (extension, stereo_rcnn_amd.pipeline): leave the keypoint branch out of the forward -- the three keypoint
         outputs are None -- because the caller will run it on the detections that survive class NMS only
-        (plan.Plan.kpts_for_kept; the reference's scripts read no other row: demo.py:196-257)."""
+        (plan.Plan.kpts_for_kept; the reference's scripts read no other row: demo.py:196-257).
+        INPUT OWNERSHIP: the forward reads im_left_data / im_right_data / im_info WHERE THEY ARE (no copy; a captured
+        hipGraph is the exception) -- asynchronously, on the calling stream, and possibly AGAIN later: a pair whose SPLIT16 range
+        guard trips is re-run on the fp32 engine from the same tensors (pipeline), and a re-calibration reads them once more.
+        The caller must leave them unmodified until it has consumed this forward's results (for the streamed entry points: until
+        the slot's pair has been collected).  Callers that refill one input buffer per frame in place should pass a clone."""
         if self.training:
             raise NotImplementedError("training forward is out of scope; call .eval()")
         B, _, H, W = im_left_data.shape

@@ -571,8 +571,14 @@ def _note_guard_trip(model, im_left_data, slot, may_recalibrate=True):
         with torch.no_grad():
             plan.calibrate(merge=True)
         if any(first.get(g, k) - k > MAX_SHIFT_WIDENING for g, k in w.shifts.items()):
+            changed = w.shifts != before[0] or w.fuse_shortcut != before[1]
             w.shifts, w.fuse_shortcut, w.calibration_max = before[0], before[1], before[2]
-            w.calib_epoch += 1
+            if changed:
+                w.calib_epoch += 1             # (calibrate() bumped it for the widened scales: the restored ones are another epoch)
+            # a rejected widening is remembered -- the trip counter starts over, so an outlier frame costs one fp32
+            # re-run per trip, not a calibration forward + a device sync + re-recorded launch programs on every one
+            w.guard_trips = 0
+            w.rejected_widenings = getattr(w, 'rejected_widenings', 0) + 1
             log.warning('SPLIT16 activation scales NOT widened: the offending frame needs more than %d bits beyond the first calibration '
                         '(an outlier frame); it keeps running on the fp32 engine', MAX_SHIFT_WIDENING)
             return

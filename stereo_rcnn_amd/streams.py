@@ -53,7 +53,7 @@ def ensure_hw_queues(n=HW_QUEUES):
     up with fewer queues (the caller may then use 'dedicated' main streams, or at most GPU_MAX_HW_QUEUES - 1 in flight).
     A smaller GPU_MAX_HW_QUEUES already in the environment is raised unless SRCNN_KEEP_HW_QUEUES=1 says it is deliberate."""
     cur = os.environ.get('GPU_MAX_HW_QUEUES')
-    if torch.cuda.is_initialized():
+    if torch.cuda.is_initialized() or _queues_at_hip_start is not None:
         return _hw_queues() >= n
     if cur is not None and cur.strip().isdigit():
         if int(cur) >= n:
@@ -64,7 +64,29 @@ def ensure_hw_queues(n=HW_QUEUES):
     return True
 
 
-_queues_at_hip_start = None       # GPU_MAX_HW_QUEUES as HIP read it (recorded the first time we see HIP initialised)
+_queues_at_hip_start = None       # GPU_MAX_HW_QUEUES as HIP read it
+
+
+def _env_queues():
+    cur = os.environ.get('GPU_MAX_HW_QUEUES', '4')
+    return int(cur) if cur.strip().isdigit() else 4
+
+
+# the value HIP starts with is the one in the environment when the runtime initialises -- and the runtime may be
+# initialised by the LIBRARY (a HIP call behind _lib.lib()) before torch's lazy init says so.  The count is therefore pinned at
+# the earliest of: this module's import if torch already runs HIP; the moment _lib loads the library (hip_may_start, called
+# before its first call); the first query that finds torch initialised.  Until then the environment may still be changed.
+if torch.cuda.is_initialized():
+    _queues_at_hip_start = _env_queues()
+
+
+def hip_may_start():
+    """_lib calls this right before it loads libsrcnn_hip.so: from here on a library call may start HIP.  Last chance to ask for
+    the serving queue count (as every entry point does through serving.before_hip()); what the environment says now is pinned."""
+    global _queues_at_hip_start
+    if _queues_at_hip_start is None and not torch.cuda.is_initialized():
+        ensure_hw_queues()
+        _queues_at_hip_start = _env_queues()
 
 
 def _hw_queues():

@@ -42,6 +42,26 @@ def test_bench_single_process_line(dev):
         r = d['roofline']
         assert r['traffic'] and 'MEASURED IN THIS RUN' in r['traffic_note'], r['traffic_note']
         assert 0.9 < r['traffic_over_algorithmic'] < 2.0, r['traffic_over_algorithmic']
+        # roofline.non_conv: every non-conv kernel family of the step, alone on the chip, bytes and GB/s
+        nc = r['non_conv']
+        fams = {row['family']: row for row in nc['rows']}
+        for f in ('max_pool', 'fpn top-down add', 'rpn scores', 'roi_align', 'proposal: NMS mask', 'proposal: NMS greedy scan',
+                  'proposal: top-6000 selection', 'decode + class NMS', 'head tails', 'stem_pack'):
+            assert f in fams and fams[f]['us'] > 0 and fams[f]['launches'] >= 1, f
+        assert 2000 < fams['max_pool']['gb_per_s'] < 8000 and fams['max_pool']['algorithmic_mb'] > 100
+        assert not any('at::native' in k for row in nc['rows'] for k in row['kernels'])      # steady-state steps only, no torch op
+    # `sustained` (item 4a): the same loop after a warm soak, >= 300 steps
+    su = d['sustained']
+    assert su['steps'] >= 300 and 0.85 * d['value'] < su['value'] < 1.1 * d['value'], (su, d['value'])
+    # `parity` (item 4b): measured in the run against the reference goldens / oracle
+    pa = d['parity']
+    dp = pa['demo_pair']
+    assert dp['proposals_matched'] == '300/300' and dp['max_abs_err_bbox_pred'] < 1e-4 and dp['max_abs_err_dim_orien_pred'] < 1e-4
+    assert dp['class_nms_keep_list_equal'] is True and dp['scores_equal'] is True and dp['decoded_boxes_max_abs_err_px'] < 2.5e-4
+    assert pa['dense_align']['argmin_index_flips'] == 0 and pa['dense_align']['status_equal'] is True
+    wc = pa['box3d_well_conditioned']
+    assert wc['host_solver_identical_detections_bit_identical'] is True and wc['host_solver_linf_on_well_conditioned']['median'] <= 2.5e-5
+    assert pa['box3d_demo_pair']['alignment_status_equal'] is True and pa['box3d_demo_pair']['linf_final_3d_box']['n'] >= 12
 
 
 
