@@ -525,13 +525,19 @@ def run_config3(args, rank, local_rank, world, use_dist):
         assert int(full.shape[0]) == K * world and n_files >= min(K, len(all_idx)), (tuple(full.shape), n_files)
         objects = int(sum(float(r[0, 0]) for r in records))
         per = lambda key, src: round(src.get(key, 0.0) * 1e3 / max(K, 1), 3)
-        main_busy = max(0.0, timers.get('loop_s', 0.0) - ptimers.get('gpu_wait_s', 0.0))
+        # the loop thread's own blocking: waiting for a pair's worker (async host phases: 'main_wait_s') or, in round 5's arrangement,
+        # in front of the device itself ('gpu_wait_s', which the workers accumulate now)
+        async_host = 'main_wait_s' in ptimers                  # (the dry run drives an injected detector: neither timer exists)
+        main_wait = ptimers.get('main_wait_s', 0.0) if async_host else ptimers.get('gpu_wait_s', 0.0)
+        main_busy = max(0.0, timers.get('loop_s', 0.0) - main_wait)
         host_ms = {'png_decode_and_calib_parse': per('decode_s', timers), 'png_decode_threads': prefetch,
                    'h2d_issue': per('h2d_s', timers), 'newton_cg_solves_wall': per('solve_s', ptimers), 'host_solver_threads': threads,
-                   'result_files_and_record': per('write_s', timers), 'waiting_for_the_gpu': per('gpu_wait_s', ptimers),
+                   'result_files_and_record': per('write_s', timers), 'waiting_for_the_gpu': round(main_wait * 1e3 / max(K, 1), 3),
+                   'workers_waiting_for_the_gpu': per('gpu_wait_s', ptimers), 'async_host_phases': bool(async_host),
                    'main_thread_busy': round(main_busy * 1e3 / max(K, 1), 3),
-                   'note': 'ms per pair on THIS rank; decode is summed over its threads (they run ahead of the loop); main_thread_busy = loop '
-                           'wall time minus time blocked on the device = launching, solves, result files, Python'}
+                   'note': 'ms per pair on THIS rank; decode is summed over its threads (they run ahead of the loop); the Newton-CG solves and the waits in '
+                           'front of a pair\'s device stages run on one worker thread per pair in flight, the result files on a writer thread; '
+                           'main_thread_busy = loop wall time minus the time the loop thread was blocked = launching + Python'}
         dec_rate = prefetch * 1e3 / max(host_ms['png_decode_and_calib_parse'], 1e-6)
         main_rate = 1e3 / max(host_ms['main_thread_busy'], 1e-6)
         cpu_ms = host_ms['png_decode_and_calib_parse'] + host_ms['main_thread_busy'] + host_ms['newton_cg_solves_wall'] * max(threads - 1, 0)
@@ -1175,7 +1181,7 @@ def main():
         if use_dist:
             dist.barrier()
         frame = (im_l, im_r, im_info, calib, (args.height, args.width, 3), float(im_info[0, 2]))
-        nfr = max(8, min(2 * args.steps, 48))
+        nfr = max(8, min(8 * args.steps, 160))          # (40-48 frames were 10 % pipeline fill and drain: profiles/flow3d_breakdown_r06.txt)
         pipeline.HOST_SOLVER_THREADS = sdist.host_solver_threads()
         full3d = {'pairs_in_flight': 4, 'frames_per_rank': nfr, 'ranks': world, 'host_solver_threads_per_rank': pipeline.HOST_SOLVER_THREADS,
                   'numa_pinning': numa}

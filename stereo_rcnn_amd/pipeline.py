@@ -144,6 +144,7 @@ class _Stage3D(object):
         self.event = torch.cuda.Event()
         self.phase = 0               # solver='host': 1 = waiting for the 4-DoF solve, 2 = for the 3-DoF solve, 0 = complete
         self.ctx = None
+        self.worker, self.error, self.done = False, None, None     # streamed flow: a worker thread runs the host phases
 
 
 _stages = {}
@@ -171,7 +172,7 @@ def _lazy(model):
 
 
 def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape, eval_thresh=0.05, class_index=1,
-              dense_align=True, slot=0, solver='device', lazy=None):
+              dense_align=True, slot=0, solver='device', lazy=None, async_host=False):
     """Everything after the forward, asynchronously on the current stream.  out: the forward's tuple; scale: im_info[0, 2] as a
     Python float (passing it spares a device read).  Returns a handle for collect_3d().
     solver='host': only class NMS, record and borders are launched here; the two Newton-CG solves then run on the HOST (the
@@ -200,6 +201,11 @@ def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape,
         st.phase = 1
         st.ctx = (torch.cuda.current_stream(), im_left_data, im_right_data, float(scale), cal, im_h, im_w, float(eval_thresh),
                   bool(dense_align))
+        st.worker, st.error = False, None
+        if async_host and ASYNC_HOST_PHASES:
+            st.done = _threading.Event()
+            st.worker = True
+            _host_executor().submit(_host_phases, st, keep_idx.device.index if keep_idx.device.index is not None else torch.cuda.current_device())
         return st
     assert solver == 'device', solver
     _lib.check(L.srcnn_solve_4dof(st.rec.data_ptr(), n, REC_COLS, im_h, im_w, cal[0], cal[1], cal[2], cal[3],
@@ -223,6 +229,37 @@ def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape,
 
 
 HOST_SOLVER_THREADS = 0          # srcnn_solve_*_records_host: <= 0 = one thread per 8 detections, at most 16
+# Streamed flow, solver='host', OPT-IN (SRCNN_ASYNC_HOST=1): the host phases of a pair (wait for its device stage, 4-DoF solves, record
+# back + dense alignment launch, wait, 3-DoF solves) on a WORKER thread per pair in flight instead of on the loop thread between
+# launches.  Built in round 6 for VERDICT r5 item 8 and measured (profiles/flow3d_async_host_r06.txt, same box): the loop thread's busy
+# time per pair drops 3.55 -> 2.14 ms (its saturation point 282 -> 467 pairs/s) and the throughput does NOT move -- tensor-input flow
+# 6.16 -> 6.08-6.16 ms per pair, configs[3] 138.1 -> 136.7 pairs/s at four in flight, 140.6 -> 123.2 at six (the workers, the 16 PNG
+# decoder threads and the loop share one GIL) -- the flow is GPU-bound at 6.1 ms (7.2 with decode + H2D + files), not loop-bound.
+# Same calls on the same streams in the same order per pair either way.
+ASYNC_HOST_PHASES = _os.environ.get('SRCNN_ASYNC_HOST', '0') != '0'
+_host_pool = None
+import threading as _threading
+_timers_lock = _threading.Lock()
+
+
+def _host_executor():
+    global _host_pool
+    if _host_pool is None:
+        import concurrent.futures as cf
+        _host_pool = cf.ThreadPoolExecutor(max_workers=8, thread_name_prefix='srcnn-host3d')
+    return _host_pool
+
+
+def _host_phases(st, dev_index):
+    """Worker thread: every remaining host phase of one pair, blocking on its own device work only."""
+    try:
+        with torch.cuda.device(dev_index):
+            while st.phase:
+                step_3d(st, block=True, _worker=True)
+    except BaseException as e:          # re-raised by collect_3d on the caller's thread
+        st.error = e
+    finally:
+        st.done.set()
 # host-side accounting of the record flow (bench.py --config 3): a dict {'solve_s', 'gpu_wait_s'} that step_3d / collect_3d add
 # to -- wall seconds of the host Newton-CG calls, and seconds the host sat in event.synchronize() waiting for the device
 TIMERS = None
@@ -231,7 +268,10 @@ TIMERS = None
 def _timed(key, t0):
     if TIMERS is not None:
         import time
-        TIMERS[key] = TIMERS.get(key, 0.0) + time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        with _timers_lock:
+            if TIMERS is not None:
+                TIMERS[key] = TIMERS.get(key, 0.0) + dt
 
 
 def _now():
@@ -239,7 +279,7 @@ def _now():
     return time.perf_counter() if TIMERS is not None else 0.0
 
 
-def step_3d(st, block=True):
+def step_3d(st, block=True, _worker=False):
     """solver='host' handles: run the next host phase.  Phase 1: 4-DoF solves on the pinned record, record back to the device,
     dense alignment launched.  Phase 2: 3-DoF solves.  block=True waits for the device work the phase needs; block=False (the
     streamed flow's opportunistic pass over the pairs in flight) returns at once when that work has not finished -- the host then
@@ -247,6 +287,8 @@ def step_3d(st, block=True):
     at the latest, when the pair's slot is needed (collect_3d blocks)."""
     if st.phase == 0:
         return
+    if getattr(st, 'worker', False) and not _worker:
+        return                                       # a worker thread owns this pair's host phases (collect_3d waits for it)
     if not block and not st.event.query():
         return
     L = _lib.lib()
@@ -295,6 +337,14 @@ def step_3d(st, block=True):
 
 def collect_3d(st):
     """Wait for a launch_3d() handle and turn its record into the object list detect_3d returns."""
+    if getattr(st, 'worker', False):
+        t0 = _now()
+        st.done.wait()
+        _timed('main_wait_s', t0)
+        st.worker = False
+        if st.error is not None:
+            err, st.error = st.error, None
+            raise err
     while st.phase:
         step_3d(st)
     st.ctx = None
@@ -456,7 +506,7 @@ def _plan_of(model, im_left_data, slot):
 
 
 def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, class_index=1, dense_align=True, slot=0,
-                     wait=True, solver='host'):
+                     wait=True, solver='host', async_host=False):
     """The same from the decoded uint8 RGB images on the device: preprocessing fused in front of the forward
     (model.forward_images), then the device 3-D flow.  wait=False returns the handle for collect_3d()."""
     with torch.no_grad():
@@ -466,7 +516,7 @@ def detect_3d_images(model, img_left_u8, img_right_u8, calib, eval_thresh=0.05, 
         scale = float(np.float32(engine.preprocess_size(int(img_left_u8.shape[0]), int(img_left_u8.shape[1]),
                                                         cfg.TEST.SCALES[0])[2]))
         st = launch_3d(out, iml, imr, info, scale, calib, tuple(img_left_u8.shape), eval_thresh, class_index, dense_align, slot,
-                       solver, lazy=_plan_of(model, iml, slot) if lazy else None)
+                       solver, lazy=_plan_of(model, iml, slot) if lazy else None, async_host=async_host and not wait)
     return collect_3d(st) if wait else st
 
 
@@ -665,14 +715,14 @@ def _detect_3d_stream(model, frames, pool, eval_thresh, class_index, dense_align
         with torch.no_grad(), torch.cuda.stream(s):
             if len(frame) == 3:
                 st = detect_3d_images(model, frame[0], frame[1], frame[2], eval_thresh, class_index, dense_align, slot, wait=False,
-                                      solver=solver)
+                                      solver=solver, async_host=True)
             else:
                 l, r, info, calib, im_shape = frame[:5]
                 scale = float(np.float32(frame[5])) if len(frame) > 5 else _scale32(info)
                 lazy = _lazy(model)
                 out = model(l, r, info, slot=slot, kpts=not lazy, alias_outputs=True)
                 st = launch_3d(out, l, r, info, scale, calib, im_shape, eval_thresh, class_index, dense_align, slot, solver,
-                               lazy=_plan_of(model, l, slot) if lazy else None)
+                               lazy=_plan_of(model, l, slot) if lazy else None, async_host=True)
         for older, _ in inflight:                              # solver='host': a host phase of every pair in flight whose device
             step_3d(older, block=False)                        # work has finished -- never waiting for one that has not
         inflight.append((st, frame))

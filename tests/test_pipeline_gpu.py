@@ -210,3 +210,37 @@ def test_three_in_flight_soak_is_bit_repeatable(dev, solver):
         if not same:
             bad.append(k)
     assert not bad, '%d of 306 frames differ from the lone run (first: %s)' % (len(bad), bad[:5])
+
+
+def test_async_host_phases_give_the_same_objects(dev):
+    """pipeline.ASYNC_HOST_PHASES (opt-in, SRCNN_ASYNC_HOST=1): a pair's host phases on a worker thread instead of on the loop
+    thread -- the same calls on the same streams in the same order per pair: every frame's objects equal the default
+    arrangement's bit for bit, also when a pair's slot is reused."""
+    from oracle.dense_align import KITTI_DEMO_CALIB as calib
+    from stereo_rcnn_amd import fixture, pipeline
+    from stereo_rcnn_amd.model.stereo_rcnn.resnet import resnet
+    m = resnet(('__background__', 'Car'), 101)
+    m.create_architecture()
+    m.load_state_dict(fixture.make_state_dict(3))
+    m.cuda().eval()
+    m.precision = 'f16x3'
+    m.use_program = True
+    frames = []
+    for seed in (3, 4, 5):
+        l, r, info = fixture.make_inputs(seed, 200, 660, target_short=320)
+        frames.append((l.to(dev), r.to(dev), info.to(dev), calib, (200, 660, 3), float(info[0, 2])))
+    saved = pipeline.ASYNC_HOST_PHASES
+    try:
+        pipeline.ASYNC_HOST_PHASES = False
+        ref = list(pipeline.detect_3d_stream(m, frames * 4, slots=3, solver='host'))
+        pipeline.ASYNC_HOST_PHASES = True
+        got = list(pipeline.detect_3d_stream(m, frames * 4, slots=3, solver='host'))
+    finally:
+        pipeline.ASYNC_HOST_PHASES = saved
+    assert len(ref) == len(got) == 12 and any(len(o) for o in ref)
+    for a, b in zip(ref, got):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            for key, va in x.items():
+                vb = y[key]
+                assert np.array_equal(va, vb) if isinstance(va, np.ndarray) else va == vb, key
