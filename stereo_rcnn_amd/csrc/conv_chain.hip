@@ -133,6 +133,10 @@ static int chain_check(const srcnn_conv_desc *d, int n, const ConvArgs *a)
         }
         SRCNN_REQUIRE(static_cast<const void *>(d[i].y) != static_cast<const void *>(d[0].x),
                       "chain: no phase may overwrite the tensor the first phase reads (other workgroups still need its halo rows)");
+        for (int j = 0; j < n; ++j)
+            SRCNN_REQUIRE(static_cast<const void *>(d[i].y) != static_cast<const void *>(d[j].residual) &&
+                              static_cast<const void *>(d[i].y) != d[j].x2,
+                          "chain: residuals and second inputs must be tensors no phase of the chain writes");
     }
     return SRCNN_OK;
 }

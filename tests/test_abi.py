@@ -60,6 +60,11 @@ def test_workspace_query_and_argument_errors_without_gpu(lib_path):
     assert L.srcnn_conv2d(ctypes.byref(d), None, 0, None) == -1
     assert b'multiple of 32' in L.srcnn_last_error()
     assert L.roi_align_forward_cuda(8, 8, 1.0, None, 1, 1, 4, 4, None, 3, 4, None, None) == 0   # roi_cols != 5
+    # chained / grouped launches validate before they launch, too
+    assert L.srcnn_conv2d_chain(None, 1, None) == -1 and L.srcnn_conv2d_group(None, 1, None) == -1
+    three = (_lib.ConvDesc * 3)()
+    assert L.srcnn_conv2d_chain(three, 4, None) == -1 and b'1 to 3' in L.srcnn_last_error()
+    assert L.srcnn_conv2d_chain_supported(2, 8, 2, 2, 2) == 1 and L.srcnn_conv2d_chain_supported(3, 8, 2, 2, 2) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
