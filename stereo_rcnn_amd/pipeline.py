@@ -637,21 +637,15 @@ def _note_guard_trip(model, im_left_data, slot, may_recalibrate=True):
                     'calibrate_activation_scales() on representative frames is the controlled way)')
 
 
-_stream_cache = {}
-
-
 def _slot_streams(n):
-    """The in-flight slots' HIP streams, created once per device: per-stream scratch buffers (_lib.workspace) and recorded launch
-    programs are keyed by stream, so fresh streams on every call would grow them without bound."""
-    dev = torch.cuda.current_device()
-    have = _stream_cache.setdefault(dev, [])
-    while len(have) < n:
-        have.append(_streams.new_stream(_streams.MAIN_KIND if _streams.MAIN_KIND in _streams.KINDS else 'dedicated'))
+    """The in-flight slots' HIP streams: the process-wide set of streams.main_streams (created once per device: per-stream scratch
+    buffers (_lib.workspace) and recorded launch programs are keyed by stream, so fresh streams on every call would grow them
+    without bound -- and fresh streams per CALLER would run out of hardware queues, see streams.main_streams)."""
     # the serving regime of bench.py's headline (serving.py): branches stay on the main streams with n > 1, the hardware-queue
     # supply is checked, and the shipped throughput-tuned conv plans are adopted (once; MI355X only; matching shapes only)
     from . import serving
     serving.enter(n)
-    return have[:n]
+    return _streams.main_streams(n, kind=_streams.MAIN_KIND if _streams.MAIN_KIND in _streams.KINDS else 'dedicated')
 
 
 def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=4, solver='host'):

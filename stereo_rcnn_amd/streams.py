@@ -113,13 +113,11 @@ _handles = []      # native handles of the streams created here: they live as lo
 
 
 def destroy_all():
-    """Destroys every native stream this module created, after dropping the wrappers the package itself caches (the pipeline's
-    slot streams): for long-lived processes that rebuild their stream set.  Callers must have dropped THEIR wrappers
+    """Destroys every native stream this module created, after dropping the wrappers the package itself caches (the in-flight
+    streams of main_streams): for long-lived processes that rebuild their stream set.  Callers must have dropped THEIR wrappers
     (tune.StepRunner objects, streams handed out by main_streams) -- a wrapper used after this call is a dangling handle."""
     import sys
-    pl = sys.modules.get(__package__ + '.pipeline')
-    if pl is not None:
-        pl._stream_cache.clear()
+    _flight.clear()
     torch.cuda.synchronize()
     while _handles:
         _lib.lib().srcnn_stream_destroy(_handles.pop())
@@ -207,7 +205,20 @@ def main_streams(n, device=None, kind=None):
     if kind == 'partition':
         n_cus = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
         return [masked_stream(m, device) for m in partition_masks(n, n_cus)]
-    return [new_stream(kind, device) for _ in range(n)]
+    # ONE set of in-flight streams per (device, kind) and process (round 6): every caller that keeps n forwards in flight -- the
+    # benchmark's headline loop, tune.StepRunner, pipeline.detect_3d_stream's slots -- gets the SAME first n streams.  Fresh streams
+    # per caller looked harmless and were not: HIP binds a stream to a hardware queue when it is first used and never gives the
+    # queue back, so bench.py's four headline streams + the pipeline's four slot streams + the null stream were nine streams on
+    # eight queues, two of the slots' forwards shared one queue, and the 3-D flow inside bench.py ran at 7.1 ms per pair where the
+    # same flow alone in a process took 5.9 (profiles/flow3d_queue_sharing_r06.txt).
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    have = _flight.setdefault((dev, kind), [])
+    while len(have) < n:
+        have.append(new_stream(kind, device))
+    return have[:n]
+
+
+_flight = {}      # (device index, kind) -> the process's in-flight streams of that kind
 
 
 def side_streams(n, device=None, kind=None):

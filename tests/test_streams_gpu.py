@@ -27,8 +27,10 @@ def test_dedicated_stream_runs_kernels_on_every_xcd(dev):
     s = streams.new_stream('dedicated')
     xcc, hw = _probe(s, dev)
     per = collections.Counter(xcc)
-    assert sorted(per) == list(range(8)) and set(per.values()) == {256}     # block b on XCD b % 8
-    assert all(x == b % 8 for b, x in enumerate(xcc))
+    assert sorted(per) == list(range(8)) and set(per.values()) == {256}     # block b on XCD (b + r) % 8
+    # (r = where the dispatcher's round-robin stood: 0 on most boxes / histories, not guaranteed -- the conv engine's tile map only
+    #  needs blocks b and b + 8 to meet on one XCD, csrc/conv_f16s.hip)
+    assert all(x == (b + xcc[0]) % 8 for b, x in enumerate(xcc))
     # ordinary torch work on the wrapped stream
     with torch.cuda.stream(s):
         a = torch.arange(1024, device=dev, dtype=torch.float32)
@@ -46,7 +48,7 @@ def test_cu_mask_partition_is_one_shader_engine_of_every_xcd(dev):
     masks = streams.partition_masks(4, n_cus)
     for k in (1, 2):
         xcc, hw = _probe(streams.masked_stream(masks[k]), dev)
-        assert all(x == b % 8 for b, x in enumerate(xcc))
+        assert all(x == (b + xcc[0]) % 8 for b, x in enumerate(xcc))
         cus = collections.defaultdict(set)
         for x, h in zip(xcc, hw):
             cus[x].add(((h >> 13) & 7, (h >> 8) & 15))          # (shader engine, CU)
