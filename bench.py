@@ -455,7 +455,7 @@ def run_config3(args, rank, local_rank, world, use_dist):
         except (AttributeError, OSError):
             cpus = os.cpu_count() or 1
         budget = max(1, cpus // lw)
-        prefetch = max(4, min(16, budget))                     # PNG decode threads (PIL releases the GIL while inflating)
+        prefetch = int(os.environ.get('SRCNN_DECODE_THREADS', max(4, min(16, budget))))     # PNG decode threads (PIL releases the GIL while inflating)
         timers, ptimers = {}, {}
         records = []
         if dry:

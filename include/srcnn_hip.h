@@ -430,7 +430,8 @@ SRCNN_API int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im
                      srcnn_stream_t stream);
 /* Record forms on HOST memory (pinned copies of `rec` / `state`): row for row the function the two kernels above run, built
  * for the host and using the host's libm, i.e. bit-identical to the reference's scipy path (scipy Newton-CG, numpy scalar
- * `**2` = pow, glibc cos / sin / atan2).  Rows are spread over `threads` host threads (<= 0: one per 8 rows, at most 16). */
+ * `**2` = pow, glibc cos / sin / atan2).  Rows are spread over host threads: one per 8 rows, at most 16, and at most `threads` when > 0
+ * (a budget, not a demand: creating 16 threads for 40 rows costs more than the rows). */
 SRCNN_API int srcnn_solve_4dof_records_host(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02,
                                   double p2_12, double p2_03_minus_p3_03, float eval_thresh, double *state4, int threads);
 SRCNN_API int srcnn_solve_3dof_records_host(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02,

@@ -153,12 +153,15 @@ __global__ void solve3_kernel(float *__restrict__ rec, int n, int cols, Calib c,
     if (threadIdx.x == 0) solve3_row(rec, n, cols, c, align_status, best_dis, state, blockIdx.x);
 }
 
-// rows [0, n) of a host record over `threads` host threads (<= 0: one per 8 rows, at most 16)
+// rows [0, n) of a host record over host threads: one per 8 rows, at most 16 -- and at most `threads` when the caller gives a budget
+// (> 0).  The budget is an upper bound, not a demand (round 6): a solve of ~40 detections takes 0.4 ms on 5 threads and 0.5-1.1 ms on
+// 16, whose creation costs more than the rows they take (profiles/flow3d_async_host_r06.txt).
 template <typename F>
 static void host_rows(int n, int threads, F &&row_fn)
 {
-    if (threads <= 0) threads = n / 8;
-    threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    int want = n / 8;
+    want = want < 1 ? 1 : (want > 16 ? 16 : want);
+    threads = threads > 0 && threads < want ? threads : want;
     if (threads > n) threads = n > 0 ? n : 1;
     if (threads == 1) {
         for (int i = 0; i < n; ++i) row_fn(i);

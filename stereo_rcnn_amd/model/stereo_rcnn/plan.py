@@ -719,8 +719,11 @@ class Plan(object):
         scale = None
         per_image = (self.H + 6) * (self.W + 8) * 4 * 4
         for i, (img, planar) in enumerate(((img_left_u8, self.im_left), (img_right_u8, self.im_right))):
-            assert img.is_cuda and img.dtype == torch.uint8 and img.dim() == 3
-            img = img.contiguous()
+            # device images, or PAGE-LOCKED host images the kernel reads over the bus itself (zero-copy: no hipMemcpy in the stream)
+            assert (img.is_cuda or img.is_pinned()) and img.dtype == torch.uint8 and img.dim() == 3
+            if img.is_cuda:
+                img = img.contiguous()
+            assert img.is_contiguous(), 'a page-locked host image must be contiguous (it is read where it is)'
             H0, W0 = int(img.shape[0]), int(img.shape[1])
             OH, OW, scale = engine.preprocess_size(H0, W0, target_short)
             assert (OH, OW) == (self.H, self.W), "plan was built for another input size"

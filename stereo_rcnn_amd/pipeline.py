@@ -651,7 +651,8 @@ def _slot_streams(n):
 def detect_3d_stream(model, frames, pool=None, eval_thresh=0.05, class_index=1, dense_align=True, slots=4, solver='host'):
     """Generator form for a sequence of pairs: yields one object list per frame, in order, with up to `slots` pairs in flight
     on their own HIP streams.  frames: iterable of (im_left_data, im_right_data, im_info, calib, im_shape[, scale]) with device
-    tensors, or (img_left_u8, img_right_u8, calib) with uint8 device images (fused preprocessing).  Per pair the results are
+    tensors, or (img_left_u8, img_right_u8, calib) with uint8 device images -- or PAGE-LOCKED host images, which the fused
+    preprocessing kernel reads where they are (no copy in any stream; they must stay unmodified until the pair is yielded).  Per pair the results are
     those of detect_3d (same launches).  solver='host': the Newton-CG solves of the pairs in flight run on the host between
     the launches (a phase of every pair whose device work has finished, per new frame: never waiting), use slots >= 4 (measured:
     profiles/config3_plans_slots_r05.txt).  solver='scipy' (needs `pool`) keeps the staged

@@ -36,6 +36,10 @@ def read_png_rgb(path):
         return np.asarray(im.convert('RGB'), dtype=np.uint8)
 
 
+# A/B switch: SRCNN_ZERO_COPY_IMAGES=0 = round 5's path (decoded images copied to the device with hipMemcpyAsync from a pinned pool)
+ZERO_COPY_IMAGES = os.environ.get('SRCNN_ZERO_COPY_IMAGES', '1') != '0'
+
+
 class _PinnedPool(object):
     """Page-locked staging buffers for the decoded uint8 images.  A host-to-device copy from PAGEABLE memory is staged by the
     runtime and blocks the issuing thread until the device has taken it (measured: 5.8 ms of the loop thread per pair in
@@ -63,6 +67,33 @@ class _PinnedPool(object):
         return dev_t
 
 
+class _PinnedRing(object):
+    """Page-locked image buffers the DEVICE reads where they are (round 6): the decode thread of frame j copies its two decoded
+    images into ring entry j % n, and the fused preprocessing kernel reads them over the bus -- no hipMemcpy in any stream.  An
+    asynchronous H2D copy per image looked free (0.35 ms of the loop thread per pair) and cost the streamed flow 1.0 ms per pair
+    (profiles/flow3d_input_path_r06.txt: 5.9 ms with device-resident images or zero-copy, 6.9 with two H2D copies per frame, 8.5
+    with the copies on a stream of their own) -- the copies, not their bytes.  Entry j % n is rewritten when frame j + n is
+    decoded, `prefetch` frames before it is consumed; frame j's pair has been collected by then if n >= prefetch + slots + 1."""
+
+    def __init__(self, n, nbytes=3 * 512 * 1408):
+        self.n, self.nbytes = n, nbytes
+        self.bufs = [None] * n
+
+    def put(self, j, left, right):
+        e = self.bufs[j % self.n]
+        if e is None:
+            e = self.bufs[j % self.n] = (torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=True),
+                                         torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=True))
+        out = []
+        for buf, arr in zip(e, (left, right)):
+            arr = np.ascontiguousarray(arr, dtype=np.uint8)
+            assert arr.nbytes <= self.nbytes, "image larger than the staging ring's entries"
+            view = buf[:arr.nbytes].view(*arr.shape)
+            np.copyto(view.numpy(), arr)
+            out.append(view)
+        return out
+
+
 def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=read_png_rgb, log=None, prefetch=4,
               solver='host', slots=4, detect_stream=None, records=None, timers=None):
     """Processes `ids` (already this rank's shard).  Returns (frames, objects written, seconds).
@@ -85,14 +116,19 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
         for k in ('decode_s', 'h2d_s', 'write_s', 'loop_s'):
             timers.setdefault(k, 0.0)
 
-    def load(frame):
+    zero_copy = detect_stream is None and solver in ('device', 'host') and ZERO_COPY_IMAGES
+    ring = _PinnedRing(max(1, prefetch) + max(1, slots) + 4) if zero_copy else None
+
+    def load(j, frame):
         td = time.perf_counter()
-        out = (read_image(os.path.join(kitti_root, 'image_2', frame + '.png')),
-               read_image(os.path.join(kitti_root, 'image_3', frame + '.png')),
-               kitti_utils.read_obj_calibration(os.path.join(kitti_root, 'calib', frame + '.txt')))
+        left = read_image(os.path.join(kitti_root, 'image_2', frame + '.png'))
+        right = read_image(os.path.join(kitti_root, 'image_3', frame + '.png'))
+        calib = kitti_utils.read_obj_calibration(os.path.join(kitti_root, 'calib', frame + '.txt'))
+        if ring is not None:
+            left, right = ring.put(j, left, right)              # page-locked views the preprocessing kernel reads directly
         if timers is not None:
             timers['decode_s'] += time.perf_counter() - td        # (float += under the GIL: good enough for a per-pair average)
-        return out
+        return (left, right, calib)
 
     calibs = collections.deque()
     pinned = _PinnedPool()
@@ -101,8 +137,8 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
         with cf.ThreadPoolExecutor(max_workers=max(1, prefetch)) as ex:
             pending = collections.deque()
             it = iter(ids)
-            for frame in it:
-                pending.append(ex.submit(load, frame))
+            for j, frame in enumerate(it):
+                pending.append(ex.submit(load, j, frame))
                 if len(pending) <= prefetch:
                     continue
                 yield to_device(pending.popleft().result())
@@ -114,6 +150,8 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
         calibs.append(calib)
         if detect_stream is not None:
             return (left, right, calib)                         # injected detector: frames stay on the host
+        if ring is not None:
+            return (left, right, calib)                         # page-locked host images: read by the fused preprocessing where they are
         th = time.perf_counter()
         lu, ru = pinned.stage(left, device), pinned.stage(right, device)
         if timers is not None:

@@ -40,7 +40,7 @@ def h2d_side_stream():
             a, b = pin_l.to(dev, non_blocking=True), pin_r.to(dev, non_blocking=True)
         torch.cuda.current_stream().wait_stream(copy_stream)
         yield (a, b, calib)
-for label, mk in (('host memcpy into pinned only (device images reused)', memcpy_only), ('H2D from a fixed pinned buffer (null stream)', h2d_only),
+for label, mk in (('pinned host images read by the kernel (zero-copy)', lambda: [(pin_l, pin_r, calib)] * N), ('host memcpy into pinned only (device images reused)', memcpy_only), ('H2D from a fixed pinned buffer (null stream)', h2d_only),
                   ('H2D on a side stream', h2d_side_stream), ('tensors', lambda: [(l, r, info, calib, (375, 1242, 3), float(info[0, 2]))] * N),
                   ('uint8 device images', lambda: [(lu, ru, calib)] * N),
                   ('uint8 host arrays via pinned staging + H2D', staged)):

@@ -13,7 +13,7 @@ m = resnet(('__background__', 'Car'), 101, pretrained=False); m.create_architect
 m.precision = 'f16x3'; m.use_program = True
 l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 375, 1242)]
 frame = (l, r, info, bench.demo_calib(), (375, 1242, 3), float(info[0, 2]))
-pipeline.HOST_SOLVER_THREADS = sdist.host_solver_threads()
+pipeline.HOST_SOLVER_THREADS = int(os.environ.get('SOLVER_THREADS', sdist.host_solver_threads()))
 pipeline.LAZY_KPTS = True
 T = collections.defaultdict(float)
 C = collections.defaultdict(int)
