@@ -1185,7 +1185,7 @@ def main():
         pipeline.HOST_SOLVER_THREADS = sdist.host_solver_threads()
         full3d = {'pairs_in_flight': 4, 'frames_per_rank': nfr, 'ranks': world, 'host_solver_threads_per_rank': pipeline.HOST_SOLVER_THREADS,
                   'numa_pinning': numa}
-        for solver in ('host', 'device', 'host+keypoints_on_kept_only'):
+        for solver in ('host', 'device', 'host+keypoints_on_kept_only', 'device+keypoints_on_kept_only'):
             pipeline.LAZY_KPTS = solver.endswith('kept_only') and lazy_default
             key = solver
             solver = solver.split('+')[0]

@@ -395,7 +395,10 @@ SRCNN_API int srcnn_dense_align(const float *im_left, const float *im_right, int
  *   than half the inferred ones.  workspace: srcnn_box3d_workspace_bytes(n, im_w).
  * srcnn_solve_4dof: demo.py:282-302 = box_estimator.py:169-385 for every row with score > eval_thresh: scipy's Newton-CG
  *   (optimize/_optimize.py:_minimize_newtoncg + MINPACK-2 dcsrch / wolfe2 line searches) restated in double precision,
- *   one detection per workgroup.  Writes columns 20-24, 27-31 and state4 (n,4) doubles (x, y, z, theta).
+ *   one detection per workgroup, the eight re-projection residuals of every cost / gradient evaluation on eight lanes of its
+ *   wavefront, summed in lane order (csrc/box_solver_wave.h).  Writes columns 20-24, 27-31 and state4 (n,4) doubles
+ *   (x, y, z, theta).  srcnn_solve_4dof_scalar / srcnn_solve_3dof_scalar: the same iteration with one lane evaluating the
+ *   residuals one after another (the form of rounds 2-5) -- bit-identical results, ~4x the time; kept as the lane form's test.
  * srcnn_align_inputs: the arrays align_parallel takes (boxes (n,4), borders (n,2), poses (n,7), valid (n)) from the record.
  * srcnn_solve_3dof: demo.py:311-319 = box_estimator.py:387-545 for rows whose 4-DoF solve and dense alignment
  *   succeeded (align_status / best_dis (n) from srcnn_dense_align, or both NULL = no alignment): columns 25-30 and
@@ -423,9 +426,14 @@ SRCNN_API int srcnn_infer_boundary(float *rec, int n, int rec_cols, int im_w, vo
                          srcnn_stream_t stream);
 SRCNN_API int srcnn_solve_4dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
                      double p2_03_minus_p3_03, float eval_thresh, double *state4, srcnn_stream_t stream);
+SRCNN_API int srcnn_solve_4dof_scalar(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                     double p2_03_minus_p3_03, float eval_thresh, double *state4, srcnn_stream_t stream);
 SRCNN_API int srcnn_align_inputs(const float *rec, int n, int rec_cols, float *boxes, float *borders, float *poses, float *valid,
                        srcnn_stream_t stream);
 SRCNN_API int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                     double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
+                     srcnn_stream_t stream);
+SRCNN_API int srcnn_solve_3dof_scalar(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
                      double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
                      srcnn_stream_t stream);
 /* Record forms on HOST memory (pinned copies of `rec` / `state`): row for row the function the two kernels above run, built

@@ -102,6 +102,10 @@ _SIGNATURES = {
     "srcnn_infer_boundary": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "srcnn_solve_4dof": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_float,
                                  c_void_p, c_void_p]),
+    "srcnn_solve_4dof_scalar": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_float,
+                                        c_void_p, c_void_p]),
+    "srcnn_solve_3dof_scalar": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     "srcnn_align_inputs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srcnn_solve_3dof": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),

@@ -3,11 +3,12 @@
 // demo.py:259-326 runs without a host round trip between the detector and the final 3-D boxes:
 //     class NMS -> pack -> [infer_boundary + border replacement] -> [4-DoF solve] -> dense alignment -> [3-DoF solve]
 // The solvers themselves are box_solver.h (scipy's Newton-CG restated; the same code also builds for the host and is
-// exported as srcnn_solve_*_host for CPU-side callers and tests).  One detection per 64-lane workgroup, lane 0 runs the
-// (data-dependent, double precision) iteration: the objects of an image spread over up to 300 CUs instead of diverging
-// inside one wavefront.
+// exported as srcnn_solve_*_host for CPU-side callers and tests).  One detection per 64-lane workgroup, so that the objects of
+// an image spread over up to 300 CUs instead of diverging inside one wavefront; within the wavefront the eight residuals of
+// every cost / gradient evaluation sit on eight lanes (box_solver_wave.h; round 6).  The form of rounds 2-5 -- lane 0 runs
+// the scalar code -- is kept as srcnn_solve_*_scalar: the two are bit-identical, which is how the lane form is tested.
 #include "common.h"
-#include "box_solver.h"
+#include "box_solver_wave.h"
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -100,6 +101,38 @@ __global__ void solve4_kernel(float *__restrict__ rec, int n, int cols, Calib c,
     if (threadIdx.x == 0) solve4_row(rec, n, cols, c, eval_thresh, state4, blockIdx.x);
 }
 
+// solve4_row with the residuals of every evaluation across the lanes of the workgroup's one wavefront: all 64 lanes run the
+// row (same loads, same control flow), lane 0 stores.  __launch_bounds__(64): the optimiser state of four nested line-search
+// levels wants ~200 VGPRs; at the default bound (1024 threads, 128 VGPRs) the scalar kernel spills 94 of them to scratch.
+__global__ void __launch_bounds__(64) solve4_wave_kernel(float *__restrict__ rec, int n, int cols, Calib c, float eval_thresh,
+                                                         double *__restrict__ state4)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const bool writer = lane == 0;
+    const int k = (int)rec[0] < n ? (int)rec[0] : n;
+    float *row = rec + (size_t)(1 + i) * cols;
+    double *out = state4 + (size_t)i * 4;
+    if (writer) out[0] = out[1] = out[2] = out[3] = 0.0;
+    if (i >= k) return;
+    const bool scored = row[C_SCORE] > eval_thresh;
+    double bl[5], br[5], dim[5], kp[5];
+    load5(row + C_BOXL, bl);
+    load5(row + C_BOXR, br);
+    load5(row + C_DIM, dim);
+    load5(row + C_KPT, kp);
+    const double alpha = atan2((double)row[C_SIN], (double)row[C_COS]);
+    if (writer) row[C_ST4] = row[C_ALIGN] = 0.f;
+    if (!scored) return;
+    double st[4];
+    const int status = solve_4dof_wave(c.im_h, c.im_w, c.f, c.cx, c.cy, c.base, alpha, dim, bl, br, kp, st, true, lane);
+    if (!writer) return;
+    for (int q = 0; q < 4; ++q) out[q] = st[q];
+    row[C_ST4] = (float)status;
+    for (int q = 0; q < 4; ++q) row[C_POSE4 + q] = (float)st[q];
+    for (int q = 0; q < 4; ++q) row[C_POSE + q] = (float)st[q];
+    row[C_ALPHA] = (float)alpha;
+}
+
 // gather of what align_parallel takes (demo.py:306-308): boxes (n,4), borders (n,2), poses (n,7), valid (n)
 __global__ void align_inputs_kernel(const float *__restrict__ rec, int n, int cols, float *__restrict__ boxes,
                                     float *__restrict__ borders, float *__restrict__ poses, float *__restrict__ valid)
@@ -151,6 +184,35 @@ __global__ void solve3_kernel(float *__restrict__ rec, int n, int cols, Calib c,
                               const float *__restrict__ best_dis, double *__restrict__ state)
 {
     if (threadIdx.x == 0) solve3_row(rec, n, cols, c, align_status, best_dis, state, blockIdx.x);
+}
+
+// solve3_row, residuals across lanes (see solve4_wave_kernel)
+__global__ void __launch_bounds__(64) solve3_wave_kernel(float *__restrict__ rec, int n, int cols, Calib c,
+                                                         const float *__restrict__ align_status,
+                                                         const float *__restrict__ best_dis, double *__restrict__ state)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const bool writer = lane == 0;
+    const int k = (int)rec[0] < n ? (int)rec[0] : n;
+    if (i >= k) return;
+    float *row = rec + (size_t)(1 + i) * cols;
+    double *out = state + (size_t)i * 4;
+    if (!(row[C_ST4] > 0.f)) return;
+    const float ast = align_status ? align_status[i] : 0.f;
+    if (writer) row[C_ALIGN] = ast;
+    if (!(ast > 0.f)) return;
+    const float dis = best_dis[i];
+    double bl[5], dim[5], kp[5];
+    load5(row + C_BOXL, bl);
+    load5(row + C_DIM, dim);
+    load5(row + C_KPT, kp);
+    const double alpha = (double)row[C_ALPHA];
+    double st[3];
+    const double z = solve_3dof_wave(c.im_h, c.im_w, c.f, c.cx, c.cy, c.base, alpha, dim, bl, (double)dis, kp, st, lane);
+    if (!writer) return;
+    row[C_DISP] = dis;
+    out[0] = st[0]; out[1] = st[1]; out[2] = z; out[3] = st[2];
+    for (int q = 0; q < 4; ++q) row[C_POSE + q] = (float)out[q];
 }
 
 // rows [0, n) of a host record over host threads: one per 8 rows, at most 16 -- and at most `threads` when the caller gives a budget
@@ -210,14 +272,29 @@ int srcnn_infer_boundary(float *rec, int n, int rec_cols, int im_w, void *worksp
     return check_launch("srcnn_infer_boundary");
 }
 
-int srcnn_solve_4dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
-                     double p2_03_minus_p3_03, float eval_thresh, double *state4, srcnn_stream_t stream)
+static int launch_solve4(bool wave, float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                         double p2_03_minus_p3_03, float eval_thresh, double *state4, srcnn_stream_t stream, const char *who)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(rec && state4 && n > 0 && rec_cols >= SRCNN_REC_COLS, "bad args (rec_cols >= SRCNN_REC_COLS)");
-    SRCNN_LAUNCH(solve4_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols,
-                       make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03), eval_thresh, state4);
-    return check_launch("srcnn_solve_4dof");
+    const Calib c = make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03);
+    if (wave) SRCNN_LAUNCH(solve4_wave_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols, c, eval_thresh, state4);
+    else SRCNN_LAUNCH(solve4_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols, c, eval_thresh, state4);
+    return check_launch(who);
+}
+
+int srcnn_solve_4dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                     double p2_03_minus_p3_03, float eval_thresh, double *state4, srcnn_stream_t stream)
+{
+    return launch_solve4(true, rec, n, rec_cols, im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03, eval_thresh, state4, stream,
+                         "srcnn_solve_4dof");
+}
+
+int srcnn_solve_4dof_scalar(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                            double p2_03_minus_p3_03, float eval_thresh, double *state4, srcnn_stream_t stream)
+{
+    return launch_solve4(false, rec, n, rec_cols, im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03, eval_thresh, state4, stream,
+                         "srcnn_solve_4dof_scalar");
 }
 
 int srcnn_align_inputs(const float *rec, int n, int rec_cols, float *boxes, float *borders, float *poses, float *valid,
@@ -230,16 +307,33 @@ int srcnn_align_inputs(const float *rec, int n, int rec_cols, float *boxes, floa
     return check_launch("srcnn_align_inputs");
 }
 
-int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
-                     double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
-                     srcnn_stream_t stream)
+static int launch_solve3(bool wave, float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                         double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
+                         srcnn_stream_t stream, const char *who)
 {
     using namespace srcnn;
     SRCNN_REQUIRE(rec && state && n > 0 && rec_cols >= SRCNN_REC_COLS, "bad args (rec_cols >= SRCNN_REC_COLS)");
     SRCNN_REQUIRE((align_status == nullptr) == (best_dis == nullptr), "align_status and best_dis come together");
-    SRCNN_LAUNCH(solve3_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols,
-                       make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03), align_status, best_dis, state);
-    return check_launch("srcnn_solve_3dof");
+    const Calib c = make_calib(im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03);
+    if (wave) SRCNN_LAUNCH(solve3_wave_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols, c, align_status, best_dis, state);
+    else SRCNN_LAUNCH(solve3_kernel, dim3(n), dim3(64), 0, as_stream(stream), rec, n, rec_cols, c, align_status, best_dis, state);
+    return check_launch(who);
+}
+
+int srcnn_solve_3dof(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                     double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
+                     srcnn_stream_t stream)
+{
+    return launch_solve3(true, rec, n, rec_cols, im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03, align_status, best_dis, state,
+                         stream, "srcnn_solve_3dof");
+}
+
+int srcnn_solve_3dof_scalar(float *rec, int n, int rec_cols, int im_h, int im_w, double p2_00, double p2_02, double p2_12,
+                            double p2_03_minus_p3_03, const float *align_status, const float *best_dis, double *state,
+                            srcnn_stream_t stream)
+{
+    return launch_solve3(false, rec, n, rec_cols, im_h, im_w, p2_00, p2_02, p2_12, p2_03_minus_p3_03, align_status, best_dis, state,
+                         stream, "srcnn_solve_3dof_scalar");
 }
 
 // ---- the same solvers for host callers (no GPU involved): box_estimator.solve_* signatures flattened

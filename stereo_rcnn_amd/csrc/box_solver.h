@@ -134,7 +134,7 @@ SRCNN_HD void setup(Problem &t, int im_h, int im_w, double f, double cx, double 
 // (glibc: last bit differs in ~0.06 % of the calls) -- and one last bit moves a chaotic Newton-CG end point.  The host build
 // therefore calls the same pow (through a volatile exponent: the compiler would fold pow(v, 2.0) into v * v); the device has
 // no glibc and squares exactly, which is one of the two reasons its end points differ from the host's (the other: ocml cos/sin).
-SRCNN_HD inline double sq(double v)
+SRCNN_HD double sq(double v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     return v * v;
@@ -223,6 +223,23 @@ SRCNN_HD void grad(const Problem &t, const double *s, double *out)
     }
 }
 
+// cost AND gradient at one point from one pass over the residuals: the doubles fun<N> and grad<N> return there (evaluate()
+// computes the cost the same way whether or not it is asked for the gradient).  The optimiser below asks for both wherever
+// scipy calls phi(stp) and derphi(stp) back to back.
+template <int N>
+SRCNN_HD double fun_grad(const Problem &t, const double *s, double *out)
+{
+    double g[4], c;
+    if (N == 4) {
+        c = evaluate(t, s[0], s[1], s[2], s[3], true, g);
+        out[0] = g[0]; out[1] = g[1]; out[2] = g[2]; out[3] = g[3];
+    } else {
+        c = evaluate(t, s[0], s[1], t.z_fixed, s[2], true, g);
+        out[0] = g[0]; out[1] = g[1]; out[2] = g[3];
+    }
+    return c;
+}
+
 // ------------------------------------------------------------------------------------------------ small vector helpers
 // np.dot of two short float64 vectors = cblas_ddot of the OpenBLAS bundled with numpy: on every x86 core with FMA (Haswell /
 // SkylakeX / Zen kernels) the n < 32 tail is the scalar loop `dot += y[i] * x[i]` compiled to fused multiply-adds
@@ -253,10 +270,11 @@ SRCNN_HD double np_clip(double v, double lo, double hi) { return fmin(fmax(v, lo
 SRCNN_HD bool fin(double v) { return v - v == 0.0; }                          // np.isfinite (false for inf and NaN)
 SRCNN_HD double np_sign(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : (v == 0 ? 0.0 : v)); }
 
-// line phi(s) = f(xk + s * pk), derphi(s) = <grad f(xk + s * pk), pk>
-template <int N>
+// line phi(s) = f(xk + s * pk), derphi(s) = <grad f(xk + s * pk), pk>.  P: the problem type -- `Problem` (one thread evaluates all
+// eight residuals) or box_solver_wave.h's WaveProblem (one residual per lane); fun<N> / grad<N> are overloaded on it.
+template <int N, class P>
 struct Line {
-    const Problem *t;
+    const P *t;
     const double *xk, *pk;
     double gval[N];          // gradient at the last derphi() point (line_search_wolfe1/2 hand it back as gfkp1)
     SRCNN_HD double phi(double s) const
@@ -271,6 +289,15 @@ struct Line {
         for (int i = 0; i < N; ++i) x[i] = xk[i] + s * pk[i];
         grad<N>(*t, x, gval);
         return dot<N>(gval, pk);
+    }
+    // phi(s) and derphi(s) of one point in one evaluation
+    SRCNN_HD double phi_derphi(double s, double &der)
+    {
+        double x[N];
+        for (int i = 0; i < N; ++i) x[i] = xk[i] + s * pk[i];
+        const double f = fun_grad<N>(*t, x, gval);
+        der = dot<N>(gval, pk);
+        return f;
     }
 };
 
@@ -403,8 +430,8 @@ SRCNN_HD int dcsrch_iterate(DcState &d, double &stp, double f, double g, double 
 }
 
 // scalar_search_wolfe1 (optimize/_linesearch.py) = DCSRCH.__call__.  Returns true and (stp, phi1) on success.
-template <int N>
-SRCNN_HD bool search_wolfe1(Line<N> &ln, double phi0, bool have_old, double old_phi0, double derphi0, double &stp_out,
+template <int N, class P>
+SRCNN_HD bool search_wolfe1(Line<N, P> &ln, double phi0, bool have_old, double old_phi0, double derphi0, double &stp_out,
                             double &phi_out)
 {
     const double c1 = 1e-4, c2 = 0.9, amax = 50, amin = 1e-8, xtol = 1e-14;
@@ -431,13 +458,13 @@ SRCNN_HD bool search_wolfe1(Line<N> &ln, double phi0, bool have_old, double old_
     double stp = alpha1;
     // iteration 0 of the Python loop was the START call (returns 'FG'); 99 more may follow
     if (!fin(stp)) return false;
-    double phi1 = ln.phi(stp), derphi1 = ln.derphi(stp);
+    double derphi1;
+    double phi1 = ln.phi_derphi(stp, derphi1);
     for (int i = 1; i < 100; ++i) {
         const int task = dcsrch_iterate(d, stp, phi1, derphi1, c1, c2, xtol, amin, amax);
         if (!fin(stp)) return false;
         if (task == 0) {
-            phi1 = ln.phi(stp);
-            derphi1 = ln.derphi(stp);
+            phi1 = ln.phi_derphi(stp, derphi1);
         } else {
             if (task == 2) return false;        // WARNING -> stp = None
             stp_out = stp;
@@ -477,8 +504,8 @@ SRCNN_HD bool quadmin(double a, double fa, double fpa, double b, double fb, doub
     return fin(xmin);
 }
 
-template <int N>
-SRCNN_HD bool zoom(Line<N> &ln, double a_lo, double a_hi, double phi_lo, double phi_hi, double derphi_lo, double phi0,
+template <int N, class P>
+SRCNN_HD bool zoom(Line<N, P> &ln, double a_lo, double a_hi, double phi_lo, double phi_hi, double derphi_lo, double phi0,
                    double derphi0, double c1, double c2, double &a_star, double &val_star)
 {
     const int maxiter = 10;
@@ -528,8 +555,8 @@ SRCNN_HD bool zoom(Line<N> &ln, double a_lo, double a_hi, double phi_lo, double 
 // scalar_search_wolfe2 with amax = None, extra_condition = None, maxiter = 10.  Returns true and (alpha, phi) when the caller
 // (_line_search_wolfe12) would accept the step: alpha_star is not None -- which includes the "did not converge" exit of the
 // for-else branch (alpha_star = alpha1, derphi_star = None).
-template <int N>
-SRCNN_HD bool search_wolfe2(Line<N> &ln, double phi0, bool have_old, double old_phi0, double derphi0, double &alpha_star,
+template <int N, class P>
+SRCNN_HD bool search_wolfe2(Line<N, P> &ln, double phi0, bool have_old, double old_phi0, double derphi0, double &alpha_star,
                             double &phi_star)
 {
     const double c1 = 1e-4, c2 = 0.9;
@@ -541,7 +568,7 @@ SRCNN_HD bool search_wolfe2(Line<N> &ln, double phi0, bool have_old, double old_
     for (int i = 0; i < 10; ++i) {
         if (alpha1 == 0) return false;                    // alpha_star = None
         if (phi_a1 > phi0 + c1 * alpha1 * derphi0 || (phi_a1 >= phi_a0 && i > 0))
-            return zoom<N>(ln, alpha0, alpha1, phi_a0, phi_a1, derphi_a0, phi0, derphi0, c1, c2, alpha_star, phi_star);
+            return zoom<N, P>(ln, alpha0, alpha1, phi_a0, phi_a1, derphi_a0, phi0, derphi0, c1, c2, alpha_star, phi_star);
         const double derphi_a1 = ln.derphi(alpha1);
         if (fabs(derphi_a1) <= -c2 * derphi0) {
             alpha_star = alpha1;
@@ -549,7 +576,7 @@ SRCNN_HD bool search_wolfe2(Line<N> &ln, double phi0, bool have_old, double old_
             return true;
         }
         if (derphi_a1 >= 0)
-            return zoom<N>(ln, alpha1, alpha0, phi_a1, phi_a0, derphi_a1, phi0, derphi0, c1, c2, alpha_star, phi_star);
+            return zoom<N, P>(ln, alpha1, alpha0, phi_a1, phi_a0, derphi_a1, phi0, derphi0, c1, c2, alpha_star, phi_star);
         const double alpha2 = 2 * alpha1;
         alpha0 = alpha1;
         alpha1 = alpha2;
@@ -565,21 +592,25 @@ SRCNN_HD bool search_wolfe2(Line<N> &ln, double phi0, bool have_old, double old_
 // ------------------------------------------------------------------------------------------------ Newton-CG
 // _minimize_newtoncg with default options.  xk: start point in, end point out.  Returns scipy's status (0 success,
 // 1 maxiter, 2 line search failed, 3 CG did not converge / NaN); the reference ignores it and takes res.x.
-template <int N>
-SRCNN_HD int newton_cg(const Problem &t, double *xk, int *iterations = nullptr)
+template <int N, class P>
+SRCNN_HD int newton_cg(const P &t, double *xk, int *iterations = nullptr)
 {
     const double avextol = 1e-5, epsilon = 1.4901161193847656e-08;     // sqrt(np.finfo(float).eps)
     const int maxiter = N * 200, cg_maxiter = 20 * N;
     const double xtol = N * avextol;
     double update_l1norm = DBL_MAX;
     int k = 0;
-    double old_fval = fun<N>(t, xk), old_old_fval = 0;
-    bool have_old = false;
+    // The gradient at the new xk is the one the MINPACK line search evaluated last (it returns the step it evaluated last, and
+    // xk + alphak * pk is formed the same way in Line and below): scipy recomputes it, fprime(xk), to the same doubles; here it
+    // is carried over.  After a wolfe2 search it is recomputed (its for-else exit returns a step whose gradient was not taken).
+    double gfk[N];
+    double old_fval = fun_grad<N>(t, xk, gfk), old_old_fval = 0;
+    bool have_old = false, have_gfk = true;
     int status = 0;
     while (update_l1norm > xtol) {
         if (k >= maxiter) { status = 1; break; }
-        double gfk[N], b[N], xsupi[N], ri[N], psupi[N];
-        grad<N>(t, xk, gfk);
+        double b[N], xsupi[N], ri[N], psupi[N];
+        if (!have_gfk) grad<N>(t, xk, gfk);
         for (int i = 0; i < N; ++i) b[i] = -gfk[i];
         const double maggrad = norm1<N>(b);
         const double eta = py_min(0.5, sqrt(maggrad));
@@ -618,15 +649,18 @@ SRCNN_HD int newton_cg(const Problem &t, double *xk, int *iterations = nullptr)
         }
         if (!broke) { status = 3; break; }             // "CG iterations didn't converge"
         const double *pk = xsupi;
-        Line<N> ln;
+        Line<N, P> ln;
         ln.t = &t;
         ln.xk = xk;
         ln.pk = pk;
         const double derphi0 = dot<N>(gfk, pk);
         double alphak = 0, new_fval = 0;
-        bool ok = search_wolfe1<N>(ln, old_fval, have_old, old_old_fval, derphi0, alphak, new_fval);
-        if (!ok) ok = search_wolfe2<N>(ln, old_fval, have_old, old_old_fval, derphi0, alphak, new_fval);
+        bool ok = search_wolfe1<N, P>(ln, old_fval, have_old, old_old_fval, derphi0, alphak, new_fval);
+        have_gfk = ok;
+        if (!ok) ok = search_wolfe2<N, P>(ln, old_fval, have_old, old_old_fval, derphi0, alphak, new_fval);
         if (!ok) { status = 2; break; }                // _LineSearchError: "precision loss"
+        if (have_gfk)
+            for (int i = 0; i < N; ++i) gfk[i] = ln.gval[i];
         old_old_fval = old_fval;
         have_old = true;
         old_fval = new_fval;
@@ -647,12 +681,12 @@ SRCNN_HD int newton_cg(const Problem &t, double *xk, int *iterations = nullptr)
 // passes `.cpu().numpy()` rows): numpy then evaluates the box-size tests (:186), the start disparity (:374) and the keypoint
 // ratio of kpt2alpha (:160) in FLOAT32 arithmetic, everything else is promoted to double by the float64 calibration entries.
 // kpts is a torch tensor row there (Python floats) and dim only enters through products with doubles.
-SRCNN_HD int solve_4dof(int im_h, int im_w, double f, double cx, double cy, double base, double alpha, const double *dim,
-                        const double *box_left, const double *box_right, const double *kpts, double *state, int *newton_status,
-                        bool boxes_f32 = false)
+// prepare_4dof: everything before the optimiser (early-outs :186-187, observation set-up, start point :374-378).  false = the
+// reference returns (zeros, status 0) without solving.
+SRCNN_HD bool prepare_4dof(Problem &t, int im_h, int im_w, double f, double cx, double cy, double base, double alpha, const double *dim,
+                           const double *box_left, const double *box_right, const double *kpts, double *state, bool boxes_f32)
 {
     state[0] = state[1] = state[2] = state[3] = 0;
-    if (newton_status) *newton_status = -1;
     double bw = box_left[2] - box_left[0], bh = box_left[3] - box_left[1];
     double disparity = (box_left[0] + box_left[2]) / 2 - (box_right[0] + box_right[2]) / 2;
     if (boxes_f32) {
@@ -663,24 +697,32 @@ SRCNN_HD int solve_4dof(int im_h, int im_w, double f, double cx, double cy, doub
         const float sl = (l0 + l2) / 2, sr = (r0 + r2) / 2;
         disparity = (double)(sl - sr);
     }
-    if (kpts[4] - kpts[3] < 3 || bw < 10 || bh < 10) return 0;                                                   // :186-187
-    Problem t;
+    if (kpts[4] - kpts[3] < 3 || bw < 10 || bh < 10) return false;                                               // :186-187
     setup(t, im_h, im_w, f, cx, cy, base, alpha, dim, box_left, box_right, kpts, boxes_f32);
     const double init_z = t.f * t.bl / disparity;
     const double init_x = init_z * (t.obs[0] + t.obs[1]) / 2.0;
     const double init_y = init_z * (t.obs[5] + t.obs[6]) / 2.0 + t.h / 2.0;
     const double init_theta = t.alpha + kPi / 2 - atan2(-init_x, init_z);
     state[0] = init_x; state[1] = init_y; state[2] = init_z; state[3] = init_theta;
+    return true;
+}
+
+SRCNN_HD int solve_4dof(int im_h, int im_w, double f, double cx, double cy, double base, double alpha, const double *dim,
+                        const double *box_left, const double *box_right, const double *kpts, double *state, int *newton_status,
+                        bool boxes_f32 = false)
+{
+    if (newton_status) *newton_status = -1;
+    Problem t;
+    if (!prepare_4dof(t, im_h, im_w, f, cx, cy, base, alpha, dim, box_left, box_right, kpts, state, boxes_f32)) return 0;
     const int st = newton_cg<4>(t, state);
     if (newton_status) *newton_status = st;
     return state[2] > 100 ? 0 : 1;                                                                                 // :383-385
 }
 
 // solve_x_y_theta_from_kpt (box_estimator.py:387-545).  state = (x, y, theta); returns z.
-SRCNN_HD double solve_3dof(int im_h, int im_w, double f, double cx, double cy, double base, double alpha, const double *dim,
-                           const double *box_left, double disparity, const double *kpts, double *state, int *newton_status)
+SRCNN_HD double prepare_3dof(Problem &t, int im_h, int im_w, double f, double cx, double cy, double base, double alpha,
+                             const double *dim, const double *box_left, double disparity, const double *kpts, double *state)
 {
-    Problem t;
     setup(t, im_h, im_w, f, cx, cy, base, alpha, dim, box_left, nullptr, kpts);
     const double z = t.f * t.bl / disparity;
     t.z_fixed = z;
@@ -688,6 +730,14 @@ SRCNN_HD double solve_3dof(int im_h, int im_w, double f, double cx, double cy, d
     const double init_y = z * (t.obs[5] + t.obs[6]) / 2.0 + t.h / 2.0;
     const double init_theta = t.alpha + kPi / 2 - atan2(-init_x, z);
     state[0] = init_x; state[1] = init_y; state[2] = init_theta;
+    return z;
+}
+
+SRCNN_HD double solve_3dof(int im_h, int im_w, double f, double cx, double cy, double base, double alpha, const double *dim,
+                           const double *box_left, double disparity, const double *kpts, double *state, int *newton_status)
+{
+    Problem t;
+    const double z = prepare_3dof(t, im_h, im_w, f, cx, cy, base, alpha, dim, box_left, disparity, kpts, state);
     const int st = newton_cg<3>(t, state);
     if (newton_status) *newton_status = st;
     return z;

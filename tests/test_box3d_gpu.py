@@ -140,6 +140,57 @@ def test_solve_kernels_vs_host_build(dev):
     assert frac(d4, 1e-4) >= 0.7 and frac(d3, 1e-4) >= 0.9 and np.median(d4) < 1e-4
 
 
+def test_lane_form_of_the_solvers_is_bit_identical_to_the_scalar_form(dev):
+    """srcnn_solve_4dof / _3dof put the eight residuals of every cost / gradient evaluation on eight lanes and sum them in lane
+    order (csrc/box_solver_wave.h); srcnn_solve_*_scalar run box_solver.h on lane 0.  Same doubles, same order -> every state
+    double and every record column identical, on well-posed, truncated, rejected and unscored rows alike."""
+    from stereo_rcnn_amd import _lib
+    L = _lib.lib()
+    calib, rows = _cases(300, 23)
+    k = len(rows)
+    rng = np.random.default_rng(5)
+    score = np.where(rng.random(k) < 0.9, 0.9, 0.01)                   # some rows under eval_thresh
+    dl = np.array([np.append(r[0], s) for r, s in zip(rows, score)], np.float32)
+    dr = np.array([np.append(r[1], s) for r, s in zip(rows, score)], np.float32)
+    # truncated boxes (left / right / top / bottom image borders) switch residuals off and the alpha residual on
+    for i in range(0, k, 7):
+        dl[i, 0] = dr[i, 0] = 5.0
+    for i in range(3, k, 11):
+        dl[i, 2] = dr[i, 2] = 1238.0
+    for i in range(5, k, 13):
+        dl[i, 1] = dr[i, 1] = 4.0
+    do = np.array([np.concatenate((r[2], [r[4], r[5]])) for r in rows], np.float32)
+    kp = np.array([r[3] for r in rows], np.float32)
+    rec0 = torch.from_numpy(_record(dl, dr, do, kp)).to(dev)
+    n = rec0.shape[0] - 1
+    cal = (float(calib.p2[0, 0]), float(calib.p2[0, 2]), float(calib.p2[1, 2]), float(calib.p2[0, 3] - calib.p3[0, 3]))
+    dis = torch.tensor([cal[3] / r[6][2] for r in rows] + [1.0] * (n - k), dtype=torch.float32, device=dev)
+    ast = torch.ones(n, dtype=torch.float32, device=dev)
+    ast[::9] = 0
+    out, ms = {}, {}
+    for form in ('', '_scalar'):
+        rec = rec0.clone()
+        state = torch.full((2, n, 4), -7.0, dtype=torch.float64, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        s4, s3 = getattr(L, 'srcnn_solve_4dof' + form), getattr(L, 'srcnn_solve_3dof' + form)
+        for rep in range(2):                                            # second pass timed (first carries the code load)
+            rec.copy_(rec0)
+            ev[0].record()
+            _lib.check(s4(rec.data_ptr(), n, _lib.REC_COLS, 375, 1242, *cal, 0.05, state[0].data_ptr(), _lib.stream()))
+            ev[1].record()
+            _lib.check(s3(rec.data_ptr(), n, _lib.REC_COLS, 375, 1242, *cal, ast.data_ptr(), dis.data_ptr(), state[1].data_ptr(),
+                          _lib.stream()))
+            ev[2].record()
+            torch.cuda.synchronize()
+        out[form] = (rec.cpu().numpy(), state.cpu().numpy())
+        ms[form] = (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]))
+    print('solve4 / solve3 of %d rows: lanes %.3f / %.3f ms, scalar %.3f / %.3f ms' % ((n,) + ms[''] + ms['_scalar']))
+    assert np.array_equal(out[''][0], out['_scalar'][0], equal_nan=True)
+    assert np.array_equal(out[''][1], out['_scalar'][1], equal_nan=True)
+    solved = out[''][0][1:k + 1, 20]
+    assert 0.5 * k < solved.sum() < k                                   # the comparison is not vacuous
+
+
 def test_masked_dense_alignment_equals_compacted(dev):
     """srcnn_dense_align with a validity mask over a fixed batch == the compacted call on the valid rows only."""
     from oracle.dense_align import KITTI_DEMO_CALIB as calib
