@@ -8,8 +8,8 @@
 //     lane k & 7:  0 ul   1 ur   2 uk   3 ul_r   4 ur_r   5 vb   6 vt   7 alpha
 // every lane carries the whole optimiser state (x, the CG vectors, the line-search brackets) redundantly, so the control flow
 // of newton_cg<N> stays wave-uniform and needs no broadcast; only the residual arithmetic differs per lane, and the five
-// sums (cost, g_x, g_y, g_z, g_theta) are taken over lanes 0..7 IN LANE ORDER (v_readlane + add), which is the order the
-// scalar code accumulates them in -- so this form is bit-identical to the scalar device build of box_solver.h
+// sums (cost, g_x, g_y, g_z, g_theta) are taken over the residual lanes IN LANE ORDER (group_prefix_sums), which is the order
+// the scalar code accumulates them in -- so this form is bit-identical to the scalar device build of box_solver.h
 // (tests/test_box3d_gpu.py), and differs from the host build exactly where that one does (ocml cos / sin / atan2, sq()).
 //
 // The residual families are brought to one form so that lanes 0..6 share one instruction stream:
@@ -27,13 +27,17 @@ namespace boxsolve {
 struct WaveProblem {
     double shift, nw, nl, dw, dl, scale, obs, alpha, z_fixed;
     int kind;        // this lane's residual: 0 = u (ul, ur, uk, ul_r, ur_r), 1 = v (vb, vt), 2 = alpha
+    int group;       // lane >> 3: the quantity this lane carries through the sums (0..3 gradient entries, 4 cost)
     bool act;        // false: the reference zeroes this residual
+    bool first;      // lane & 7 == 0
 };
 
 __device__ inline WaveProblem make_wave(const Problem &t, int lane)
 {
     WaveProblem w;
     const int k = lane & 7;
+    w.group = lane >> 3;
+    w.first = k == 0;
     w.alpha = t.alpha;
     w.z_fixed = t.z_fixed;
     w.shift = 0.0;
@@ -54,14 +58,30 @@ __device__ inline WaveProblem make_wave(const Problem &t, int lane)
     return w;
 }
 
-// sum over lanes 0..7 in lane order, the same value in every lane (0.0 + v0 = v0: the scalar code's `cost = 0.0; cost += ...`)
-__device__ inline double lane_sum8(double v)
+// Ordered sums over the eight residual lanes, several quantities at once.  The wavefront is eight groups of eight lanes; lane l
+// evaluates residual l & 7 (all groups redundantly) and group l >> 3 carries ONE quantity's contributions: v = that quantity of
+// this lane's residual.  Seven steps of
+//     s[l] = (l & 7 ? s[l - 1] : 0.0) + v[l]          (row_shr:1 DPP moves; s starts as 0.0 + v)
+// leave 0.0 + v0 + v1 + ... + vk, added in that order, in lane k of every group from step k on (lane 0 holds 0.0 + v0 throughout,
+// lane k at step j >= k adds v[k] to lane k - 1's finished prefix): the scalar code's `sum = 0.0; sum += ...` for every
+// quantity in 7 x 5 instructions instead of 8 x 3 per quantity through v_readlane.  Lane 7 of group q then holds quantity q.
+__device__ inline double group_prefix_sums(double v, bool first)
 {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    double s = 0.0;
+    double s = 0.0 + v;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += __hiloint2double(__builtin_amdgcn_readlane(hi, k), __builtin_amdgcn_readlane(lo, k));
+    for (int j = 0; j < 7; ++j) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(s), 0x111, 0xf, 0xf, true);      // row_shr:1, zero fill
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(s), 0x111, 0xf, 0xf, true);
+        const double t = first ? 0.0 : __hiloint2double(hi, lo);
+        s = t + v;
+    }
     return s;
+}
+
+__device__ inline double group_total(double s, int group)          // the finished sum of `group`, the same value in every lane
+{
+    const int l = group * 8 + 7;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), l), __builtin_amdgcn_readlane(__double2loint(s), l));
 }
 
 // evaluate() of box_solver.h, one residual per lane.  g: (x, y, z, theta), as there.
@@ -102,12 +122,15 @@ __device__ inline double evaluate_wave(const WaveProblem &t, double x, double y,
         }
     }
     if (GRAD) {
-        g[0] = lane_sum8(c0);
-        g[1] = lane_sum8(c1);
-        g[2] = lane_sum8(c2);
-        g[3] = lane_sum8(c3);
+        const int q = t.group;
+        const double s = group_prefix_sums(q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : (q == 3 ? c3 : c))), t.first);
+        g[0] = group_total(s, 0);
+        g[1] = group_total(s, 1);
+        g[2] = group_total(s, 2);
+        g[3] = group_total(s, 3);
+        return group_total(s, 4);
     }
-    return lane_sum8(c);
+    return group_total(group_prefix_sums(c, t.first), 0);
 }
 
 template <int N>
