@@ -481,8 +481,9 @@ def detect_3d(model, im_left_data, im_right_data, im_info, calib, im_shape, eval
             return objs
     with torch.no_grad():
         lazy = _lazy(model)
+        scale = _scale32(im_info)            # a blocking device read: before the forward is enqueued, not behind it
         out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy, alias_outputs=True)
-        st = launch_3d(out, im_left_data, im_right_data, im_info, _scale32(im_info), calib, im_shape, eval_thresh,
+        st = launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape, eval_thresh,
                        class_index, dense_align, slot, solver, lazy=_plan_of(model, im_left_data, slot) if lazy else None)
     try:
         return collect_3d(st)
@@ -531,11 +532,18 @@ def image_outputs(out, b):
 
 
 def launch_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shapes, eval_thresh=0.05, class_index=1,
-                    dense_align=True, slot=0, solver='host'):
+                    dense_align=True, slot=0, solver='host', scales=None):
     """BASELINE configs[2] form: ONE forward over a batch of B pairs (rois carry the batch index, proposal_layer.py:139), then
     the 3-D stage of every image of the batch (the reference's post-processing is per image: demo.py:153,212) enqueued on the
-    current stream, each with its own stage buffers.  Returns the handles for collect_3d_batch()."""
+    current stream, each with its own stage buffers.  Returns the handles for collect_3d_batch().
+
+    scales: the B resize factors (im_info[:, 2]) as Python floats when the caller has them on the host.  Otherwise they are read
+    from the device BEFORE the forward is enqueued: reading im_info[b, 2] per image afterwards, as this function did until round
+    6, is a blocking copy behind the whole forward and every earlier image's 3-D stage -- eight of them made the batch form
+    host-serialised (53 of its 61 ms per batch, tools/batch_host_probe.py)."""
     B = int(im_left_data.shape[0])
+    if scales is None:
+        scales = [float(v) for v in im_info.view(-1, 3)[:, 2].cpu()]        # float32 elements -> Python floats, as _scale32
     with torch.no_grad():
         lazy = _lazy(model)
         out = model(im_left_data, im_right_data, im_info, slot=slot, kpts=not lazy, alias_outputs=True)
@@ -544,7 +552,7 @@ def launch_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shap
         for b in range(B):
             info_b = im_info.view(-1, 3)[b:b + 1]
             handles.append(launch_3d(image_outputs(out, b), im_left_data[b:b + 1], im_right_data[b:b + 1], info_b,
-                                     _scale32(info_b), calibs[b], im_shapes[b], eval_thresh, class_index, dense_align,
+                                     scales[b], calibs[b], im_shapes[b], eval_thresh, class_index, dense_align,
                                      (slot, b), solver, lazy=pl))
         for h in handles[1:]:
             h.batch_head = handles[0]        # see collect_3d: the shared forward's range flag lives in image 0's record
@@ -554,7 +562,15 @@ def launch_3d_batch(model, im_left_data, im_right_data, im_info, calibs, im_shap
 def collect_3d_batch(handles):
     """Object lists of the batch, one per image.  The batch shares one forward and therefore one range flag: the record of the
     first image carries it (the pack clears the word), and a tripped flag condemns the whole batch -- every other handle of the
-    batch looks at image 0's record too (`batch_head`), so per-handle collect_3d() in any order raises as well."""
+    batch looks at image 0's record too (`batch_head`), so per-handle collect_3d() in any order raises as well.
+
+    solver='host': the host phases run image-major per phase, not phase-major per image -- every image's 4-DoF solves and
+    dense-alignment launch first, then every image's 3-DoF solves -- so the host solves image b + 1 while the device aligns image
+    b, instead of sitting in front of each alignment's event in turn (eight waits of a busy GPU's queueing latency per batch)."""
+    for phase in (1, 2):
+        for st in handles:
+            if st.phase == phase:
+                step_3d(st)
     return [collect_3d(st) for st in handles]
 
 
