@@ -24,6 +24,102 @@ from .model.utils import kitti_utils
 from .model.utils.config import cfg
 
 
+# PNG decode of the KITTI loop in worker PROCESSES (default; SRCNN_DECODE_PROCESSES=0 = decoder threads inside this process, round 5's form)
+DECODE_PROCESSES = os.environ.get('SRCNN_DECODE_PROCESSES', '1') != '0'
+
+
+class _DecodeWorkers(object):
+    """`n` png_worker.py processes and the shared file they decode into (one slot of two images per worker).  decode() hands a
+    request to an idle worker and blocks the calling THREAD on its answer (a pipe read: no GIL held), then returns views of the
+    worker's slot and the worker itself -- the caller copies the pixels out (into the page-locked ring) and release()s it."""
+
+    def __init__(self, n, nbytes=3 * 512 * 1408):
+        import mmap
+        import queue
+        import subprocess
+        import sys
+        import tempfile
+        self.n, self.nbytes = n, nbytes
+        base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+        fd, self.path = tempfile.mkstemp(prefix='srcnn_png_', dir=base)
+        os.ftruncate(fd, n * 2 * nbytes)
+        self.mm = mmap.mmap(fd, 0)
+        os.close(fd)
+        self.view = np.frombuffer(self.mm, dtype=np.uint8)
+        script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'png_worker.py')
+        self.procs, self.idle = [], queue.Queue()
+        try:
+            for i in range(n):
+                self.procs.append(subprocess.Popen([sys.executable, script, self.path, str(i), str(nbytes)], stdin=subprocess.PIPE,
+                                                   stdout=subprocess.PIPE, universal_newlines=True, bufsize=1))
+            for i, pr in enumerate(self.procs):
+                if pr.stdout.readline().strip() != 'ready':
+                    raise RuntimeError('PNG decode worker %d did not start (exit code %s)' % (i, pr.poll()))
+                self.idle.put(i)
+        except Exception:
+            self.close()
+            raise
+        os.unlink(self.path)              # every worker has it mapped: the file goes away with the last mapping
+        self.path = None
+
+    def decode(self, paths):
+        import json
+        i = self.idle.get()
+        pr = self.procs[i]
+        try:
+            pr.stdin.write(json.dumps({'paths': list(paths)}) + '\n')
+            pr.stdin.flush()
+            line = pr.stdout.readline()
+            if not line:
+                raise RuntimeError('PNG decode worker %d died (exit code %s)' % (i, pr.poll()))
+            reply = json.loads(line)
+            if 'error' in reply:
+                raise RuntimeError('PNG decode worker: %s' % reply['error'])
+        except Exception:
+            self.idle.put(i)
+            raise
+        base, out = i * 2 * self.nbytes, []
+        for k, shape in enumerate(reply['shapes']):
+            nb = int(np.prod(shape))
+            out.append(self.view[base + k * self.nbytes: base + k * self.nbytes + nb].reshape(shape))
+        return i, out
+
+    def release(self, i):
+        self.idle.put(i)
+
+    def close(self):
+        for pr in self.procs:
+            try:
+                pr.stdin.close()
+            except Exception:
+                pass
+        for pr in self.procs:
+            try:
+                pr.wait(timeout=5)
+            except Exception:
+                pr.kill()
+        self.procs = []
+        if self.path:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+            self.path = None
+
+
+_decode_workers = {}
+
+
+def decode_workers(n):
+    """The process-wide set of `n` decode workers (started on first use, reused by later splits, stopped at exit)."""
+    w = _decode_workers.get(n)
+    if w is None:
+        import atexit
+        w = _decode_workers[n] = _DecodeWorkers(n)
+        atexit.register(w.close)
+    return w
+
+
 def read_split(path):
     with open(path) as fh:
         return [ln.strip() for ln in fh if ln.strip()]
@@ -118,13 +214,22 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
 
     zero_copy = detect_stream is None and solver in ('device', 'host') and ZERO_COPY_IMAGES
     ring = _PinnedRing(max(1, prefetch) + max(1, slots) + 4) if zero_copy else None
+    # decode in worker processes: the default reader on the zero-copy path (a custom `read_image` runs on the prefetch threads)
+    workers = decode_workers(max(1, prefetch)) if (ring is not None and read_image is read_png_rgb and DECODE_PROCESSES) else None
 
     def load(j, frame):
         td = time.perf_counter()
-        left = read_image(os.path.join(kitti_root, 'image_2', frame + '.png'))
-        right = read_image(os.path.join(kitti_root, 'image_3', frame + '.png'))
+        paths = (os.path.join(kitti_root, 'image_2', frame + '.png'), os.path.join(kitti_root, 'image_3', frame + '.png'))
+        if workers is not None:
+            w, (left, right) = workers.decode(paths)            # this thread sleeps on the worker's pipe meanwhile
+            try:
+                left, right = ring.put(j, left, right)          # out of the worker's slot into the page-locked ring
+            finally:
+                workers.release(w)
+        else:
+            left, right = read_image(paths[0]), read_image(paths[1])
         calib = kitti_utils.read_obj_calibration(os.path.join(kitti_root, 'calib', frame + '.txt'))
-        if ring is not None:
+        if ring is not None and workers is None:
             left, right = ring.put(j, left, right)              # page-locked views the preprocessing kernel reads directly
         if timers is not None:
             timers['decode_s'] += time.perf_counter() - td        # (float += under the GIL: good enough for a per-pair average)

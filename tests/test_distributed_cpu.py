@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -254,3 +255,38 @@ def test_bench_config3_val_list_replay_dry_run_world_2():
     assert sat['LOCAL_WORLD_SIZE'] == 2 and sat['pairs_per_s_at_which_the_host_saturates'] > 0
     assert {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
             'data', 'config', 'roofline'} <= set(d)
+
+
+def test_png_decode_worker_processes(tmp_path):
+    """test_net._DecodeWorkers: png_worker.py processes decode into their slots of a shared file; several threads drive them at
+    once (as run_split's prefetch threads do); pixels equal read_png_rgb's; a failing request raises in the caller and leaves the
+    worker usable; the worker script imports neither torch nor the package."""
+    import concurrent.futures as cf
+    import os
+    import numpy as np
+    from stereo_rcnn_amd import fixture, test_net
+    src = open(os.path.join(os.path.dirname(test_net.__file__), 'png_worker.py')).read()
+    assert 'import torch' not in src and 'stereo_rcnn_amd' not in src.split('"""')[2]
+    ids = fixture.write_kitti_tree(str(tmp_path), 7, distinct=3, height=48, width=160)
+    w = test_net._DecodeWorkers(2)
+    try:
+        def one(f):
+            i, (l, r) = w.decode((str(tmp_path / 'image_2' / (f + '.png')), str(tmp_path / 'image_3' / (f + '.png'))))
+            try:
+                return l.copy(), r.copy()
+            finally:
+                w.release(i)
+        with cf.ThreadPoolExecutor(4) as ex:
+            res = list(ex.map(one, ids))
+        for f, (l, r) in zip(ids, res):
+            assert np.array_equal(l, test_net.read_png_rgb(str(tmp_path / 'image_2' / (f + '.png'))))
+            assert np.array_equal(r, test_net.read_png_rgb(str(tmp_path / 'image_3' / (f + '.png'))))
+        with pytest.raises(RuntimeError, match='FileNotFoundError'):
+            w.decode(('/nonexistent/left.png', '/nonexistent/right.png'))
+        assert w.idle.qsize() == 2                         # both workers back in the idle set
+        l, r = one(ids[0])
+        assert np.array_equal(l, res[0][0])
+        assert w.path is None                              # the shared file is unlinked once every worker has mapped it
+    finally:
+        w.close()
+    assert all(pr.poll() is not None for pr in w.procs) or not w.procs

@@ -113,6 +113,15 @@ def test_kitti_split_driver_writes_result_files(dev, tmp_path):
     assert frames2 == 3
     for f in written:
         assert (tmp_path / 'result2' / 'data' / f).read_text() == (tmp_path / 'result' / 'data' / f).read_text()
+    # PNG decode on threads of this process (round 5's form) instead of the worker processes: the same pixels, the same files
+    assert test_net.DECODE_PROCESSES and test_net._decode_workers
+    test_net.DECODE_PROCESSES = False
+    try:
+        test_net.run_split(m, str(root), ids, str(tmp_path / 'result_threads'), dev)
+    finally:
+        test_net.DECODE_PROCESSES = True
+    for f in sorted(os.listdir(str(tmp_path / 'result2' / 'data'))):
+        assert (tmp_path / 'result_threads' / 'data' / f).read_text() == (tmp_path / 'result2' / 'data' / f).read_text()
     # the scipy comparison arrangement (host numpy + scipy in a process pool, staged) finds the same objects per frame
     with pipeline.SolverPool(2) as pool:
         frames3, n_obj3, _ = test_net.run_split(m, str(root), ids, str(tmp_path / 'result3'), dev, pool, solver='scipy')

@@ -30,7 +30,8 @@ l, r, info = [t.to(dev) for t in fixture.make_inputs(3, 375, 1242)]
 calib, shape = bench.demo_calib(), (375, 1242, 3)
 frame = (l, r, info, calib, shape, float(info[0, 2]))
 lu, ru = fixture.synthetic_pair(3, 375, 1242)
-lp, rp = torch.from_numpy(lu).pin_memory(), torch.from_numpy(ru).pin_memory()
+import numpy as np
+lp, rp = torch.from_numpy(np.ascontiguousarray(lu)).pin_memory(), torch.from_numpy(np.ascontiguousarray(ru)).pin_memory()
 l8, r8, i8 = bench.make_batch(2, 0, 375, 1242, dev)
 pipeline.HOST_SOLVER_THREADS = sdist.host_solver_threads()
 root = tempfile.mkdtemp(prefix='kitti_')
