@@ -28,6 +28,10 @@ from .model.utils.config import cfg
 DECODE_PROCESSES = os.environ.get('SRCNN_DECODE_PROCESSES', '1') != '0'
 
 
+# result files + records on a writer thread (SRCNN_WRITER_THREAD=0: written by the loop thread between two launches)
+WRITER_THREAD = os.environ.get('SRCNN_WRITER_THREAD', '1') != '0'
+
+
 class _DecodeWorkers(object):
     """`n` png_worker.py processes and the shared file they decode into (one slot of two images per worker).  decode() hands a
     request to an idle worker and blocks the calling THREAD on its answer (a pipe read: no GIL held), then returns views of the
@@ -279,19 +283,37 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
             for f in frames():
                 yield pipeline.detect_3d(model, *f[:5], solver='scipy')
 
-    for k, (frame, objs) in enumerate(zip(ids, results())):
-        calib = calibs.popleft()
+    def write(frame, calib, objs):
         tw = time.perf_counter()
         open(os.path.join(result_dir, 'data', frame + '.txt'), 'w').close()      # a frame without detections still gets a file
         pipeline.write_kitti_results(result_dir, frame, calib, [o for o in objs if o['aligned']])   # test_net.py:322-330
-        n_obj += sum(o['aligned'] for o in objs)
         if records is not None:
             from .distributed import objects_to_record
             records.append(objects_to_record(objs))
         if timers is not None:
             timers['write_s'] += time.perf_counter() - tw
-        if log and (k + 1) % 50 == 0:
-            log('%d/%d frames, %.1f frames/s' % (k + 1, len(ids), (k + 1) / (time.time() - t0)))
+
+    # result files and records on ONE writer thread, in frame order: the loop thread goes straight back to launching the next pair
+    # (with the PNG decoders in processes of their own the writer is the only other user of this interpreter)
+    writer = cf.ThreadPoolExecutor(max_workers=1) if WRITER_THREAD else None
+    written = collections.deque()
+    try:
+        for k, (frame, objs) in enumerate(zip(ids, results())):
+            calib = calibs.popleft()
+            n_obj += sum(o['aligned'] for o in objs)
+            if writer is None:
+                write(frame, calib, objs)
+            else:
+                written.append(writer.submit(write, frame, calib, objs))
+                while len(written) > 64:
+                    written.popleft().result()                                   # bounded backlog; raises what the writer raised
+            if log and (k + 1) % 50 == 0:
+                log('%d/%d frames, %.1f frames/s' % (k + 1, len(ids), (k + 1) / (time.time() - t0)))
+        while written:
+            written.popleft().result()
+    finally:
+        if writer is not None:
+            writer.shutdown(wait=True)
     if device is not None and torch.device(device).type == 'cuda':
         torch.cuda.synchronize(device)
     if timers is not None:
