@@ -229,14 +229,15 @@ def launch_3d(out, im_left_data, im_right_data, im_info, scale, calib, im_shape,
 
 
 HOST_SOLVER_THREADS = 0          # srcnn_solve_*_records_host: <= 0 = one thread per 8 detections, at most 16
-# Streamed flow, solver='host', OPT-IN (SRCNN_ASYNC_HOST=1): the host phases of a pair (wait for its device stage, 4-DoF solves, record
-# back + dense alignment launch, wait, 3-DoF solves) on a WORKER thread per pair in flight instead of on the loop thread between
-# launches.  Built in round 6 for VERDICT r5 item 8 and measured (profiles/flow3d_async_host_r06.txt, same box): the loop thread's busy
-# time per pair drops 3.55 -> 2.14 ms (its saturation point 282 -> 467 pairs/s) and the throughput does NOT move -- tensor-input flow
-# 6.16 -> 6.08-6.16 ms per pair, configs[3] 138.1 -> 136.7 pairs/s at four in flight, 140.6 -> 123.2 at six (the workers, the 16 PNG
-# decoder threads and the loop share one GIL) -- the flow is GPU-bound at 6.1 ms (7.2 with decode + H2D + files), not loop-bound.
-# Same calls on the same streams in the same order per pair either way.
-ASYNC_HOST_PHASES = _os.environ.get('SRCNN_ASYNC_HOST', '0') != '0'
+# Streamed flow, solver='host' (default; SRCNN_ASYNC_HOST=0 = on the loop thread between launches): the host phases of a pair (wait for
+# its device stage, 4-DoF solves, record back + dense alignment launch, wait, 3-DoF solves) on a WORKER thread per pair in flight.
+# Same calls on the same streams in the same order per pair either way.  History of the switch (round 6): built for VERDICT r5 item
+# 8 and first measured with the KITTI loop's 16 PNG decoders as threads of this interpreter -- the loop thread's busy time per pair
+# fell 3.55 -> 2.14 ms and the throughput did not move (configs[3] 138.1 -> 136.7 pairs/s, 123 at six in flight: workers, decoders
+# and loop on one GIL; profiles/flow3d_async_host_r06.txt), so it stayed off.  With the decoders in processes of their own
+# (test_net._DecodeWorkers) the same switch gives configs[3] 155.6-163.4 -> 169.7-170.0 pairs/s on one box and leaves the
+# tensor-fed flow where it was (GPU-bound at 5.7 ms per pair: 175.2 vs 175.5) -- profiles/config3_host_side_r06.txt.
+ASYNC_HOST_PHASES = _os.environ.get('SRCNN_ASYNC_HOST', '1') != '0'
 _host_pool = None
 import threading as _threading
 _timers_lock = _threading.Lock()

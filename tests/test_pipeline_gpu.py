@@ -222,7 +222,7 @@ def test_three_in_flight_soak_is_bit_repeatable(dev, solver):
 
 
 def test_async_host_phases_give_the_same_objects(dev):
-    """pipeline.ASYNC_HOST_PHASES (opt-in, SRCNN_ASYNC_HOST=1): a pair's host phases on a worker thread instead of on the loop
+    """pipeline.ASYNC_HOST_PHASES (default; SRCNN_ASYNC_HOST=0 switches it off): a pair's host phases on a worker thread instead of on the loop
     thread -- the same calls on the same streams in the same order per pair: every frame's objects equal the default
     arrangement's bit for bit, also when a pair's slot is reused."""
     from oracle.dense_align import KITTI_DEMO_CALIB as calib
