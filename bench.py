@@ -531,12 +531,15 @@ def run_config3(args, rank, local_rank, world, use_dist):
         main_wait = ptimers.get('main_wait_s', 0.0) if async_host else ptimers.get('gpu_wait_s', 0.0)
         main_busy = max(0.0, timers.get('loop_s', 0.0) - main_wait)
         host_ms = {'png_decode_and_calib_parse': per('decode_s', timers), 'png_decode_threads': prefetch,
+                   'png_decode_in': 'worker processes (one per prefetch thread, stereo_rcnn_amd/png_worker.py)' if (not dry and test_net.DECODE_PROCESSES and test_net.ZERO_COPY_IMAGES) else 'threads of the loop process',
+                   'result_files_on': 'a writer thread' if test_net.WRITER_THREAD else 'the loop thread',
                    'h2d_issue': per('h2d_s', timers), 'newton_cg_solves_wall': per('solve_s', ptimers), 'host_solver_threads': threads,
                    'result_files_and_record': per('write_s', timers), 'waiting_for_the_gpu': round(main_wait * 1e3 / max(K, 1), 3),
                    'workers_waiting_for_the_gpu': per('gpu_wait_s', ptimers), 'async_host_phases': bool(async_host),
                    'main_thread_busy': round(main_busy * 1e3 / max(K, 1), 3),
-                   'note': 'ms per pair on THIS rank; decode is summed over its threads (they run ahead of the loop); the Newton-CG solves and the waits in '
-                           'front of a pair\'s device stages run on one worker thread per pair in flight, the result files on a writer thread; '
+                   'note': 'ms per pair on THIS rank; decode is the wall time of a frame\'s two PNGs + calibration summed over the prefetch threads (each sleeps on its '
+                           'worker process meanwhile; they run ahead of the loop); with async_host_phases the Newton-CG solves and the waits in '
+                           'front of a pair\'s device stages run on one worker thread per pair in flight; '
                            'main_thread_busy = loop wall time minus the time the loop thread was blocked = launching + Python'}
         dec_rate = prefetch * 1e3 / max(host_ms['png_decode_and_calib_parse'], 1e-6)
         main_rate = 1e3 / max(host_ms['main_thread_busy'], 1e-6)
