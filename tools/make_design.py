@@ -40,7 +40,6 @@ s1 = rep(s1, "| HIP, masked fixed-size batch; parity vs oracle + reference-code 
          "| HIP, masked fixed-size batch; **argmin index of both stages exact** on every fixture (91 objects: 0 flips; cost vectors exposed through `srcnn_dense_align_workspace_layout` and tie-audited, §6), disparities bit-equal to the oracle and to the reference-code golden; planted-disparity property; bit-repeatable beside concurrent forwards (306-frame soak in `pytest -m gpu`, §6) |")
 s1 = rep(s1, "(it) and `cpu_baseline`" if False else "and `cpu_baseline`; `--config 1|2|4`", "and `cpu_baseline`; round 6: **`sustained`** (2 s soak + 300 steps), **`parity`** (demo pair, NMS lists, 3-D boxes, dense-alignment indices against the reference goldens / oracle, computed in the run: `bench_parity.py`), **`roofline.non_conv`** (every non-conv kernel family: µs alone, bytes, GB/s, fraction of 6.3 TB/s); `--config 1|2|4`")
 s1 = rep(s1, "| BASELINE configs[2] (batch 8, full pipeline) |", "| chained bottleneck launch (round 6; VERDICT r5 item 1) | `csrc/conv_chain.hip:conv_chain_kernel`, `srcnn_conv2d_chain`, `engine.conv_chain`, `plan.trunk` | `[conv2 3×3 → conv3 (+ residual / projection shortcut) → conv1 of the next block]` (`resnet.py:82-102`, shifted by one convolution so the 3×3 comes first) as ONE launch whose workgroups keep their rows; bit-identical to the three launches on every tile (`tests/test_conv_chain_gpu.py`); **measured neutral** on the headline at every depth (§8) — opt-in (`SRCNN_BOTTLENECK_CHAIN=1`), 119 → 73 conv launches |\n| BASELINE configs[2] (batch 8, full pipeline) |")
-s1 = rep(s1, "(`value` 125–130 pairs/s **with** the whole 3-D flow and the keypoint branch on all rois; 145 the way the pipeline runs it, §5)", "(`value` %.0f pairs/s **with** the whole 3-D flow and the keypoint branch on all rois, §4)" % B2['value'])
 s1 = rep(s1, "driver-runnable (58–61 pairs/s)", "driver-runnable (%.1f pairs/s)" % B4['value'])
 
 # ------------------------------------------------------------------ section 2: tolerances
@@ -92,7 +91,7 @@ for all 300 rois of every forward, as the reference's `forward` does:
 | … keypoint branch on the kept detections only (the pipeline's default) | **%.1f** | %.2f | |
 | strictly one pair at a time (branches on side streams, in-situ plans) | **%.1f** | %.2f | backbone alone on the chip: 731.2 GFLOP in %.2f ms = %.1f TF = %.3f issued of 2.5 PF (`roofline.backbone`) |
 | exact fp32 engine, four in flight | %.1f | %.1f | %.2f of the 157.3 TF fp32 MFMA peak in headline mode |
-| full 3-D flow, four in flight (48 frames incl. pipeline fill), `solver='host'` | %.1f with the keypoint branch in the forward, **%.1f** as the pipeline runs it · `'device'` %.1f | | |
+| full 3-D flow, four in flight (160 frames), `solver='host'` | %.1f with the keypoint branch in the forward, **%.1f** as the pipeline runs it · `'device'` %.1f | | |
 | **configs[2]** batch 8 + the whole 3-D flow per image | %.1f | %.1f per 8 pairs | kernel level frac %.4f |
 | **configs[3]** the 3769-id val list replayed from PNG files, four in flight (§10) | **%.1f** | %.2f | |
 | **configs[4]** ResNet-50, 1200×3974, batch 4 | %.1f | %.1f per 4 pairs | kernel level frac %.4f |
@@ -143,7 +142,23 @@ s5 = rep(s5, "* 3-D stage (`pipeline.py`)", '''* **More than one convolution per
   threads now write into a ring of page-locked buffers and the fused preprocessing kernel reads them over the bus where they are (5.94 ms):
   configs[3] 130 -> 138 pairs/s.  The host solvers' thread count became a budget (5 threads for ~40 detections instead of 16, whose
   creation cost more than the rows they took): 1.07 -> 0.49 ms of solves per pair, configs[3] 141, loop thread busy 2.7 ms per pair.
-* 3-D stage (`pipeline.py`)'''.replace('%%', '%'))
+* **One interpreter, one job** (round 6, second pass; `config3_host_side_r06.txt`).  The KITTI loop still lost 1.2 ms per pair against the
+  same flow fed tensors, and taking the PNG decode out (images served from memory) gave it back: 16 decoder THREADS are not short of cores
+  (21 ms of CPU per pair), they are hundreds of GIL hand-overs per image against a loop thread that makes ~300 ctypes launches per pair.
+  The decoders are worker PROCESSES now (`stereo_rcnn_amd/png_worker.py`: numpy + PIL only; each decodes into its slot of a shared file, the
+  prefetch thread that sleeps on its pipe copies the pixels into the page-locked ring): loop thread busy 2.97 -> 2.36 ms.  With the
+  interpreter to themselves the two switches that had bought nothing earlier in the round pay: result files + records on a writer thread
+  (144-151 -> 154-156 pairs/s) and the host phases of every pair in flight on a worker thread (156-163 -> 170; default on now, the
+  tensor-fed flow is GPU-bound and does not move).  configs[3] 141.7 -> @C3@ pairs/s on the refresh box = the tensor-fed flow's rate;
+  the host side saturates at @C3SAT@.
+* **No blocking device read behind an enqueued forward** (round 6; `config2_blocking_reads_r06.txt`, `tools/sync_probe.py`).  The batch
+  form (configs[2]) read `im_info[b, 2]` from the DEVICE once per image after the batch's forward had been enqueued: eight blocking copies,
+  each behind the forward and every earlier image's 3-D stage -- 53 of its 61 ms per batch were the host sitting in them
+  (`host_enqueue_ms_per_step` equal to `ms_per_step` was the symptom).  The scales are read once before the forward (or passed in), and
+  `collect_3d_batch` runs the host phases image-major per phase instead of waiting for each image's alignment in turn: configs[2]
+  130.6 -> @C2@ pairs/s (keypoints on the kept detections only: 146.6 -> @C2KEPT@).  torch's sync debug mode finds no other blocking call in
+  any flow (`tools/sync_probe.py`: streamed flows, batch form, KITTI loop).
+* 3-D stage (`pipeline.py`)'''.replace('%%', '%').replace('@C3@', '%.1f' % B3['value']).replace('@C3SAT@', '%.0f' % B3['config']['host_saturation']['pairs_per_s_at_which_the_host_saturates']).replace('@C2@', '%.1f' % B2['value']).replace('@C2KEPT@', '%.1f' % B2['config']['keypoints_on_kept_detections_only']['value']))
 
 # ------------------------------------------------------------------ section 6 (rewritten)
 s6 = '''## 6. Dense alignment (A15/A16)
@@ -260,8 +275,9 @@ workgroups' residency unchanged (fewer launches, re-reads from a nearer cache, o
    the two waves of a SIMD are not parked at the same barrier; the kernels that run it are 60 %% of the step.
 4. **MFMA-form head, second pass** (weight slice by the ring's DMA at kernel start, 16-row blocks on `v_mfma_f32_16x16x32_f16`): 42 → ≈20 µs of
    the P2 launch, and the keypoint classifier's MFMA form no slower than the VALU form.
-5. **configs[3]'s last 1.2 ms per pair** (%.0f pairs/s against %.0f for the same flow fed device-resident tensors): not the decoders, not the
-   GIL's switch interval, not H2D copies any more (§10); a per-frame timeline of the loop thread with the device's own timestamps is the next step.
+5. **The flows are GPU-bound now** (configs[3] %.0f pairs/s against %.0f for the same flow fed device-resident tensors; configs[2] host enqueue
+   1.7 ms per batch of 8 with the GPU idle): their next step is the headline's (items 1-3), plus the batch form's own: its 3-D stage runs image
+   after image on the batch's stream (latency-bound kernels, ≈1.5 ms per image) where the streamed form overlaps them with other pairs' forwards.
 6. **Device solvers** ((f)1): built this round as a wavefront per detection with the residuals across lanes (§7): 4× (961 → 241 µs),
    bit-identical to the scalar form, level with the host placement at four in flight.  The remaining time is a chain of ≈450 dependent
    evaluations per object; ≤150 µs needs another optimiser (batched Gauss-Newton on the true Jacobian), which would end iteration-level
@@ -279,7 +295,7 @@ s12 = '''## 12. Changelog
 | 3 | 141.9 | 0.0991 | buffer-descriptor LDS DMA; 256×256 tile on 8 waves; (channel tile, tap) K order; per-tensor SPLIT16 scales; stereo RPN conv as one launch; projection shortcut inside conv3; keypoint branch on kept detections (pipeline default); per-layer roofline table |
 | 4 | 150.4 | 0.0977 | one hardware queue per forward in flight (+8 %%); throughput-objective tuner + shipped plans; keypoint classifier inside the deconvolution; sustained-rate probe (1.50 PF); two-product / Winograd no-go |
 | 5 | 154.5 | 0.0949 | RPN head as a second GEMM in `RPN_Conv`'s epilogue; in-mix per-layer instruments (marginal cost, stamps, energy); radix passes without a device-scope fence (+4 %%); ROIAlign one workgroup per roi; configs[3] driver-runnable; decision-level tie audit of the proposal layer |
-| 6 | (driver: `BENCH_r06.json`; builder-run %.1f, %.1f sustained) | %.4f | tile code shared by single / CHAINED / GROUPED launches (chain: bit-identical, neutral, opt-in; RPN P3–P6 grouped); dense-alignment argmin exact (scalar/tensor semantics) + cost vectors exposed; `upsample2x` 90 → 29 µs; tolerances centralised at 2× measured; bench line: `sustained`, `parity`, `roofline.non_conv`; 3-D flows: one process-wide stream set (+17 %% on the bench's 3-D leg), zero-copy images + solver thread budget (configs[3] 130 → 141); device solvers with the residuals across lanes (4×, bit-identical to the scalar form); ADVICE r5 |
+| 6 | (driver: `BENCH_r06.json`; builder-run %.1f, %.1f sustained) | %.4f | tile code shared by single / CHAINED / GROUPED launches (chain: bit-identical, neutral, opt-in; RPN P3–P6 grouped); dense-alignment argmin exact (scalar/tensor semantics) + cost vectors exposed; `upsample2x` 90 → 29 µs; tolerances centralised at 2× measured; bench line: `sustained`, `parity`, `roofline.non_conv`; 3-D flows: one process-wide stream set (+17 %% on the bench's 3-D leg), zero-copy images + solver thread budget (configs[3] 130 → 141); device solvers with the residuals across lanes (4×, bit-identical to the scalar form); blocking reads behind the forward out of the batch form (configs[2] 131 → 156); KITTI loop: decoder processes, writer thread, worker-thread host phases (configs[3] 142 → 176); ADVICE r5 |
 
 ''' % (B['value'], B['sustained']['value'], R['frac'])
 hm = B3['config']['host_ms_per_pair']
@@ -287,15 +303,15 @@ s10 = '''## 10. Host-buffer note
 
 The boundary takes device pointers -- or, for the uint8 images of the fused preprocessing, page-locked HOST pointers that the kernel reads
 over the bus (round 6).  `value` is measured with inputs resident in HBM.  The PCIe-inclusive path is configs[3] (`bench.py --config 3`):
-decoded images land in a ring of page-locked buffers (written by the decoder threads) and are read where they are -- 2 × 1.4 MB per pair,
+decoded images land in a ring of page-locked buffers (decoded by worker processes into a shared file, copied in by the prefetch threads) and are read where they are -- 2 × 1.4 MB per pair,
 no `hipMemcpyAsync` (two of them per frame cost the flow 1.0 ms per pair, §5); `solver='host'` adds 2 × 38 KB + 9.6 KB D2H and 38 KB H2D of
 record per pair.  **Measured end to end (configs[3])**: %.1f pairs/s (%.2f ms per pair); per pair on one rank: PNG decode + calibration parse
-%.1f ms summed over %d decode threads (they run ahead), Newton-CG solves %.2f ms wall, result files + record %.2f ms, loop thread busy %.2f ms,
-waiting for the GPU %.2f ms: the host side saturates at %.0f pairs/s (the single-threaded loop), the decode threads at %.0f.  The same flow fed
-device-resident tensors runs at 5.7–5.9 ms per pair (170–177 pairs/s, `full_3d_flow`); the remaining 1.2 ms of configs[3] is not the decoders
-(4 / 8 / 16 threads, or none: a decode cache gives +4 %%), not the interpreter's switch interval, not the result files' share of the loop
-(`flow3d_input_path_r06.txt`); running the host phases on worker threads was built and measured slower (one GIL; opt-in `SRCNN_ASYNC_HOST=1`,
-`flow3d_async_host_r06.txt`).  On an 8-GPU node every rank gets cores / 8 (≤16 solver threads as a budget, NUMA-pinned, §5).
+%.1f ms summed over %d decode workers (they run ahead), Newton-CG solves %.2f ms wall, result files + record %.2f ms, loop thread busy %.2f ms,
+waiting for the GPU %.2f ms: the host side saturates at %.0f pairs/s (the single-threaded loop), the decode workers at %.0f.  The same flow fed
+device-resident tensors runs at 5.6–5.9 ms per pair (170–177 pairs/s, `full_3d_flow`), and since the round's second pass so does this one: the
+1.2 ms it used to lose were the decoder THREADS' GIL hand-overs against the loop thread (decode served from memory gave them back); with the
+decoders in worker processes, the result files on a writer thread and every pair's host phases on a worker thread the loop thread is busy
+1.5 ms per pair and waits for the device the rest of the time (§5, `config3_host_side_r06.txt`).  On an 8-GPU node every rank gets cores / 8 (≤16 solver threads as a budget, NUMA-pinned, §5).
 
 ''' % (B3['value'], B3['ms_per_step'], hm['png_decode_and_calib_parse'], hm['png_decode_threads'], hm['newton_cg_solves_wall'], hm['result_files_and_record'],
        hm['main_thread_busy'], hm['waiting_for_the_gpu'], B3['config']['host_saturation']['main_thread_bound_pairs_per_s'], B3['config']['host_saturation']['decode_bound_pairs_per_s'])
