@@ -219,7 +219,13 @@ def run_split(model, kitti_root, ids, result_dir, device, pool=None, read_image=
     zero_copy = detect_stream is None and solver in ('device', 'host') and ZERO_COPY_IMAGES
     ring = _PinnedRing(max(1, prefetch) + max(1, slots) + 4) if zero_copy else None
     # decode in worker processes: the default reader on the zero-copy path (a custom `read_image` runs on the prefetch threads)
-    workers = decode_workers(max(1, prefetch)) if (ring is not None and read_image is read_png_rgb and DECODE_PROCESSES) else None
+    workers = None
+    if ring is not None and read_image is read_png_rgb and DECODE_PROCESSES:
+        try:
+            workers = decode_workers(max(1, prefetch))
+        except (OSError, RuntimeError) as e:       # no room for the shared file, no process table entries, ...: decode on the threads
+            import warnings
+            warnings.warn('PNG decode workers unavailable (%s): decoding on %d threads of this process' % (e, max(1, prefetch)))
 
     def load(j, frame):
         td = time.perf_counter()
