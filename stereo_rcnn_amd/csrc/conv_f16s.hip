@@ -103,12 +103,15 @@ bool conv_f16s_plan_ok(const Plan &pl, const ConvArgs &a)
     case 224: return pl.stages == 2;
     case 228: return pl.stages == 2 || pl.stages == 4;
     case 428: return pl.stages == 3;
+    case 424: case 244:                       // 256x128 / 128x256 on 4 waves of 128x64 / 64x128 (explicit plans and the throughput tuner only)
+        if (pl.stages != 2 && pl.stages != 3) return false;
+        [[fallthrough]];
     case 444:                                 // 256x256 on 4 waves of 128x128 (one wave per SIMD, 256 accumulator registers): a
                                               // third fewer LDS fragment reads per MFMA than the 8-wave form (16 per 48 instead of 12 per 24)
     case 448: {                               // 256x256 on 8 waves of 64x128 (two waves per SIMD, 256 registers each):
         const int cq = a.mode == 1 ? (a.Cout >> 2) : a.Cout;      // vector epilogue only (see the kernel's general path)
-        if (t == 444 && (a.head_w || a.head_wf)) return false;   // the fused heads live in the 8-wave form
-        return pl.stages == 2 && !a.x2 && !a.up_top && (cq & 7) == 0 && (a.ycs & 7) == 0 && (a.yco & 7) == 0 && (!a.res || (a.rcs & 7) == 0);
+        if (t != 448 && (a.head_w || a.head_wf)) return false;   // the fused heads live in the 8-wave form
+        return (pl.stages == 2 || t == 424 || t == 244) && !a.x2 && !a.up_top && (cq & 7) == 0 && (a.ycs & 7) == 0 && (a.yco & 7) == 0 && (!a.res || (a.rcs & 7) == 0);
     }
     default: return false;
     }
@@ -130,6 +133,10 @@ void launch_conv_f16s(const ConvArgs &a, const Plan &pl, hipStream_t st)
     case 4283: launch<2, 2, 4, 3>(a, pl.splits, st); break;   // 256x128 on 8 waves of 64x64
     case 4482: launch<2, 4, 4, 2>(a, pl.splits, st); break;   // 256x256 on 8 waves of 64x128
     case 4442: launch<4, 4, 2, 2>(a, pl.splits, st); break;   // 256x256 on 4 waves of 128x128
+    case 4242: launch<4, 2, 2, 2>(a, pl.splits, st); break;   // 256x128 on 4 waves of 128x64
+    case 4243: launch<4, 2, 2, 3>(a, pl.splits, st); break;
+    case 2442: launch<2, 4, 2, 2>(a, pl.splits, st); break;   // 128x256 on 4 waves of 64x128
+    case 2443: launch<2, 4, 2, 3>(a, pl.splits, st); break;
     default: launch<1, 1, 2, 2>(a, pl.splits, st); break;     // unreachable: plan_for() validates with conv_f16s_plan_ok
     }
 }

@@ -267,7 +267,7 @@ def test_conv_with_projection_shortcut_as_second_operand(dev, plan, case):
 
 
 @pytest.mark.parametrize("plans", [
-    [(2, 2, 4, 2, 1), (4, 2, 8, 3, 1), (4, 4, 8, 2, 1), (4, 4, 4, 2, 1)],       # per-wave tile >= 2x2: one accumulator chain
+    [(2, 2, 4, 2, 1), (4, 2, 8, 3, 1), (4, 4, 8, 2, 1), (4, 4, 4, 2, 1), (4, 2, 4, 2, 1), (4, 2, 4, 3, 1), (2, 4, 4, 2, 1), (2, 4, 4, 3, 1)],       # per-wave tile >= 2x2: one accumulator chain
     [(2, 1, 4, 2, 1), (2, 1, 4, 3, 1), (1, 2, 4, 3, 1), (2, 2, 8, 2, 1), (2, 2, 8, 4, 1)],   # two chains
     [(1, 1, 4, 2, 1), (1, 1, 4, 4, 1)],                                         # three chains
 ])

@@ -51,7 +51,8 @@ with torch.no_grad():
     hits, engine.KEY_HITS = engine.KEY_HITS, None
     m.use_program = prog
 
-TILES = [(4, 4, 8, 2), (4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 2, 4, 2), (2, 1, 4, 2), (1, 1, 4, 2)]
+TILES = [(4, 4, 8, 2), (4, 2, 8, 3), (2, 2, 8, 4), (2, 2, 8, 2), (2, 2, 4, 2), (2, 1, 4, 2), (1, 1, 4, 2),
+         (4, 4, 4, 2), (4, 2, 4, 2), (4, 2, 4, 3), (2, 4, 4, 2), (2, 4, 4, 3)]       # round 6: the 4-wave forms with 128-wide wave tiles
 for key, n in hits.items():
     if key[0] != 'f16x3' or key not in engine._TUNED or 'lim' in key:
         continue
