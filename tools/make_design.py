@@ -236,7 +236,7 @@ issued n more times, (t_n − t_0) / n -- and workgroup residency from the kerne
 | tiles small enough to co-reside beside the 256×256 kernels (round 5) | -- | −5 %% |
 | residual groups of conv3 requested before the K loop (round 6, `res_early_ab_r06.txt`) | the residual's HBM latency in front of the epilogue | 6.45 vs 6.24 ms (−3.4 %%): the first K tile starts one HBM latency late, the 128×128 8-wave tile loses its co-resident partner |
 | re-tuning the shipped plans on the new code (round 6, `tune_from_shipped_r06.txt`) | -- | 0 of 32 shapes change |
-| 256×256 tile on four waves of 128×128 instead of eight of 64×128 (round 6, `tile_4wave_ab_r06.txt`; bit-identical) | a third of the LDS fragment reads per MFMA in the kernels that are 25 %% of the step | 6.43–6.48 vs 6.41–6.43 ms |
+| 256×256 tile on four waves of 128×128 instead of eight of 64×128 (round 6, `tile_4wave_ab_r06.txt`; bit-identical) | a third of the LDS fragment reads per MFMA in the kernels that are 25 %% of the step | 6.43–6.48 vs 6.41–6.43 ms; with the 256×128 / 128×256 four-wave forms too as candidates the in-mix tuner changes 0 of 32 plans |
 | in-launch split-K reduction (round 4), one barrier per two K tiles (round 3), non-temporal stores (rounds 3, 5) | launches / barriers / L2 pollution | slower or equal |
 
 The step does not respond to launch count, to which cache level serves a re-read, to depth, or to how the same work is cut into workgroups: it
