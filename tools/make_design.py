@@ -209,6 +209,11 @@ issued n more times, (t_n − t_0) / n -- and workgroup residency from the kerne
 
 %s
 
+The hardware's own counters agree with the stamps (`pmc_r06_f16x3_bench_sums.txt`: separate `rocprofv3 --pmc` passes, one pair at a time because the
+tool serialises kernels): `SQ_INSTS_MFMA` = the issued flops / 32768, MFMA pipe busy 0.32 of the SIMD-cycles while conv kernels run, and the conv
+engine's wave time splits 42 %% parked at `s_waitcnt` / barriers, 33 %% issue-stalled behind MFMA dependencies, 25 %% issuing (LDS issue stalls 1.7 %%, bank
+conflicts 3 %% of LDS cycles; L2 hit rate 0.84).
+
 **What bounds it: joules.**  In this regime the package sits at its limit -- 1.37–1.38 kW of 1.4 kW at 1.89–1.91 GHz over 2000 steps
 (`clocks_under_bench_r04.txt`) -- and the step is energy-additive: per-launch millijoules × launch counts give the ≈9 J per pair the mix burns
 (`energy_per_kernel_r05.txt`).  Three numbers fix the scale:
